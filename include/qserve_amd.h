@@ -1,0 +1,136 @@
+/*
+ * qserve_amd.h -- C ABI of libqserve_amd.so: MI355X (gfx950) implementation of QServe's W4A8KV4 hot path.
+ *
+ * This is the drop-in boundary.  Every entry point below is what the reference's pybind11 torch-extension
+ * functions (package `qserve_backend`, kernels/setup.py:157-245) reduce to once the torch::Tensor arguments
+ * are lowered to device pointers + sizes.  The Python package `qserve_backend/` in this repository is the
+ * host-side mirror that performs exactly that lowering (same module names, same callables, same argument
+ * order and error behaviour); INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless stated otherwise; `half` data is passed as `const void*`/`void*`
+ *     to IEEE binary16 storage (the ABI carries no torch / HIP types);
+ *   - `stream` is a hipStream_t passed as void* (NULL = legacy default stream, which is what the reference
+ *     GEMMs use: gemm_cuda.cu:53);
+ *   - return value: 0 on success, a negative QS_E* code on rejected arguments (nothing was launched),
+ *     a positive hipError_t if the launch failed.  qs_last_error() returns a thread-local message;
+ *   - nothing here allocates device memory; callers own every buffer (ownership rules of the reference,
+ *     SURVEY.md 8(b) "Conventions").
+ */
+#ifndef QSERVE_AMD_H
+#define QSERVE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QS_OK 0
+#define QS_EINVAL (-1)   /* bad shape / alignment / null pointer */
+#define QS_ENOSUP (-2)   /* combination the reference never instantiates (e.g. head_dim != 128) */
+
+typedef void* qs_stream_t;
+
+/* Library identification: version = 100*major + minor; arch string is "gfx950". */
+int qs_version(void);
+const char* qs_arch(void);
+const char* qs_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * W4A8 per-channel GEMM.
+ * Replaces qserve_backend.qgemm_w4a8_per_chn.gemm_forward_cuda
+ *   (kernels/csrc/qgemm/w4a8_per_chn/gemm_cuda.h:11, gemm_cuda.cu:596-652, pybind.cpp:13-16).
+ *   in_feats  int8  [M,K] row-major          kernel   int8 [N,K/2]  reference packed layout (w4a8_linear.py:290-322)
+ *   wscales   half  [N]                       ascales  half [M]
+ *   w_szs     half  [N]  (= zero*scale)       a_ssums  half [M]  (= sum_k x)
+ *   out_feats half  [M,N] written in place:   (float(acc)*wscale[n])*ascale[m] - w_sz[n]*a_ssum[m]
+ * Requirements: N % 64 == 0, K % 128 == 0 (the reference requires N % CTA_N, K % CTA_K; all model shapes comply).
+ * ---------------------------------------------------------------------------------------------------------- */
+int qs_w4a8_per_chn_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscales, const void* ascales,
+                         const void* w_szs, const void* a_ssums, void* out_feats, int M, int N, int K,
+                         qs_stream_t stream);
+
+/* W4A8 per-group (g128) GEMM.
+ * Replaces qserve_backend.qgemm_w4a8_per_group.gemm_forward_cuda
+ *   (kernels/csrc/qgemm/w4a8_per_group/gemm_cuda.h:11, gemm_cuda.cu:630-702).
+ *   zeros, scales_i8  int8 [K/128, N] in the reference's per-32 channel permutation (w4a8_linear.py:231-277)
+ *   out = float(acc) * (wscale[n]*ascale[m]),  acc over the level-2 dequantised int8 weights. */
+int qs_w4a8_per_group_gemm(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros,
+                           const int8_t* scales_i8, const void* wscales, const void* ascales, void* out_feats,
+                           int M, int N, int K, qs_stream_t stream);
+
+/* Debug/parity entry points: same kernels, but the raw INT32 accumulators are written to acc_out [M,N]
+ * instead of the fp16 epilogue (the reference keeps them in registers: gemm_cuda.cu:327). */
+int qs_w4a8_per_chn_gemm_acc(const int8_t* in_feats, const int8_t* kernel, int32_t* acc_out, int M, int N, int K,
+                             qs_stream_t stream);
+int qs_w4a8_per_group_gemm_acc(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros,
+                               const int8_t* scales_i8, int32_t* acc_out, int M, int N, int K, qs_stream_t stream);
+
+/* W8A8 GEMM (importable-module requirement only).
+ * Replaces qserve_backend.qgemm_w8a8.w8a8_gemm_forward_cuda (kernels/csrc/qgemm/w8a8/w8a8_gemm_cuda.h:11).
+ *   kernel int8 [N,K] row-major.  out = float(acc) * (wscale[n]*ascale[m]).  N % 16 == 0, K % 64 == 0. */
+int qs_w8a8_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscales, const void* ascales,
+                 void* out_feats, int M, int N, int K, qs_stream_t stream);
+
+/* Kernel-variant selection for benchmarking / A-B tests (process-wide; default -1 = heuristic). */
+void qs_set_gemm_variant(int variant);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Decode attention over the paged, quantised KV cache.
+ * Replaces qserve_backend.fused_attention.single_query_attention
+ *   (kernels/csrc/fused_attention/fused_attention.h:13-28, fused_attention.cpp:150-240).
+ *   q   half [B,H,Dh]   view, element strides (q_stride0, Dh, 1)
+ *   k,v half [B,Hkv,Dh] views, element strides (kv_stride0, Dh, 1)          (un-rotated new token)
+ *   kv_pointers int64 [B,2,max_blocks]: device ADDRESSES of K pages ([:,0,:]) and V pages ([:,1,:])
+ *   length_per_sample int32 [B] (may be NULL -> every sequence uses `timestep`): context length INCLUDING
+ *                     the new token
+ *   out half [B,H,Dh] contiguous (the reference returns torch::empty_like(q))
+ * Page layout (kvCacheUtils.h:47-126): [Hkv][tokens_per_block][Dh'] data, then half scale[Hkv][tpb], then
+ * half zero[Hkv][tpb]; Dh' = size_per_token / Hkv bytes.
+ * Side effect: quantises the new token's rotated K and V into the page of position length-1.
+ * Supported (what the reference instantiates): Dh = 128, tokens_per_block = 64, neox style, kv_cache_with_zeros.
+ * ---------------------------------------------------------------------------------------------------------- */
+int qs_single_query_attention(const void* q, const void* k, const void* v, const int64_t* kv_pointers,
+                              const int32_t* length_per_sample, void* out, int batch, int num_heads,
+                              int num_kv_heads, int head_dim, int64_t q_stride0, int64_t kv_stride0,
+                              int max_blocks, int memory_max_seqlen, int tokens_per_block, int size_per_token,
+                              int timestep, int rotary_embedding_dim, float rotary_base, int neox_rotary_style,
+                              int int4_kv_cache, int kv_cache_with_zeros, qs_stream_t stream);
+
+/* Prefill KV writer.  Replaces qserve_backend.fused_attention.apply_bias_rope_update_kv_cache
+ *   (kernels/csrc/fused_attention/update_kv_cache.h:11-27, update_kv_cache.cu:20-108).
+ *   qkv half [num_tokens, (H+2Hkv)*Dh] modified in place (rotated q and k are written back);
+ *   seq_lens int32 [batch]; padding_offset int32 [num_tokens]; kv_pointers as above (NULL: no cache write). */
+int qs_apply_bias_rope_update_kv_cache(void* qkv, const int32_t* seq_lens, const int32_t* padding_offset,
+                                       const int64_t* kv_pointers, int num_tokens, int batch, int max_blocks,
+                                       int head_num, int kv_head_num, int seq_len, int tokens_per_block,
+                                       int size_per_token, int rotary_embedding_dim, float rotary_embedding_base,
+                                       int rotary_embedding_max_positions, int neox_rotary_style,
+                                       int int4_kv_cache, int kv_cache_with_zeros, qs_stream_t stream);
+
+/* Replaces qserve_backend.fused_attention.compute_padding_offsets (input_metadata_helper.h:12-13). */
+int qs_compute_padding_offsets(int32_t* padding_offsets, const int32_t* cu_seqlens, int batch, int max_seqlen,
+                               qs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Activation-side kernels adjacent to the hot path (they produce the GEMM's A / ascales / a_ssums).
+ * Replace qserve_backend.fused_kernels.invoke_quant(_fuse_sum)      (kernels/csrc/fused.cpp:47-71),
+ *         qserve_backend.layernorm_ops.rms_norm(_general(_fuse_sum)) (kernels/csrc/layernorm.cpp:47-72),
+ *         qserve_backend.activation_ops.silu_and_mul                 (kernels/csrc/activation.cpp:25-39).
+ * hidden % 8 == 0 required.  `input_sum` may be NULL (non-_fuse_sum variants).
+ * ---------------------------------------------------------------------------------------------------------- */
+int qs_invoke_quant(int8_t* out, const void* input, void* input_sum, void* scale, int num_tokens, int hidden,
+                    qs_stream_t stream);
+int qs_rms_norm_general(int8_t* out, const void* input, const void* weight, void* input_sum, void* scaling,
+                        float epsilon, int num_tokens, int hidden, qs_stream_t stream);
+int qs_rms_norm(void* out, const void* input, const void* weight, float epsilon, int num_tokens, int hidden,
+                qs_stream_t stream);
+int qs_silu_and_mul(void* out, const void* input, int num_tokens, int d, qs_stream_t stream);
+/* fp16 residual add (the reference does this with a torch add, llama_w4a8_unpad.py:348,360): a += b */
+int qs_residual_add(void* a, const void* b, int64_t numel, qs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QSERVE_AMD_H */

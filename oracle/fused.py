@@ -1,0 +1,98 @@
+"""Oracle: the activation-side kernels adjacent to the hot path (they produce the GEMM's A, ascales, a_ssums).
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  numpy only.  PARITY UNPINNED by reference tests.
+
+  * invoke_quant / invoke_quant_fuse_sum ... kernels/csrc/fused_kernels.cu:52-137
+  * rms_norm_general(_fuse_sum) ............ kernels/csrc/layernorm_kernels.cu:20-29, 189-326, 427-508
+        NOTE: despite the name this is TRT-LLM's mean-subtracting generalLayerNorm
+        with beta = nullptr; reproduced as is.
+  * rms_norm ............................... kernels/csrc/layernorm_kernels.cu:330-362
+  * silu_and_mul ........................... kernels/csrc/activation_kernels.cu:7-30
+
+Each function returns the exact integer outputs plus `pre`, the fp32 value that was rounded to int8,
+so that tests can exclude exact-tie cases whose rounding depends on fp32 summation order.
+"""
+import numpy as np
+
+
+def rni_sat_s8(x):
+    """cvt.rni.sat.s8.f32 (utils.cuh:79-84)."""
+    r = np.rint(np.nan_to_num(np.asarray(x, np.float32), nan=0.0, posinf=127.0, neginf=-128.0))
+    return np.clip(r, -128, 127).astype(np.int8)
+
+
+def quant_per_token(x, with_sum=False):
+    """fused_kernels.cu:58-82 / :106-130: amax over the row (fp32), scale = half_rn(amax/127),
+    q = rni_sat_s8(x * (127/amax)) with the UNROUNDED fp32 amax, sum = half_rn(fp32 row sum)."""
+    xf = np.asarray(x, np.float16).astype(np.float32)
+    amax = np.abs(xf).max(axis=-1)
+    scale = (amax / np.float32(127.0)).astype(np.float32).astype(np.float16)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tmp = (np.float32(127.0) / amax).astype(np.float32)
+        pre = (xf * tmp[..., None]).astype(np.float32)
+    q = rni_sat_s8(pre)
+    if with_sum:
+        s = xf.sum(axis=-1, dtype=np.float64).astype(np.float32).astype(np.float16)
+        return q, scale, s, pre
+    return q, scale, pre
+
+
+def _threads_for(hidden):
+    b = min(hidden, 1024)
+    return 32 * ((b + 31) // 32)   # layernorm_kernels.cu:436-437
+
+
+def rms_norm_general(x, gamma, eps, with_sum=False):
+    """generalLayerNorm(_fuse_sum), per-token dynamic scaling branch (layernorm_kernels.cu:207-326).
+
+    mean = sum(x)/H; var = sum((x-mean)^2)/H; rstd = rsqrt(var+eps);
+    val  = half_rn((x-mean)*rstd*gamma)         (compute_layernorm in fp32, cast to T=half)
+    amax = max(|val|, 1e-6) kept in half; sum accumulated PER THREAD in a half variable over that thread's
+    strided elements, then reduced over the block in fp32 (:275,:286) and stored as half;
+    q = rni_sat_s8( ((x-mean)*rstd*gamma) * (127/amax) )  - the un-rounded fp32 value is re-computed (:312);
+    scale = half_rn(amax/127).
+    """
+    xf = np.asarray(x, np.float16).astype(np.float32)
+    g = np.asarray(gamma, np.float16).astype(np.float32)
+    T, H = xf.shape
+    mean = (xf.sum(axis=-1, dtype=np.float64) / H).astype(np.float32)
+    diff = (xf - mean[:, None]).astype(np.float32)
+    var = ((diff.astype(np.float64) ** 2).sum(axis=-1) / H).astype(np.float32)
+    rstd = (np.float32(1.0) / np.sqrt((var + np.float32(eps)).astype(np.float32))).astype(np.float32)
+    valf = ((diff * rstd[:, None]).astype(np.float32) * g[None, :]).astype(np.float32)
+    val16 = valf.astype(np.float16)
+    amax = np.maximum(np.abs(val16).max(axis=-1), np.float16(1e-6)).astype(np.float32)
+    scale = (amax / np.float32(127.0)).astype(np.float32).astype(np.float16)
+    dyn = (np.float32(127.0) / amax).astype(np.float32)
+    pre = (valf * dyn[:, None]).astype(np.float32)
+    q = rni_sat_s8(pre)
+    if not with_sum:
+        return q, scale, pre
+    nt = _threads_for(H)
+    part = np.zeros((T, nt), np.float16)
+    for i0 in range(0, H, nt):                         # thread t adds element i0+t, rounding to half each time
+        seg = val16[:, i0:i0 + nt].astype(np.float32)
+        w = seg.shape[1]
+        part[:, :w] = (part[:, :w].astype(np.float32) + seg).astype(np.float16)
+    s = part.astype(np.float64).sum(axis=-1).astype(np.float32).astype(np.float16)
+    return q, scale, s, pre
+
+
+def rms_norm(x, weight, eps):
+    """rms_norm_kernel<use_quant=false> (layernorm_kernels.cu:330-362): out = half(x*rstd) * weight (half mul)."""
+    xf = np.asarray(x, np.float16).astype(np.float32)
+    H = xf.shape[-1]
+    var = ((xf.astype(np.float64) ** 2).sum(axis=-1) / H).astype(np.float32)
+    rstd = (np.float32(1.0) / np.sqrt((var + np.float32(eps)).astype(np.float32))).astype(np.float32)
+    t = (xf * rstd[..., None]).astype(np.float32).astype(np.float16)
+    return (t.astype(np.float32) * np.asarray(weight, np.float16).astype(np.float32)).astype(np.float16)
+
+
+def silu_and_mul(x):
+    """activation_kernels.cu:9-30: out = half( half(x/(1+exp(-x))) * y ), x = in[:, :d], y = in[:, d:]."""
+    xin = np.asarray(x, np.float16)
+    d = xin.shape[-1] // 2
+    a = xin[..., :d].astype(np.float32)
+    b = xin[..., d:].astype(np.float32)
+    s = (a / (np.float32(1.0) + np.exp(-a).astype(np.float32))).astype(np.float32).astype(np.float16)
+    return (s.astype(np.float32) * b).astype(np.float32).astype(np.float16)

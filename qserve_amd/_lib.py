@@ -1,0 +1,57 @@
+"""ctypes binding of libqserve_amd.so -- the C ABI declared in include/qserve_amd.h.
+
+The product path has NO fallback: if the shared library is missing or fails to load, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqserve_amd.so")
+
+# name -> (restype, argtypes); must list every symbol of include/qserve_amd.h (tests/test_abi.py checks that)
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+SIGNATURES = {
+    "qs_version": (_i, []),
+    "qs_arch": (C.c_char_p, []),
+    "qs_last_error": (C.c_char_p, []),
+    "qs_w4a8_per_chn_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "qs_w4a8_per_group_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "qs_w4a8_per_chn_gemm_acc": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "qs_w4a8_per_group_gemm_acc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "qs_w8a8_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "qs_set_gemm_variant": (None, [_i]),
+    "qs_single_query_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _i, _i, _i, _i,
+                                       _i, _f, _i, _i, _i, _vp]),
+    "qs_apply_bias_rope_update_kv_cache": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i,
+                                                _i, _i, _vp]),
+    "qs_compute_padding_offsets": (_i, [_vp, _vp, _i, _i, _vp]),
+    "qs_invoke_quant": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "qs_rms_norm_general": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
+    "qs_rms_norm": (_i, [_vp, _vp, _vp, _f, _i, _i, _vp]),
+    "qs_silu_and_mul": (_i, [_vp, _vp, _i, _i, _vp]),
+    "qs_residual_add": (_i, [_vp, _vp, _i64, _vp]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m qserve_amd.build` (hipcc --offload-arch=gfx950). "
+            "qserve_amd has no CPU / PyTorch fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    """0 -> ok; otherwise raise RuntimeError like the reference's TORCH_CHECK does."""
+    if rc != 0:
+        msg = lib.qs_last_error()
+        raise RuntimeError(f"{what}: {msg.decode() if msg else 'error'} (code {rc})")

@@ -1,0 +1,73 @@
+"""Build libqserve_amd.so (hand-written HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+    python -m qserve_amd.build [--force] [--debug-asm]
+
+hipcc cross-compiles without a GPU, so this runs in the authoring container as well as on the MI355X box.
+The .so lands in qserve_amd/ (git-ignored, but shipped to the GPU box by gpurun).
+"""
+import argparse
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+BUILD = os.path.join(HERE, "_build")
+LIB = os.path.join(HERE, "libqserve_amd.so")
+SOURCES = ["lib.hip", "gemm_w4a8.hip", "gemm_w8a8.hip", "attention.hip", "fused_small.hip"]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found (need ROCm >= 7.0 with the gfx950 target)")
+    return exe
+
+
+def _deps_mtime():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "qserve_amd.h"))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def _compile(src, force, extra):
+    obj = os.path.join(BUILD, src.replace(".hip", ".o"))
+    srcp = os.path.join(CSRC, src)
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), _deps_mtime())):
+        return obj, False
+    cmd = [hipcc(), *FLAGS, *extra, "-c", srcp, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+    return obj, True
+
+
+def build(force=False, verbose=True, extra=()):
+    os.makedirs(BUILD, exist_ok=True)
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        res = list(ex.map(lambda s: _compile(s, force, list(extra)), SOURCES))
+    objs = [o for o, _ in res]
+    rebuilt = any(r for _, r in res)
+    if rebuilt or not os.path.exists(LIB) or force:
+        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+        if verbose:
+            print(f"[qserve_amd.build] linked {LIB}")
+    elif verbose:
+        print(f"[qserve_amd.build] up to date: {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    a = ap.parse_args()
+    build(force=a.force)
+    sys.exit(0)

@@ -1,0 +1,64 @@
+// common.h -- shared helpers for the gfx950 kernels of libqserve_amd.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/qserve_amd.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32;
+
+void qs_set_error(const char* fmt, ...);
+
+#define QS_REQUIRE(cond, ...)             \
+    do {                                  \
+        if (!(cond)) {                    \
+            qs_set_error(__VA_ARGS__);    \
+            return QS_EINVAL;             \
+        }                                 \
+    } while (0)
+
+static inline int qs_launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        qs_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return QS_OK;
+}
+
+// wave64 reductions -------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// cvt.rni.sat.{s8,u8}.f32 equivalents: round-to-nearest-even then saturate (NaN -> 0)
+__device__ __forceinline__ int rni_sat_s8(float x) {
+    float r = rintf(x);
+    r = fminf(fmaxf(r, -128.f), 127.f);   // fmaxf/fminf drop NaN -> -128 ; handle below
+    return (x != x) ? 0 : (int)r;
+}
+__device__ __forceinline__ unsigned rni_sat_u8(float x) {
+    float r = rintf(x);
+    r = fminf(fmaxf(r, 0.f), 255.f);
+    return (x != x) ? 0u : (unsigned)r;
+}

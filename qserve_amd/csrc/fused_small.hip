@@ -1,0 +1,237 @@
+// fused_small.hip -- activation-side kernels adjacent to the W4A8 GEMMs (they produce A / ascales / a_ssums).
+//
+// Behaviour follows (not code):
+//   invoke_quant(_fuse_sum) ......... kernels/csrc/fused_kernels.cu:52-137
+//   rms_norm_general(_fuse_sum) ..... kernels/csrc/layernorm_kernels.cu:20-29,189-326,427-508  (mean-subtracting
+//                                     generalLayerNorm with beta = nullptr, per-token dynamic int8 scaling)
+//   rms_norm ........................ kernels/csrc/layernorm_kernels.cu:330-362
+//   silu_and_mul .................... kernels/csrc/activation_kernels.cu:7-30
+// HBM-bound row kernels: one 256-thread workgroup per token, 16-byte (8 x fp16) accesses, wave64 shuffles +
+// one LDS hop for the block reductions.  hidden % 8 == 0.
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+__device__ __forceinline__ float block_reduce(float v, float* sm, int op) {
+    // op 0 = sum, 1 = max ; returns the result to every thread
+    v = op == 0 ? wave_sum(v) : wave_max(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();   // protect sm reuse
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    float r = sm[0];
+#pragma unroll
+    for (int w = 1; w < TPB / 64; ++w) r = op == 0 ? r + sm[w] : fmaxf(r, sm[w]);
+    return r;
+}
+
+__device__ __forceinline__ h8 load8(const _Float16* p) { return *reinterpret_cast<const h8*>(p); }
+
+__device__ __forceinline__ void store_q8(int8_t* p, const float (&v)[8], float mul) {
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        lo |= ((unsigned)rni_sat_s8(v[j] * mul) & 0xFFu) << (8 * j);
+        hi |= ((unsigned)rni_sat_s8(v[4 + j] * mul) & 0xFFu) << (8 * j);
+    }
+    *reinterpret_cast<uint2*>(p) = make_uint2(lo, hi);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void quant_kernel(int8_t* __restrict__ out, const _Float16* __restrict__ in,
+                                                    __half* __restrict__ sum_out, __half* __restrict__ scale_out,
+                                                    int hidden) {
+    __shared__ float sm[TPB / 64];
+    const size_t base = (size_t)blockIdx.x * hidden;
+    float amax = 0.f, sum = 0.f;
+    for (int i = threadIdx.x * 8; i < hidden; i += TPB * 8) {
+        h8 v = load8(in + base + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = (float)v[j];
+            sum += f;
+            amax = fmaxf(amax, fabsf(f));
+        }
+    }
+    amax = block_reduce(amax, sm, 1);
+    if (sum_out) sum = block_reduce(sum, sm, 0);
+    if (threadIdx.x == 0) {
+        scale_out[blockIdx.x] = __float2half_rn(amax / 127.0f);          // fused_kernels.cu:72
+        if (sum_out) sum_out[blockIdx.x] = __float2half_rn(sum);         // :121
+    }
+    const float mul = 127.0f / amax;                                     // :78 (unrounded fp32 amax)
+    for (int i = threadIdx.x * 8; i < hidden; i += TPB * 8) {
+        h8 v = load8(in + base + i);
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
+        store_q8(out + base + i, f, mul);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ln_val(float x, float mean, float rstd, float g) {
+#pragma clang fp contract(off)
+    return (x - mean) * rstd * g;                                        // layernorm_kernels.cu:23
+}
+
+__global__ __launch_bounds__(TPB) void general_norm_quant_kernel(int8_t* __restrict__ out,
+                                                                 const _Float16* __restrict__ in,
+                                                                 const _Float16* __restrict__ gamma,
+                                                                 __half* __restrict__ sum_out,
+                                                                 __half* __restrict__ scale_out, float eps,
+                                                                 int hidden) {
+    __shared__ float sm[TPB / 64];
+    const size_t base = (size_t)blockIdx.x * hidden;
+    float s = 0.f;
+    for (int i = threadIdx.x * 8; i < hidden; i += TPB * 8) {
+        h8 v = load8(in + base + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (float)v[j];
+    }
+    const float mean = block_reduce(s, sm, 0) / hidden;                  // :248
+    float vs = 0.f;
+    for (int i = threadIdx.x * 8; i < hidden; i += TPB * 8) {
+        h8 v = load8(in + base + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float d = (float)v[j] - mean;
+            vs += d * d;
+        }
+    }
+    const float rstd_e = 1.0f / sqrtf(block_reduce(vs, sm, 0) / hidden + eps);   // :271 (rsqrtf there)
+    float amax = (float)(_Float16)1e-6f, sum = 0.f;                      // :285-286 (amax, sum start values)
+    for (int i = threadIdx.x * 8; i < hidden; i += TPB * 8) {
+        h8 v = load8(in + base + i);
+        h8 g = load8(gamma + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 hv = (_Float16)ln_val((float)v[j], mean, rstd_e, (float)g[j]);   // cast to T = half, :292
+            amax = fmaxf(amax, fabsf((float)hv));
+            sum += (float)hv;
+        }
+    }
+    amax = block_reduce(amax, sm, 1);
+    if (sum_out) sum = block_reduce(sum, sm, 0);
+    const float mul = 127.f / amax;                                      // :308
+    for (int i = threadIdx.x * 8; i < hidden; i += TPB * 8) {
+        h8 v = load8(in + base + i);
+        h8 g = load8(gamma + i);
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = ln_val((float)v[j], mean, rstd_e, (float)g[j]);   // fp32, :315
+        store_q8(out + base + i, f, mul);
+    }
+    if (threadIdx.x == 0) {
+        scale_out[blockIdx.x] = __float2half_rn(amax / 127.f);           // :322
+        if (sum_out) sum_out[blockIdx.x] = __float2half_rn(sum);         // :323
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void rms_norm_kernel(_Float16* __restrict__ out, const _Float16* __restrict__ in,
+                                                       const _Float16* __restrict__ w, float eps, int hidden) {
+    __shared__ float sm[TPB / 64];
+    const size_t base = (size_t)blockIdx.x * hidden;
+    float vs = 0.f;
+    for (int i = threadIdx.x * 8; i < hidden; i += TPB * 8) {
+        h8 v = load8(in + base + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vs += (float)v[j] * (float)v[j];
+    }
+    const float rstd = 1.0f / sqrtf(block_reduce(vs, sm, 0) / hidden + eps);   // :347
+    for (int i = threadIdx.x * 8; i < hidden; i += TPB * 8) {
+        h8 v = load8(in + base + i);
+        h8 g = load8(w + i);
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 t = (_Float16)((float)v[j] * rstd);                 // (scalar_t)(x * s_variance), :358
+            o[j] = (_Float16)((float)t * (float)g[j]);                   // half * half
+        }
+        *reinterpret_cast<h8*>(out + base + i) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void silu_and_mul_kernel(_Float16* __restrict__ out,
+                                                           const _Float16* __restrict__ in, int d) {
+    const size_t ib = (size_t)blockIdx.x * 2 * d, ob = (size_t)blockIdx.x * d;
+    for (int i = threadIdx.x * 8; i < d; i += TPB * 8) {
+        h8 x = load8(in + ib + i);
+        h8 y = load8(in + ib + d + i);
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xf = (float)x[j];
+            _Float16 s = (_Float16)(xf / (1.0f + expf(-xf)));            // activation_kernels.cu:11
+            o[j] = (_Float16)((float)s * (float)y[j]);
+        }
+        *reinterpret_cast<h8*>(out + ob + i) = o;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void residual_add_kernel(_Float16* __restrict__ a, const _Float16* __restrict__ b,
+                                                           int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n8; i += (int64_t)gridDim.x * TPB) {
+        h8 x = reinterpret_cast<const h8*>(a)[i];
+        h8 y = reinterpret_cast<const h8*>(b)[i];
+        reinterpret_cast<h8*>(a)[i] = x + y;
+    }
+}
+
+}  // namespace
+
+extern "C" int qs_invoke_quant(int8_t* out, const void* input, void* input_sum, void* scale, int num_tokens,
+                               int hidden, qs_stream_t stream) {
+    QS_REQUIRE(out && input && scale, "invoke_quant: null pointer");
+    QS_REQUIRE(hidden > 0 && hidden % 8 == 0, "invoke_quant: hidden=%d must be a positive multiple of 8", hidden);
+    if (num_tokens <= 0) return QS_OK;
+    hipLaunchKernelGGL(quant_kernel, dim3(num_tokens), dim3(TPB), 0, (hipStream_t)stream, out,
+                       (const _Float16*)input, (__half*)input_sum, (__half*)scale, hidden);
+    return qs_launch_status("invoke_quant");
+}
+
+extern "C" int qs_rms_norm_general(int8_t* out, const void* input, const void* weight, void* input_sum, void* scaling,
+                                   float epsilon, int num_tokens, int hidden, qs_stream_t stream) {
+    QS_REQUIRE(out && input && weight && scaling, "rms_norm_general: null pointer");
+    QS_REQUIRE(hidden > 0 && hidden % 8 == 0, "rms_norm_general: hidden=%d must be a positive multiple of 8", hidden);
+    if (num_tokens <= 0) return QS_OK;
+    hipLaunchKernelGGL(general_norm_quant_kernel, dim3(num_tokens), dim3(TPB), 0, (hipStream_t)stream, out,
+                       (const _Float16*)input, (const _Float16*)weight, (__half*)input_sum, (__half*)scaling, epsilon,
+                       hidden);
+    return qs_launch_status("rms_norm_general");
+}
+
+extern "C" int qs_rms_norm(void* out, const void* input, const void* weight, float epsilon, int num_tokens, int hidden,
+                           qs_stream_t stream) {
+    QS_REQUIRE(out && input && weight, "rms_norm: null pointer");
+    QS_REQUIRE(hidden > 0 && hidden % 8 == 0, "rms_norm: hidden=%d must be a positive multiple of 8", hidden);
+    if (num_tokens <= 0) return QS_OK;
+    hipLaunchKernelGGL(rms_norm_kernel, dim3(num_tokens), dim3(TPB), 0, (hipStream_t)stream, (_Float16*)out,
+                       (const _Float16*)input, (const _Float16*)weight, epsilon, hidden);
+    return qs_launch_status("rms_norm");
+}
+
+extern "C" int qs_silu_and_mul(void* out, const void* input, int num_tokens, int d, qs_stream_t stream) {
+    QS_REQUIRE(out && input, "silu_and_mul: null pointer");
+    QS_REQUIRE(d > 0 && d % 8 == 0, "silu_and_mul: d=%d must be a positive multiple of 8", d);
+    if (num_tokens <= 0) return QS_OK;
+    hipLaunchKernelGGL(silu_and_mul_kernel, dim3(num_tokens), dim3(TPB), 0, (hipStream_t)stream, (_Float16*)out,
+                       (const _Float16*)input, d);
+    return qs_launch_status("silu_and_mul");
+}
+
+extern "C" int qs_residual_add(void* a, const void* b, int64_t numel, qs_stream_t stream) {
+    QS_REQUIRE(a && b, "residual_add: null pointer");
+    QS_REQUIRE(numel % 8 == 0, "residual_add: numel must be a multiple of 8");
+    if (numel <= 0) return QS_OK;
+    const int64_t n8 = numel / 8;
+    int blocks = (int)((n8 + TPB - 1) / TPB);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(residual_add_kernel, dim3(blocks), dim3(TPB), 0, (hipStream_t)stream, (_Float16*)a,
+                       (const _Float16*)b, n8);
+    return qs_launch_status("residual_add");
+}

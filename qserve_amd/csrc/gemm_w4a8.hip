@@ -1,0 +1,280 @@
+// gemm_w4a8.hip -- W4A8 GEMMs for MI355X (gfx950): int8 activations x uint4 weights -> int32 (MFMA) -> fp16.
+//
+// Replaces (behaviour, not code) the reference kernels
+//   kernels/csrc/qgemm/w4a8_per_chn/gemm_cuda.cu:303-594   (per-channel; zero point folded into the epilogue)
+//   kernels/csrc/qgemm/w4a8_per_group/gemm_cuda.cu:328-628 (per-group-128; level-2 dequant u4 -> s8 in registers)
+// and consumes the reference's packed `qweight` layout as is (w4a8_linear.py:196-226):
+//   bytes [N/32][K/32][lane 32][16];  lane = c*4+e;  byte t = d*8+b*4+f;
+//   low nibble  = W[32*n32 + 8b + c      ][32*k32 + 16d + 4e + f]
+//   high nibble = W[32*n32 + 8b + c + 16 ][ same ]
+// i.e. the 64 contiguous bytes at tile*512 + c*64 hold, for the four rows {c, 8+c, 16+c, 24+c} of the tile, all
+// 32 k of the tile; dword e of {bytes 0-3 | 4-7 | 8-11 | 12-15} of chunk e = k {4e..4e+3} (+16 for bytes 8-15) of
+// rows {c | 8+c} (low nibble) and {16+c | 24+c} (high nibble).
+//
+// CDNA4 mapping (this is NOT the reference's mma.m16n8k32 lane scheme):
+//   v_mfma_i32_16x16x64_i8:  D[i][j] += sum_k A[i][k] B[k][j];  lane l supplies A[i=l&15][16 k of group g=l>>4] and
+//   B[same 16 k][j=l&15] and receives D[i=4g+r][j=l&15], r=0..3.
+//   * A operand = WEIGHTS.  MFMA row i <-> (tile select tsel=i>>3, c=i&7) of a 64-row "unit" (two n32 tiles);
+//     lane (i,g) owns the 64-byte c-row of tile (T0+tsel, k32 = 4*kstep+g).  From those 64 bytes it builds, with
+//     AND / shift only, eight operands: 4 row classes (x-lo, y-lo, x-hi, y-hi = rows c, 8+c, 16+c, 24+c) x 2 k-halves
+//     (bytes 0-7 / 8-15 of every chunk).  Operand byte p=4e+f <-> k = 32*k32 + 16h + p: 16 CONTIGUOUS k, so
+//   * B operand = ACTIVATIONS: lane (m=l&15, g) needs act[m][128*kstep + 32g + 16h .. +16]: plain 16-byte loads,
+//     16 rows x 128 contiguous bytes per instruction.
+//   * one k-step = 128 k = exactly one quantisation group: per-group scales/zeros are one dword per lane per step.
+//   * accumulator (mt, cls)[r] of lane (m,g) is out[m0+16mt+m][32*(T0+(g>>1)) + 8cls + 4(g&1) + r]: four
+//     consecutive channels -> one 8-byte fp16x4 store.
+//   Integer accumulation is exact, so any consistent k-permutation is legal; the one above needs no cross-lane
+//   movement at all.
+//
+// Kernel `w4a8_gemm_splitk`: one workgroup = NW waves that all own the same 64 output channels and (16*MT) tokens and
+// split K between them (k-steps interleaved); partial int32 tiles are reduced through LDS and the fp32 epilogue is
+// fused.  This is the decode-shape kernel (M <= 128: weight-streaming, HBM-bound; every weight byte is read once).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ u32 vadd4(u32 a, u32 b) {
+    // per-byte wrapping add (__vadd4 semantics, per_group/gemm_cuda.cu:302)
+    return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
+}
+
+template <int MODE>
+__device__ __forceinline__ u32 unpack_lo(u32 raw, u32 s, u32 zb) {
+    u32 u = raw & 0x0F0F0F0Fu;
+    if (MODE == 1) u = vadd4(u * s, zb);   // 32-bit multiply, byte carries as in the reference (:300-301)
+    return u;
+}
+template <int MODE>
+__device__ __forceinline__ u32 unpack_hi(u32 raw, u32 s, u32 zb) {
+    u32 u = (raw >> 4) & 0x0F0F0F0Fu;
+    if (MODE == 1) u = vadd4(u * s, zb);
+    return u;
+}
+
+// fp32 epilogues with the reference's evaluation order and NO fma contraction (oracle/w4a8.py epilogue_*).
+__device__ __forceinline__ float epi_per_chn(int acc, float ws, float sa, float wz, float ss) {
+#pragma clang fp contract(off)
+    float t = (float)acc * ws;   // per_chn/gemm_cuda.cu:586
+    t = t * sa;
+    const float u = wz * ss;
+    return t - u;
+}
+__device__ __forceinline__ float epi_per_group(int acc, float ws, float sa) {
+#pragma clang fp contract(off)
+    const float sc = ws * sa;    // per_group/gemm_cuda.cu:620
+    return (float)acc * sc;
+}
+
+// MODE 0 = per-channel, 1 = per-group(128).  OUTK 0 = fp16 epilogue, 1 = raw int32 accumulators.
+template <int MT, int MODE, int OUTK>
+__global__ __launch_bounds__(512) void w4a8_gemm_splitk(const int8_t* __restrict__ A, const uint8_t* __restrict__ W,
+                                                        const int8_t* __restrict__ zeros,
+                                                        const int8_t* __restrict__ scales8,
+                                                        const __half* __restrict__ wscales,
+                                                        const __half* __restrict__ ascales,
+                                                        const __half* __restrict__ wszs,
+                                                        const __half* __restrict__ assums, void* __restrict__ out,
+                                                        int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) int red[];   // [NW][MT*16][64]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = blockDim.x >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int tsel = li >> 3, c = li & 7;
+    const int T0 = blockIdx.x * 2;
+    const int m0 = blockIdx.y * (16 * MT);
+    const int KT = K >> 5;
+    const int nsteps = K >> 7;
+
+    const uint8_t* wrow = W + ((size_t)(T0 + tsel) * KT) * 512 + c * 64 + (size_t)g * 512;
+    const int8_t* arow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int row = m0 + 16 * mt + li;
+        row = row < M ? row : M - 1;
+        arow[mt] = A + (size_t)row * K + 32 * g;
+    }
+    const int meta_off = (T0 + tsel) * 32 + c * 4;   // per-group scale / zero dword of this lane's 4 row classes
+
+    v4i acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl) acc[mt][cl] = (v4i){0, 0, 0, 0};
+
+    for (int ks = wave; ks < nsteps; ks += NW) {
+        const uint4* wp = reinterpret_cast<const uint4*>(wrow + (size_t)ks * 2048);
+        uint4 ch[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ch[e] = wp[e];
+        v4i b[MT][2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const v4i* ap = reinterpret_cast<const v4i*>(arow[mt] + (size_t)ks * 128);
+            b[mt][0] = ap[0];
+            b[mt][1] = ap[1];
+        }
+        u32 sdw = 0, zdw = 0;
+        if (MODE == 1) {
+            sdw = *reinterpret_cast<const u32*>(scales8 + (size_t)ks * N + meta_off);
+            zdw = *reinterpret_cast<const u32*>(zeros + (size_t)ks * N + meta_off);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32 rx[4], ry[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                rx[e] = h ? ch[e].z : ch[e].x;
+                ry[e] = h ? ch[e].w : ch[e].y;
+            }
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl) {
+                u32 s = 0, zb = 0;
+                if (MODE == 1) {
+                    s = (sdw >> (8 * cl)) & 0xFFu;
+                    zb = ((zdw >> (8 * cl)) & 0xFFu) * 0x01010101u;
+                }
+                v4i a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const u32 raw = (cl & 1) ? ry[e] : rx[e];
+                    a[e] = (int)((cl & 2) ? unpack_hi<MODE>(raw, s, zb) : unpack_lo<MODE>(raw, s, zb));
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][cl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b[mt][h], acc[mt][cl], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- cross-wave (split-K) reduction through LDS; wave w finalises pairs p = w, w+NW, ...
+    constexpr int NP = MT * 4;
+    if (NW > 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(wave * NP * 4 + (mt * 4 + cl) * 4 + r) * 64 + lane] = acc[mt][cl][r];
+        __syncthreads();
+    }
+    const int ncol0 = 32 * (T0 + (g >> 1)) + 4 * (g & 1);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl) {
+            const int p = mt * 4 + cl;
+            if (NW > 1 && (p % NW) != wave) continue;
+            v4i s = acc[mt][cl];
+            if (NW > 1) {
+                s = (v4i){0, 0, 0, 0};
+                for (int w = 0; w < NW; ++w)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[r] += red[(w * NP * 4 + p * 4 + r) * 64 + lane];
+            }
+            const int m = m0 + 16 * mt + li;
+            const int n = ncol0 + 8 * cl;
+            if (m < M) {
+                if (OUTK == 1) {
+                    *reinterpret_cast<v4i*>(reinterpret_cast<int*>(out) + (size_t)m * N + n) = s;
+                } else {
+                    h4 o;
+                    const float sa = __half2float(ascales[m]);
+                    if (MODE == 0) {
+                        const float ss = __half2float(assums[m]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            o[r] = (_Float16)epi_per_chn(s[r], __half2float(wscales[n + r]), sa,
+                                                         __half2float(wszs[n + r]), ss);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            o[r] = (_Float16)epi_per_group(s[r], __half2float(wscales[n + r]), sa);
+                    }
+                    *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(out) + (size_t)m * N + n) = o;
+                }
+            }
+        }
+    }
+}
+
+int g_variant = -1;
+
+template <int MT, int MODE, int OUTK>
+int launch_splitk(const int8_t* A, const uint8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
+                  const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K, int NW,
+                  hipStream_t stream) {
+    auto kern = w4a8_gemm_splitk<MT, MODE, OUTK>;
+    const size_t smem = NW > 1 ? (size_t)NW * MT * 16 * 64 * sizeof(int) : 0;
+    static size_t configured = 0;   // per instantiation
+    if (smem > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) {
+            qs_set_error("w4a8 gemm: cannot reserve %zu bytes of LDS: %s", smem, hipGetErrorString(e));
+            return (int)e;
+        }
+        configured = smem;
+    }
+    dim3 grid(N / 64, (M + 16 * MT - 1) / (16 * MT));
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, stream, A, W, zeros, scales8,
+                       reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
+                       reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K);
+    return qs_launch_status("w4a8 gemm");
+}
+
+template <int MODE, int OUTK>
+int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
+             const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K,
+             qs_stream_t stream_) {
+    QS_REQUIRE(A && W && out, "w4a8 gemm: null pointer");
+    QS_REQUIRE(M >= 0 && N > 0 && K > 0, "w4a8 gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    QS_REQUIRE(N % 64 == 0, "w4a8 gemm: N=%d must be a multiple of 64", N);
+    QS_REQUIRE(K % 128 == 0, "w4a8 gemm: K=%d must be a multiple of 128", K);
+    if (OUTK == 0) QS_REQUIRE(wscales && ascales, "w4a8 gemm: null scale pointer");
+    if (MODE == 0 && OUTK == 0) QS_REQUIRE(wszs && assums, "w4a8 per-channel gemm: null w_szs / a_ssums");
+    if (MODE == 1) QS_REQUIRE(zeros && scales8, "w4a8 per-group gemm: null zeros / scales_i8");
+    if (M == 0) return QS_OK;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const uint8_t* Wu = reinterpret_cast<const uint8_t*>(W);
+    const int nsteps = K / 128;
+    int NW = nsteps >= 8 ? 8 : (nsteps >= 4 ? 4 : (nsteps >= 2 ? 2 : 1));
+    if (g_variant >= 100) NW = g_variant - 100 > nsteps ? nsteps : g_variant - 100;   // A/B: force wave count
+    if (M <= 16) return launch_splitk<1, MODE, OUTK>(A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, NW, stream);
+    if (M <= 32) return launch_splitk<2, MODE, OUTK>(A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, NW, stream);
+    if (M <= 48) return launch_splitk<3, MODE, OUTK>(A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, NW, stream);
+    if (NW > 4) NW = 4;   // LDS: NW*MT*4 KiB
+    return launch_splitk<4, MODE, OUTK>(A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, NW, stream);
+}
+
+}  // namespace
+
+extern "C" void qs_set_gemm_variant(int variant) { g_variant = variant; }
+
+extern "C" int qs_w4a8_per_chn_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscales,
+                                    const void* ascales, const void* w_szs, const void* a_ssums, void* out_feats,
+                                    int M, int N, int K, qs_stream_t stream) {
+    return dispatch<0, 0>(in_feats, kernel, nullptr, nullptr, wscales, ascales, w_szs, a_ssums, out_feats, M, N, K,
+                          stream);
+}
+
+extern "C" int qs_w4a8_per_group_gemm(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros,
+                                      const int8_t* scales_i8, const void* wscales, const void* ascales,
+                                      void* out_feats, int M, int N, int K, qs_stream_t stream) {
+    return dispatch<1, 0>(in_feats, kernel, zeros, scales_i8, wscales, ascales, nullptr, nullptr, out_feats, M, N, K,
+                          stream);
+}
+
+extern "C" int qs_w4a8_per_chn_gemm_acc(const int8_t* in_feats, const int8_t* kernel, int32_t* acc_out, int M, int N,
+                                        int K, qs_stream_t stream) {
+    return dispatch<0, 1>(in_feats, kernel, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, acc_out, M, N, K,
+                          stream);
+}
+
+extern "C" int qs_w4a8_per_group_gemm_acc(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros,
+                                          const int8_t* scales_i8, int32_t* acc_out, int M, int N, int K,
+                                          qs_stream_t stream) {
+    return dispatch<1, 1>(in_feats, kernel, zeros, scales_i8, nullptr, nullptr, nullptr, nullptr, acc_out, M, N, K,
+                          stream);
+}

@@ -1,0 +1,201 @@
+"""One decode step of a Llama-style W4A8KV4 model expressed with the `qserve_backend` ops -- the bench / smoke driver.
+
+It issues exactly the op sequence of the reference's model code for `is_prompt=False`
+(qserve/modeling/models/llama_w4a8_unpad.py:185-291, 330-361, 69-93):
+
+    rms_norm_general_fuse_sum -> qkv GEMM -> single_query_attention -> invoke_quant_fuse_sum -> o_proj GEMM
+    -> residual add -> rms_norm_general_fuse_sum -> gate_up GEMM -> silu_and_mul -> invoke_quant_fuse_sum
+    -> down GEMM -> residual add;   then rms_norm, fp16 lm_head, greedy sampling.
+
+Weights are synthetic (random packed nibbles / scales of the right shapes, distinct per layer so nothing is
+served from cache); the KV cache is filled by the prefill writer.  Tensor parallelism: rank r owns
+H/tp query heads, Hkv/tp KV heads and the matching column / row shards; the partial outputs of o_proj and
+down_proj are summed with one RCCL all-reduce each.
+"""
+import torch
+
+import qserve_backend.activation_ops as activation_ops
+import qserve_backend.fused_attention as fused_attention
+import qserve_backend.fused_kernels as fused_kernels
+import qserve_backend.layernorm_ops as layernorm_ops
+import qserve_backend.qgemm_w4a8_per_chn as gemm_chn
+import qserve_backend.qgemm_w4a8_per_group as gemm_grp
+
+from . import tp as tpmod
+
+LLAMA3_8B = dict(name="Llama-3-8B", hidden=4096, heads=32, kv_heads=8, inter=14336, layers=32, vocab=128256,
+                 rope_theta=5e5, eps=1e-5)
+QWEN15_72B = dict(name="Qwen1.5-72B", hidden=8192, heads=64, kv_heads=64, inter=24576, layers=80, vocab=152064,
+                  rope_theta=1e6, eps=1e-6)
+TINY = dict(name="tiny-llama", hidden=256, heads=4, kv_heads=2, inter=512, layers=2, vocab=512, rope_theta=1e4,
+            eps=1e-5)
+
+
+class W4A8Linear:
+    """Synthetic stand-in for W4A8OF16LinearDynamicInputScale (w4a8_linear.py:12-134): same buffers, same call."""
+
+    def __init__(self, n, k, group_size, device, gen):
+        self.n, self.k, self.group_size = n, k, group_size
+        self.qweight = torch.randint(-128, 128, (n, k // 2), dtype=torch.int8, device=device, generator=gen)
+        self.s1_scales = (torch.rand((n,), device=device, generator=gen) * 0.004 + 0.001).half()
+        if group_size == -1:
+            z = torch.randint(0, 16, (n,), device=device, generator=gen).half()
+            self.s1_szeros = (z * self.s1_scales).half()
+        else:
+            # small level-2 scales keep q*s2 <= 255; any bytes are well-defined input for the kernel
+            self.s2_scales = torch.randint(1, 9, (k // 128, n), dtype=torch.int8, device=device, generator=gen)
+            zz = torch.randint(0, 16, (k // 128, n), device=device, generator=gen).to(torch.int16)
+            self.s2_zeros = (-(zz * self.s2_scales.to(torch.int16))).to(torch.int8)
+
+    def __call__(self, x, input_scales, input_sum, out):
+        if self.group_size == -1:   # forward_per_chn, w4a8_linear.py:105-118
+            gemm_chn.gemm_forward_cuda(x, self.qweight, self.s1_scales, input_scales, self.s1_szeros, input_sum, out)
+        else:                       # forward_per_group, :120-134
+            gemm_grp.gemm_forward_cuda(x, self.qweight, self.s2_zeros, self.s2_scales, self.s1_scales, input_scales,
+                                       out)
+
+
+class DecodeEngine:
+    def __init__(self, cfg, batch, prompt_len, max_new, group_size=-1, int4_kv=True, device="cuda:0", seed=0,
+                 tp_rank=0, tp_world=1, with_lm_head=True):
+        self.cfg, self.B, self.dev = cfg, batch, torch.device(device)
+        self.tp_rank, self.tp_world = tp_rank, tp_world
+        self.group_size, self.int4 = group_size, int4_kv
+        H, Hkv = cfg["heads"], cfg["kv_heads"]
+        assert H % tp_world == 0 and Hkv % tp_world == 0 and cfg["inter"] % (tp_world * 128) == 0
+        self.H, self.Hkv = H // tp_world, Hkv // tp_world
+        hid, inter = cfg["hidden"], cfg["inter"] // tp_world
+        self.hid, self.inter = hid, inter
+        self.qkv_n = (self.H + 2 * self.Hkv) * 128
+        gen = torch.Generator(device=self.dev).manual_seed(seed + 1000 * tp_rank)
+        self.layers = []
+        for _ in range(cfg["layers"]):
+            self.layers.append(dict(
+                ln1=(torch.rand((hid,), device=self.dev, generator=gen) + 0.5).half(),
+                ln2=(torch.rand((hid,), device=self.dev, generator=gen) + 0.5).half(),
+                qkv=W4A8Linear(self.qkv_n, hid, group_size, self.dev, gen),
+                o=W4A8Linear(hid, self.H * 128, group_size, self.dev, gen),
+                gate_up=W4A8Linear(2 * inter, hid, group_size, self.dev, gen),
+                down=W4A8Linear(hid, inter, group_size, self.dev, gen),
+            ))
+        self.norm_w = (torch.rand((hid,), device=self.dev, generator=gen) + 0.5).half()
+        self.with_lm_head = with_lm_head
+        if with_lm_head:
+            self.embed = (torch.randn((cfg["vocab"], hid), device=self.dev, generator=gen) * 0.05).half()
+            self.lm_head = (torch.randn((cfg["vocab"], hid), device=self.dev, generator=gen) * 0.02).half()
+        # ---- paged KV pools (cache_engine.py:59-115) and pointer tables (model_runner.py:396-414)
+        self.max_len = prompt_len + max_new
+        self.mb = (self.max_len + 63) // 64 + 1            # README.md:369 page budget rule (+1 page)
+        dhb = 64 if int4_kv else 128
+        self.size_per_token = self.Hkv * dhb
+        self.page_bytes = self.Hkv * 64 * dhb + 64 * self.Hkv * 4
+        nblocks = batch * self.mb
+        perm = torch.randperm(nblocks, generator=torch.Generator().manual_seed(seed)).reshape(batch, self.mb)
+        self.pools, self.tables = [], []
+        for _ in range(cfg["layers"]):
+            kp = torch.zeros((nblocks, self.page_bytes), dtype=torch.uint8, device=self.dev)
+            vp = torch.zeros((nblocks, self.page_bytes), dtype=torch.uint8, device=self.dev)
+            t = torch.empty((batch, 2, self.mb), dtype=torch.int64)
+            t[:, 0] = kp.data_ptr() + perm * self.page_bytes
+            t[:, 1] = vp.data_ptr() + perm * self.page_bytes
+            self.pools.append((kp, vp))
+            self.tables.append(t.to(self.dev))
+        # ---- activation buffers (ActivationBuffer, input_metadata.py:71-109)
+        B = batch
+        f16, i8 = torch.float16, torch.int8
+        self.hidden = torch.zeros((B, hid), dtype=f16, device=self.dev)
+        self.q_act = torch.empty((B, max(hid, self.H * 128)), dtype=i8, device=self.dev)
+        self.q_mlp = torch.empty((B, inter), dtype=i8, device=self.dev)
+        self.q_scale = torch.empty((B,), dtype=f16, device=self.dev)
+        self.q_sum = torch.empty((B,), dtype=f16, device=self.dev)
+        self.qkv_buf = torch.empty((B, self.qkv_n), dtype=f16, device=self.dev)
+        self.proj_out = torch.empty((B, hid), dtype=f16, device=self.dev)
+        self.gate_up_buf = torch.empty((B, 2 * inter), dtype=f16, device=self.dev)
+        self.mlp_act = torch.empty((B, inter), dtype=f16, device=self.dev)
+        self.final = torch.empty((B, hid), dtype=f16, device=self.dev)
+        self.lengths = torch.full((B,), prompt_len, dtype=torch.int32, device=self.dev)   # context incl. new token
+        self.tokens = torch.randint(0, cfg["vocab"], (B,), device=self.dev, generator=gen)
+        self.graph = None
+
+    # ---- fill the cache for positions [0, prompt_len) through the prefill writer (random K/V source) ----------
+    def prefill_cache(self, prompt_len, chunk=8):
+        B = self.B
+        gen = torch.Generator(device=self.dev).manual_seed(99)
+        seq = torch.full((B,), prompt_len, dtype=torch.int32, device=self.dev)
+        cu = (torch.arange(0, B + 1, device=self.dev, dtype=torch.int32) * prompt_len)
+        pad = fused_attention.compute_padding_offsets(cu, prompt_len, B * prompt_len)
+        qkv = torch.randn((B * prompt_len, self.qkv_n), dtype=torch.float16, device=self.dev, generator=gen)
+        for li in range(self.cfg["layers"]):
+            work = qkv if li == 0 else (qkv * (1.0 + 0.01 * li)).half()
+            fused_attention.apply_bias_rope_update_kv_cache(
+                work, seq, pad, self.tables[li], self.H, self.Hkv, prompt_len, 64, self.size_per_token, 128,
+                self.cfg["rope_theta"], 8192, True, self.int4, True)
+        self.lengths.fill_(prompt_len + 1)
+        torch.cuda.synchronize()
+
+    # ---- one decode step (llama_w4a8_unpad.py:330-361 per layer) --------------------------------------------
+    def step(self):
+        cfg, B = self.cfg, self.B
+        fuse_sum = self.group_size == -1
+        if self.with_lm_head:
+            torch.index_select(self.embed, 0, self.tokens, out=self.hidden)
+        h = self.hidden
+        qa = self.q_act[:, : self.hid]
+        qo = self.q_act[:, : self.H * 128]
+        for li, L in enumerate(self.layers):
+            if fuse_sum:
+                layernorm_ops.rms_norm_general_fuse_sum(qa, h, L["ln1"], self.q_sum, self.q_scale, cfg["eps"], True)
+            else:
+                layernorm_ops.rms_norm_general(qa, h, L["ln1"], self.q_scale, cfg["eps"], True)
+            L["qkv"](qa, self.q_scale, self.q_sum, self.qkv_buf)
+            q, k, v = self.qkv_buf.split([self.H * 128, self.Hkv * 128, self.Hkv * 128], dim=-1)
+            attn = fused_attention.single_query_attention(
+                q.reshape(B, self.H, 128), k.reshape(B, self.Hkv, 128), v.reshape(B, self.Hkv, 128), self.tables[li],
+                self.lengths, None, 8192, 64, self.size_per_token, self.max_len, 128, cfg["rope_theta"], True,
+                self.int4, True)
+            attn = attn.reshape(B, -1)
+            if fuse_sum:
+                fused_kernels.invoke_quant_fuse_sum(qo, attn, self.q_sum, self.q_scale)
+            else:
+                fused_kernels.invoke_quant(qo, attn, self.q_scale)
+            L["o"](qo, self.q_scale, self.q_sum, self.proj_out)
+            tpmod.all_reduce_sum_(self.proj_out)
+            h.add_(self.proj_out)
+            if fuse_sum:
+                layernorm_ops.rms_norm_general_fuse_sum(qa, h, L["ln2"], self.q_sum, self.q_scale, cfg["eps"], True)
+            else:
+                layernorm_ops.rms_norm_general(qa, h, L["ln2"], self.q_scale, cfg["eps"], True)
+            L["gate_up"](qa, self.q_scale, self.q_sum, self.gate_up_buf)
+            activation_ops.silu_and_mul(self.mlp_act, self.gate_up_buf)
+            if fuse_sum:
+                fused_kernels.invoke_quant_fuse_sum(self.q_mlp, self.mlp_act, self.q_sum, self.q_scale)
+            else:
+                fused_kernels.invoke_quant(self.q_mlp, self.mlp_act, self.q_scale)
+            L["down"](self.q_mlp, self.q_scale, self.q_sum, self.proj_out)
+            tpmod.all_reduce_sum_(self.proj_out)
+            h.add_(self.proj_out)
+        layernorm_ops.rms_norm(self.final, h, self.norm_w, cfg["eps"])
+        if self.with_lm_head:
+            logits = torch.matmul(self.final, self.lm_head.t())      # un-quantised fp16 lm_head (:392,476)
+            torch.argmax(logits, dim=-1, out=self.tokens)            # greedy sampler
+        self.lengths.add_(1)
+
+    def capture(self):
+        """Capture one step in a hipGraph (removes ~400 launches of host overhead per step)."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.step()                       # warm-up outside capture (allocator, lazy init)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.step()
+        self.graph = g
+        return g
+
+    def run(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.step()

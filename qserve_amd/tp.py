@@ -1,0 +1,71 @@
+"""Tensor-parallel sharding of the packed W4A8 weights + the one collective the path needs.
+
+The reference is single-GPU (tp_size = 1 everywhere, llama_w4a8_unpad.py:513-514); this is the Megatron-style
+extension: column-parallel qkv_proj / gate_up_proj (split N), row-parallel o_proj / down_proj (split K) followed by
+ONE fp16 sum all-reduce (RCCL over xGMI: torch.distributed backend "nccl" on ROCm).
+
+Sharding rules for the reference's packed layout (w4a8_linear.py:196-277):
+  * qweight bytes are [N/32][K/32][512]: a split of N at a multiple of 32 rows is a plain row slice of the
+    [N, K/2] view; a split of K must slice the 4-D tile view on its K/32 axis (a column slice of the 2-D view would
+    be WRONG) and, for g128 weights, at multiples of 4 tiles so that groups stay intact;
+  * s1_scales / s1_szeros [N]: slice for column-parallel, replicate for row-parallel;
+  * s2_scales / s2_zeros [K/128, N] (per-32 permuted along N): slice dim 1 at multiples of 32 (column-parallel),
+    slice dim 0 (row-parallel).
+Works on torch tensors on any device (pure indexing, no kernels).
+"""
+import torch
+
+
+def shard_column_parallel(qweight, vecs_n=(), mats_gn=(), rank=0, world=1):
+    """Split the OUTPUT dim N.  qweight int8 [N, K/2]; vecs_n: per-channel [N] tensors (s1_scales, s1_szeros, bias);
+    mats_gn: [K/128, N] tensors (s2_scales, s2_zeros).  Returns (qweight_r, [vecs...], [mats...])."""
+    N = qweight.shape[0]
+    assert N % (32 * world) == 0, "column-parallel split must fall on 32-row tiles"
+    n0, n1 = rank * N // world, (rank + 1) * N // world
+    return (qweight[n0:n1].contiguous(), [v[n0:n1].contiguous() for v in vecs_n],
+            [m[:, n0:n1].contiguous() for m in mats_gn])
+
+
+def shard_row_parallel(qweight, mats_gn=(), rank=0, world=1, group_size=-1):
+    """Split the INPUT dim K.  Slices the tile view [N/32, K/32, 512] on axis 1.  Per-channel vectors are
+    replicated (not returned).  mats_gn ([K/128, N]) are sliced on dim 0."""
+    N, K2 = qweight.shape
+    K = K2 * 2
+    kt = K // 32
+    unit = 4 if group_size == 128 else 1          # keep 128-wide groups intact
+    assert kt % (world * unit) == 0, "row-parallel split must fall on whole 32-k tiles (128-k groups for g128)"
+    t0, t1 = rank * kt // world, (rank + 1) * kt // world
+    tiles = qweight.reshape(N // 32, kt, 512)[:, t0:t1].contiguous()
+    qw = tiles.reshape(N, (t1 - t0) * 16)
+    mats = []
+    for m in mats_gn:
+        g = m.shape[0]
+        mats.append(m[rank * g // world:(rank + 1) * g // world].contiguous())
+    return qw, mats
+
+
+def all_reduce_sum_(t, group=None):
+    """In-place fp16 sum all-reduce of the row-parallel partial outputs (2 per layer).  No-op without a process
+    group or at world size 1."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+class RowParallelLinear:
+    """y = all_reduce( gemm(x_shard, W_shard) ) (+ bias once, after the reduce).
+
+    `gemm` is any callable with the signature of `qserve_backend.qgemm_w4a8_per_chn.gemm_forward_cuda` or the
+    per-group one; every rank quantises its own activation slice, so ascales / a_ssums are per shard (the
+    zero-point term is linear in K, partial corrections add up: SURVEY 8e)."""
+
+    def __init__(self, gemm, weight_args, bias=None, group=None):
+        self.gemm, self.weight_args, self.bias, self.group = gemm, weight_args, bias, group
+
+    def __call__(self, x_q, ascales, a_ssums, out):
+        self.gemm(x_q, ascales, a_ssums, out, *self.weight_args)
+        all_reduce_sum_(out, self.group)
+        if self.bias is not None:
+            out += self.bias
+        return out

@@ -1,0 +1,127 @@
+"""GPU parity: W4A8 GEMMs through the C ABI (via the qserve_backend mirror) vs the CPU oracle.
+Bar: INT32 accumulators bit-exact; fp16 output bit-exact vs the oracle's un-contracted fp32 epilogue
+(<= 1 fp16 ulp is what the reference itself guarantees)."""
+import numpy as np
+import pytest
+import torch
+
+from _helpers import dev, int_matmul_torch, ulp_diff_f16, unpack_qweight_torch
+from oracle import synth, w4a8
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1, 64, 128), (7, 64, 256), (16, 128, 128), (17, 192, 384), (33, 64, 1024), (48, 128, 512),
+          (64, 256, 512), (65, 64, 256), (100, 128, 640), (128, 192, 256), (200, 64, 384)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_per_channel_vs_oracle(gpu, M, N, K):
+    import qserve_backend.qgemm_w4a8_per_chn as op
+    pr = synth.per_channel_problem(M, N, K, seed=M + N + K)
+    acc_ref, out_ref = w4a8.gemm_per_chn(pr["A"], pr["qweight"], pr["wscales"], pr["ascales"], pr["w_szs"], pr["a_ssums"])
+    A, W = dev(pr["A"]), dev(pr["qweight"])
+    acc = torch.full((M, N), -7, dtype=torch.int32, device=gpu)
+    op.gemm_forward_acc(A, W, acc)
+    assert np.array_equal(acc.cpu().numpy(), acc_ref), "int32 accumulator mismatch"
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+    op.gemm_forward_cuda(A, W, dev(pr["wscales"]), dev(pr["ascales"]), dev(pr["w_szs"]), dev(pr["a_ssums"]), out)
+    d = ulp_diff_f16(out.cpu().numpy(), out_ref)
+    assert d.max() == 0, f"fp16 output differs by up to {d.max()} ulp"
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("valid", [True, False])
+def test_per_group_vs_oracle(gpu, M, N, K, valid):
+    import qserve_backend.qgemm_w4a8_per_group as op
+    pr = synth.per_group_problem(M, N, K, seed=M * 3 + N + K, valid=valid)
+    acc_ref, out_ref = w4a8.gemm_per_group(pr["A"], pr["qweight"], pr["s2_zeros"], pr["s2_scales"], pr["wscales"], pr["ascales"])
+    A, W, Z, S = dev(pr["A"]), dev(pr["qweight"]), dev(pr["s2_zeros"]), dev(pr["s2_scales"])
+    acc = torch.full((M, N), -7, dtype=torch.int32, device=gpu)
+    op.gemm_forward_acc(A, W, Z, S, acc)
+    assert np.array_equal(acc.cpu().numpy(), acc_ref), "int32 accumulator (dequantised int8 path) mismatch"
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+    op.gemm_forward_cuda(A, W, Z, S, dev(pr["wscales"]), dev(pr["ascales"]), out)
+    assert ulp_diff_f16(out.cpu().numpy(), out_ref).max() == 0
+
+
+def test_rows_beyond_M_untouched_and_empty_batch(gpu):
+    import qserve_backend.qgemm_w4a8_per_chn as op
+    pr = synth.per_channel_problem(5, 64, 128, seed=9)
+    buf = torch.full((8, 64), 123.0, dtype=torch.float16, device=gpu)
+    op.gemm_forward_cuda(dev(pr["A"]), dev(pr["qweight"]), dev(pr["wscales"]), dev(pr["ascales"]), dev(pr["w_szs"]),
+                         dev(pr["a_ssums"]), buf[:5])
+    assert torch.all(buf[5:] == 123.0)
+    op.gemm_forward_cuda(dev(pr["A"])[:0], dev(pr["qweight"]), dev(pr["wscales"]), dev(pr["ascales"])[:0],
+                         dev(pr["w_szs"]), dev(pr["a_ssums"])[:0], buf[:0])   # M = 0: no-op
+
+
+def test_bad_arguments_raise(gpu):
+    import qserve_backend.qgemm_w4a8_per_chn as op
+    pr = synth.per_channel_problem(4, 64, 128, seed=1)
+    out = torch.empty((4, 64), dtype=torch.float16, device=gpu)
+    with pytest.raises(RuntimeError):     # dtype mismatch (reference: data_ptr<int8_t>() throws)
+        op.gemm_forward_cuda(dev(pr["A"]).to(torch.int32), dev(pr["qweight"]), dev(pr["wscales"]), dev(pr["ascales"]),
+                             dev(pr["w_szs"]), dev(pr["a_ssums"]), out)
+    with pytest.raises(RuntimeError):     # N not a multiple of 64
+        op.gemm_forward_cuda(dev(pr["A"]), dev(pr["qweight"]), dev(pr["wscales"]), dev(pr["ascales"]),
+                             dev(pr["w_szs"]), dev(pr["a_ssums"]), out[:, :32].contiguous())
+
+
+LLAMA = [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)]
+
+
+@pytest.mark.parametrize("N,K", LLAMA)
+@pytest.mark.parametrize("M", [64, 128])
+def test_full_size_llama_shapes_exact_on_device(gpu, M, N, K):
+    """BASELINE.json sizes: the oracle is too slow, so check against an independent exact integer matmul on the
+    GPU (torch fp32 slices of the unpacked weights) + a checksum of checksums on the CPU."""
+    import qserve_backend.qgemm_w4a8_per_chn as op
+    g = torch.Generator(device=gpu).manual_seed(N + K + M)
+    W = torch.randint(-128, 128, (N, K // 2), dtype=torch.int8, device=gpu, generator=g)
+    A = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=gpu, generator=g)
+    acc = torch.empty((M, N), dtype=torch.int32, device=gpu)
+    op.gemm_forward_acc(A, W, acc)
+    Q = unpack_qweight_torch(W)
+    ref = int_matmul_torch(A, Q)
+    assert torch.equal(acc.to(torch.int64), ref)
+    # linearity: acc(A, W) summed over tokens == acc(sum-free check) column checksums
+    col = (A.to(torch.int64).sum(0)[None, :] * Q.to(torch.int64)).sum(1)
+    assert torch.equal(acc.to(torch.int64).sum(0), col)
+
+
+def test_config1_4096_cubed_per_channel(gpu):
+    """configs[0] of BASELINE.json (the reference's CPU-runnable case) on the GPU, exact."""
+    import qserve_backend.qgemm_w4a8_per_chn as op
+    g = torch.Generator(device=gpu).manual_seed(0)
+    W = torch.randint(-128, 128, (4096, 2048), dtype=torch.int8, device=gpu, generator=g)
+    A = torch.randint(-127, 128, (4096, 4096), dtype=torch.int8, device=gpu, generator=g)
+    acc = torch.empty((4096, 4096), dtype=torch.int32, device=gpu)
+    op.gemm_forward_acc(A, W, acc)
+    ref = int_matmul_torch(A, unpack_qweight_torch(W))
+    assert torch.equal(acc.to(torch.int64), ref)
+
+
+def test_per_group_full_size_exact_on_device(gpu):
+    import qserve_backend.qgemm_w4a8_per_group as op
+    N, K, M = 4096, 4096, 128
+    pr = synth.per_group_problem(M, N, K, seed=11)
+    A, W, Z, S = dev(pr["A"]), dev(pr["qweight"]), dev(pr["s2_zeros"]), dev(pr["s2_scales"])
+    acc = torch.empty((M, N), dtype=torch.int32, device=gpu)
+    op.gemm_forward_acc(A, W, Z, S, acc)
+    w8 = (pr["q"].astype(np.int16) - np.repeat(pr["z"], 128, 1)) * np.repeat(pr["s2"], 128, 1)
+    ref = int_matmul_torch(A, dev(w8.astype(np.int8)))
+    assert torch.equal(acc.to(torch.int64), ref)
+
+
+def test_w8a8_module(gpu):
+    import qserve_backend.qgemm_w8a8 as op
+    r = np.random.default_rng(3)
+    M, N, K = 37, 96, 256
+    A = r.integers(-127, 128, (M, K), dtype=np.int8)
+    W = r.integers(-127, 128, (N, K), dtype=np.int8)
+    ws = r.uniform(0.002, 0.02, N).astype(np.float16)
+    sa = r.uniform(0.005, 0.05, M).astype(np.float16)
+    _, ref = w4a8.gemm_w8a8(A, W, ws, sa)
+    out = torch.empty((M, N), dtype=torch.float16, device=gpu)
+    op.w8a8_gemm_forward_cuda(dev(A), dev(W), dev(ws), dev(sa), out)
+    assert ulp_diff_f16(out.cpu().numpy(), ref).max() == 0
