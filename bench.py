@@ -73,8 +73,7 @@ def kernel_bench(eng, torch):
     import qserve_backend.fused_attention as fa
     B, nl = eng.B, len(eng.layers)
     res = []
-    qa = eng.q_act[:, : eng.hid]
-    qo = eng.q_act[:, : eng.H * 128]
+    qa, qo = eng.q_act, eng.q_attn
     specs = [("qkv", qa, eng.qkv_buf), ("o", qo, eng.proj_out), ("gate_up", qa, eng.gate_up_buf),
              ("down", eng.q_mlp, eng.proj_out)]
     for name, x, out in specs:

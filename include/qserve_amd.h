@@ -98,6 +98,9 @@ int qs_single_query_attention(const void* q, const void* k, const void* v, const
                               int timestep, int rotary_embedding_dim, float rotary_base, int neox_rotary_style,
                               int int4_kv_cache, int kv_cache_with_zeros, qs_stream_t stream);
 
+/* Kernel selection for A/B tests: 0 = matrix-core (MFMA) kernel for KV4 [default], 1 = VALU kernel. */
+void qs_set_attention_variant(int variant);
+
 /* Prefill KV writer.  Replaces qserve_backend.fused_attention.apply_bias_rope_update_kv_cache
  *   (kernels/csrc/fused_attention/update_kv_cache.h:11-27, update_kv_cache.cu:20-108).
  *   qkv half [num_tokens, (H+2Hkv)*Dh] modified in place (rotated q and k are written back);

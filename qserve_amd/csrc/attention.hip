@@ -500,6 +500,13 @@ int launch_decode(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Fl
 
 }  // namespace
 
+// KV4 fast path on the matrix cores (attention_mfma.hip)
+int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
+                          const int64_t* kvp, const int* len, _Float16* out, int H, int Hkv, int64_t qs, int64_t kvs,
+                          int mb, int timestep, float base);
+static int g_attn_variant = 0;   // 0 = MFMA kernel for KV4 (default), 1 = VALU kernel everywhere (A/B tests)
+extern "C" void qs_set_attention_variant(int variant) { g_attn_variant = variant; }
+
 extern "C" int qs_single_query_attention(const void* q, const void* k, const void* v, const int64_t* kv_pointers,
                                          const int32_t* length_per_sample, void* out, int batch, int num_heads,
                                          int num_kv_heads, int head_dim, int64_t q_stride0, int64_t kv_stride0,
@@ -525,6 +532,10 @@ extern "C" int qs_single_query_attention(const void* q, const void* k, const voi
     dim3 grid(num_kv_heads, batch);
     const int G = num_heads / num_kv_heads;
     hipStream_t st = (hipStream_t)stream;
+    if (int4_kv_cache && g_attn_variant == 0)
+        return qs_launch_decode_mfma(G, grid, st, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
+                                     kv_pointers, length_per_sample, (_Float16*)out, num_heads, num_kv_heads,
+                                     q_stride0, kv_stride0, max_blocks, timestep, rotary_base);
     if (int4_kv_cache)
         return launch_decode<true>(G, grid, st, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
                                    kv_pointers, length_per_sample, (_Float16*)out, num_heads, num_kv_heads, q_stride0,

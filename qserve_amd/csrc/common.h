@@ -14,6 +14,7 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32;
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
 void qs_set_error(const char* fmt, ...);
 

@@ -66,16 +66,32 @@ __device__ __forceinline__ float epi_per_group(int acc, float ws, float sa) {
 }
 
 // MODE 0 = per-channel, 1 = per-group(128).  OUTK 0 = fp16 epilogue, 1 = raw int32 accumulators.
-template <int MT, int MODE, int OUTK>
-__global__ __launch_bounds__(512) void w4a8_gemm_splitk(const int8_t* __restrict__ A, const uint8_t* __restrict__ W,
+//
+// Work decomposition: grid = (N/64, ceil(M/(16 MT)), S).  The S blocks of one output tile and the NW waves of each
+// block split the K/128 k-steps: block z owns a contiguous range, its waves take the steps of that range
+// round-robin.  Each wave keeps NSTAGE k-steps of operands in flight in registers (weights are streamed from HBM
+// exactly once; with ~2 us of loaded-HBM latency the bytes in flight per CU decide the bandwidth).
+// Reduction: waves -> LDS (int32, exact) ; blocks -> per-tile int32 slabs in a workspace + arrival counter, the last
+// arriving block sums the slabs and runs the fused fp32 epilogue (agent-scope release / acquire, placement
+// independent; counters are reset by the last arriver so the workspace is reusable without host work).
+template <int MT>
+struct Stage {
+    v4u w[4];
+    v4i b[MT][2];
+    u32 sdw, zdw;
+};
+
+template <int MT, int MODE, int OUTK, int NSTAGE>
+__global__ __launch_bounds__(256, 2) void w4a8_gemm_splitk(const int8_t* __restrict__ A, const uint8_t* __restrict__ W,
                                                         const int8_t* __restrict__ zeros,
                                                         const int8_t* __restrict__ scales8,
                                                         const __half* __restrict__ wscales,
                                                         const __half* __restrict__ ascales,
                                                         const __half* __restrict__ wszs,
                                                         const __half* __restrict__ assums, void* __restrict__ out,
+                                                        int* __restrict__ slabs, unsigned* __restrict__ counters,
                                                         int M, int N, int K) {
-    extern __shared__ __attribute__((aligned(16))) int red[];   // [NW][MT*16][64]
+    extern __shared__ __attribute__((aligned(16))) int red[];   // [NW][MT*16][64] ; red[0] doubles as the "last" flag
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,7 +101,9 @@ __global__ __launch_bounds__(512) void w4a8_gemm_splitk(const int8_t* __restrict
     const int T0 = blockIdx.x * 2;
     const int m0 = blockIdx.y * (16 * MT);
     const int KT = K >> 5;
-    const int nsteps = K >> 7;
+    const int nsteps_all = K >> 7;
+    const int S = gridDim.z, z = blockIdx.z;
+    const int ks_begin = (int)(((long)nsteps_all * z) / S), ks_end = (int)(((long)nsteps_all * (z + 1)) / S);
 
     const uint8_t* wrow = W + ((size_t)(T0 + tsel) * KT) * 512 + c * 64 + (size_t)g * 512;
     const int8_t* arow[MT];
@@ -103,37 +121,37 @@ __global__ __launch_bounds__(512) void w4a8_gemm_splitk(const int8_t* __restrict
 #pragma unroll
         for (int cl = 0; cl < 4; ++cl) acc[mt][cl] = (v4i){0, 0, 0, 0};
 
-    for (int ks = wave; ks < nsteps; ks += NW) {
-        const uint4* wp = reinterpret_cast<const uint4*>(wrow + (size_t)ks * 2048);
-        uint4 ch[4];
+    auto load_stage = [&](Stage<MT>& st, int ks) {
+        const v4u* wp = reinterpret_cast<const v4u*>(wrow + (size_t)ks * 2048);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ch[e] = wp[e];
-        v4i b[MT][2];
+        for (int e = 0; e < 4; ++e) st.w[e] = wp[e];
+        // (nontemporal loads measured 1.6x SLOWER for this 64-byte-row pattern: scripts/microbench_wstream.hip P2)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const v4i* ap = reinterpret_cast<const v4i*>(arow[mt] + (size_t)ks * 128);
-            b[mt][0] = ap[0];
-            b[mt][1] = ap[1];
+            st.b[mt][0] = ap[0];
+            st.b[mt][1] = ap[1];
         }
-        u32 sdw = 0, zdw = 0;
         if (MODE == 1) {
-            sdw = *reinterpret_cast<const u32*>(scales8 + (size_t)ks * N + meta_off);
-            zdw = *reinterpret_cast<const u32*>(zeros + (size_t)ks * N + meta_off);
+            st.sdw = *reinterpret_cast<const u32*>(scales8 + (size_t)ks * N + meta_off);
+            st.zdw = *reinterpret_cast<const u32*>(zeros + (size_t)ks * N + meta_off);
         }
+    };
+    auto compute_stage = [&](const Stage<MT>& st) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             u32 rx[4], ry[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                rx[e] = h ? ch[e].z : ch[e].x;
-                ry[e] = h ? ch[e].w : ch[e].y;
+                rx[e] = h ? st.w[e].z : st.w[e].x;
+                ry[e] = h ? st.w[e].w : st.w[e].y;
             }
 #pragma unroll
             for (int cl = 0; cl < 4; ++cl) {
                 u32 s = 0, zb = 0;
                 if (MODE == 1) {
-                    s = (sdw >> (8 * cl)) & 0xFFu;
-                    zb = ((zdw >> (8 * cl)) & 0xFFu) * 0x01010101u;
+                    s = (st.sdw >> (8 * cl)) & 0xFFu;
+                    zb = ((st.zdw >> (8 * cl)) & 0xFFu) * 0x01010101u;
                 }
                 v4i a;
 #pragma unroll
@@ -143,7 +161,25 @@ __global__ __launch_bounds__(512) void w4a8_gemm_splitk(const int8_t* __restrict
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[mt][cl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b[mt][h], acc[mt][cl], 0, 0, 0);
+                    acc[mt][cl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, st.b[mt][h], acc[mt][cl], 0, 0, 0);
+            }
+        }
+    };
+
+    Stage<MT> st[NSTAGE];
+#pragma unroll
+    for (int s = 0; s < NSTAGE; ++s) {
+        const int kk = ks_begin + wave + s * NW;
+        if (kk < ks_end) load_stage(st[s], kk);
+    }
+    for (int ks = ks_begin + wave; ks < ks_end; ks += NW * NSTAGE) {
+#pragma unroll
+        for (int s = 0; s < NSTAGE; ++s) {
+            const int kk = ks + s * NW;
+            if (kk < ks_end) {
+                compute_stage(st[s]);
+                const int nk = kk + NSTAGE * NW;
+                if (nk < ks_end) load_stage(st[s], nk);
             }
         }
     }
@@ -158,7 +194,63 @@ __global__ __launch_bounds__(512) void w4a8_gemm_splitk(const int8_t* __restrict
 #pragma unroll
                 for (int r = 0; r < 4; ++r) red[(wave * NP * 4 + (mt * 4 + cl) * 4 + r) * 64 + lane] = acc[mt][cl][r];
         __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl) {
+                const int p = mt * 4 + cl;
+                if ((p % NW) != wave) continue;
+                v4i s = (v4i){0, 0, 0, 0};
+                for (int w = 0; w < NW; ++w)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[r] += red[(w * NP * 4 + p * 4 + r) * 64 + lane];
+                acc[mt][cl] = s;
+            }
     }
+
+    // ---- cross-block reduction: slabs + arrival ticket, last arriver finalises ---------------------------------
+    if (S > 1) {
+        const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        v4i* slab = reinterpret_cast<v4i*>(slabs) + (tile * S) * (size_t)(NP * 64);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl) {
+                const int p = mt * 4 + cl;
+                if (NW > 1 && (p % NW) != wave) continue;
+                slab[((size_t)z * NP + p) * 64 + lane] = acc[mt][cl];
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // also orders the LDS reads above before red[0] is reused as a flag
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned t = __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            red[0] = (t == (unsigned)(S - 1)) ? 1 : 0;
+        }
+        __syncthreads();
+        if (red[0] == 0) return;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-cleaning
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl) {
+                const int p = mt * 4 + cl;
+                if (NW > 1 && (p % NW) != wave) continue;
+                v4i s = (v4i){0, 0, 0, 0};
+                for (int zz = 0; zz < S; ++zz) {
+                    const v4i t = slab[((size_t)zz * NP + p) * 64 + lane];
+                    s += t;
+                }
+                acc[mt][cl] = s;
+            }
+    }
+
+    // ---- fused epilogue -----------------------------------------------------------------------------------------
     const int ncol0 = 32 * (T0 + (g >> 1)) + 4 * (g & 1);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -166,13 +258,7 @@ __global__ __launch_bounds__(512) void w4a8_gemm_splitk(const int8_t* __restrict
         for (int cl = 0; cl < 4; ++cl) {
             const int p = mt * 4 + cl;
             if (NW > 1 && (p % NW) != wave) continue;
-            v4i s = acc[mt][cl];
-            if (NW > 1) {
-                s = (v4i){0, 0, 0, 0};
-                for (int w = 0; w < NW; ++w)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s[r] += red[(w * NP * 4 + p * 4 + r) * 64 + lane];
-            }
+            const v4i s = acc[mt][cl];
             const int m = m0 + 16 * mt + li;
             const int n = ncol0 + 8 * cl;
             if (m < M) {
@@ -201,12 +287,45 @@ __global__ __launch_bounds__(512) void w4a8_gemm_splitk(const int8_t* __restrict
 
 int g_variant = -1;
 
-template <int MT, int MODE, int OUTK>
+// Split-K workspace (per device): int32 slabs + arrival counters, allocated lazily on first use (never while a
+// stream is being captured: a failed allocation simply disables cross-block split-K).
+struct Workspace {
+    int* slabs = nullptr;
+    unsigned* counters = nullptr;
+    size_t slab_bytes = 0;
+    int ncounters = 0;
+    bool tried = false;
+};
+Workspace g_ws[16];
+
+Workspace* get_workspace() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    Workspace& w = g_ws[dev];
+    if (!w.tried) {
+        w.tried = true;
+        const size_t slab_bytes = 48u << 20;
+        const int ncnt = 1 << 16;
+        void *a = nullptr, *b = nullptr;
+        if (hipMalloc(&a, slab_bytes) == hipSuccess && hipMalloc(&b, ncnt * sizeof(unsigned)) == hipSuccess &&
+            hipMemset(b, 0, ncnt * sizeof(unsigned)) == hipSuccess) {
+            w.slabs = reinterpret_cast<int*>(a);
+            w.counters = reinterpret_cast<unsigned*>(b);
+            w.slab_bytes = slab_bytes;
+            w.ncounters = ncnt;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    return w.slabs ? &w : nullptr;
+}
+
+template <int MT, int MODE, int OUTK, int NSTAGE>
 int launch_splitk(const int8_t* A, const uint8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
                   const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K, int NW,
-                  hipStream_t stream) {
-    auto kern = w4a8_gemm_splitk<MT, MODE, OUTK>;
-    const size_t smem = NW > 1 ? (size_t)NW * MT * 16 * 64 * sizeof(int) : 0;
+                  int S, hipStream_t stream) {
+    auto kern = w4a8_gemm_splitk<MT, MODE, OUTK, NSTAGE>;
+    size_t smem = NW > 1 ? (size_t)NW * MT * 16 * 64 * sizeof(int) : 16;
     static size_t configured = 0;   // per instantiation
     if (smem > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -217,10 +336,23 @@ int launch_splitk(const int8_t* A, const uint8_t* W, const int8_t* zeros, const 
         }
         configured = smem;
     }
-    dim3 grid(N / 64, (M + 16 * MT - 1) / (16 * MT));
+    dim3 grid(N / 64, (M + 16 * MT - 1) / (16 * MT), 1);
+    int* slabs = nullptr;
+    unsigned* counters = nullptr;
+    if (S > 1) {
+        Workspace* ws = get_workspace();
+        const size_t tiles = (size_t)grid.x * grid.y;
+        const size_t need = tiles * S * (size_t)(MT * 4 * 64) * 16;
+        if (ws && need <= ws->slab_bytes && tiles <= (size_t)ws->ncounters) {
+            slabs = ws->slabs;
+            counters = ws->counters;
+            grid.z = S;
+        }
+    }
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, stream, A, W, zeros, scales8,
                        reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
-                       reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K);
+                       reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, slabs,
+                       counters, M, N, K);
     return qs_launch_status("w4a8 gemm");
 }
 
@@ -228,24 +360,38 @@ template <int MODE, int OUTK>
 int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
              const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K,
              qs_stream_t stream_) {
-    QS_REQUIRE(A && W && out, "w4a8 gemm: null pointer");
     QS_REQUIRE(M >= 0 && N > 0 && K > 0, "w4a8 gemm: bad shape M=%d N=%d K=%d", M, N, K);
     QS_REQUIRE(N % 64 == 0, "w4a8 gemm: N=%d must be a multiple of 64", N);
     QS_REQUIRE(K % 128 == 0, "w4a8 gemm: K=%d must be a multiple of 128", K);
+    if (M == 0) return QS_OK;   // empty batch: nothing to do (zero-size tensors carry null pointers)
+    QS_REQUIRE(A && W && out, "w4a8 gemm: null pointer");
     if (OUTK == 0) QS_REQUIRE(wscales && ascales, "w4a8 gemm: null scale pointer");
     if (MODE == 0 && OUTK == 0) QS_REQUIRE(wszs && assums, "w4a8 per-channel gemm: null w_szs / a_ssums");
     if (MODE == 1) QS_REQUIRE(zeros && scales8, "w4a8 per-group gemm: null zeros / scales_i8");
-    if (M == 0) return QS_OK;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const uint8_t* Wu = reinterpret_cast<const uint8_t*>(W);
     const int nsteps = K / 128;
-    int NW = nsteps >= 8 ? 8 : (nsteps >= 4 ? 4 : (nsteps >= 2 ? 2 : 1));
-    if (g_variant >= 100) NW = g_variant - 100 > nsteps ? nsteps : g_variant - 100;   // A/B: force wave count
-    if (M <= 16) return launch_splitk<1, MODE, OUTK>(A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, NW, stream);
-    if (M <= 32) return launch_splitk<2, MODE, OUTK>(A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, NW, stream);
-    if (M <= 48) return launch_splitk<3, MODE, OUTK>(A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, NW, stream);
-    if (NW > 4) NW = 4;   // LDS: NW*MT*4 KiB
-    return launch_splitk<4, MODE, OUTK>(A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, NW, stream);
+    // heuristic: 4 waves per block; enough blocks (tiles x S) to put >= ~2 blocks on each of the 256 CUs while every
+    // wave still gets >= 2 k-steps
+    int NW = nsteps >= 4 ? 4 : (nsteps >= 2 ? 2 : 1);
+    const int mtile = M <= 16 ? 1 : M <= 32 ? 2 : M <= 48 ? 3 : 4;
+    const long tiles = (long)(N / 64) * ((M + 16 * mtile - 1) / (16 * mtile));
+    int S = 1;
+    while (tiles * S < 384 && S < 8 && nsteps / (S * 2) >= NW * 2) S *= 2;
+    if (g_variant >= 1000 && g_variant < 100000) {   // A/B: variant = 1000 + 10*S + NW
+        S = (g_variant - 1000) / 10;
+        NW = (g_variant - 1000) % 10;
+        if (S < 1) S = 1;
+        if (NW < 1) NW = 1;
+        if (NW > 4) NW = 4;
+    }
+#define QS_GO(MTV) \
+    return launch_splitk<MTV, MODE, OUTK, 2>(A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, NW, S, stream)
+    if (mtile == 1) QS_GO(1);
+    if (mtile == 2) QS_GO(2);
+    if (mtile == 3) QS_GO(3);
+    QS_GO(4);
+#undef QS_GO
 }
 
 }  // namespace

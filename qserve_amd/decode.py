@@ -104,7 +104,8 @@ class DecodeEngine:
         B = batch
         f16, i8 = torch.float16, torch.int8
         self.hidden = torch.zeros((B, hid), dtype=f16, device=self.dev)
-        self.q_act = torch.empty((B, max(hid, self.H * 128)), dtype=i8, device=self.dev)
+        self.q_act = torch.empty((B, hid), dtype=i8, device=self.dev)
+        self.q_attn = torch.empty((B, self.H * 128), dtype=i8, device=self.dev)
         self.q_mlp = torch.empty((B, inter), dtype=i8, device=self.dev)
         self.q_scale = torch.empty((B,), dtype=f16, device=self.dev)
         self.q_sum = torch.empty((B,), dtype=f16, device=self.dev)
@@ -140,8 +141,7 @@ class DecodeEngine:
         if self.with_lm_head:
             torch.index_select(self.embed, 0, self.tokens, out=self.hidden)
         h = self.hidden
-        qa = self.q_act[:, : self.hid]
-        qo = self.q_act[:, : self.H * 128]
+        qa, qo = self.q_act, self.q_attn
         for li, L in enumerate(self.layers):
             if fuse_sum:
                 layernorm_ops.rms_norm_general_fuse_sum(qa, h, L["ln1"], self.q_sum, self.q_scale, cfg["eps"], True)

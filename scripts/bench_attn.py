@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""A/B micro-benchmark of decode attention (graph-timed): variant 0 = MFMA kernel, 1 = VALU kernel."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch
+import qserve_backend.fused_attention as fa
+from qserve_amd._lib import lib
+from bench_gemm import timeit
+
+dev = torch.device("cuda:0")
+B, H, Hkv = 64, 32, 8
+int4 = "--kv8" not in sys.argv
+NL = 8
+LS = [int(x) for x in os.environ.get("LS", "1024,1280,1535,4096").split(",")]
+for L in LS:
+    mb = (L + 63) // 64 + 1
+    dhb = 64 if int4 else 128
+    pb = Hkv * 64 * dhb + 64 * Hkv * 4
+    nblocks = B * mb
+    pools, tables = [], []
+    for _ in range(NL):
+        kp = torch.randint(0, 255, (nblocks, pb), dtype=torch.uint8, device=dev)
+        vp = torch.randint(0, 255, (nblocks, pb), dtype=torch.uint8, device=dev)
+        # sane fp16 scale/zero tails
+        kp[:, Hkv * 64 * dhb:] = torch.tensor([0x00, 0x34], dtype=torch.uint8, device=dev).repeat((pb - Hkv * 64 * dhb) // 2)
+        vp[:, Hkv * 64 * dhb:] = torch.tensor([0x00, 0x34], dtype=torch.uint8, device=dev).repeat((pb - Hkv * 64 * dhb) // 2)
+        perm = torch.randperm(nblocks).reshape(B, mb)
+        t = torch.empty((B, 2, mb), dtype=torch.int64)
+        t[:, 0] = kp.data_ptr() + perm * pb
+        t[:, 1] = vp.data_ptr() + perm * pb
+        pools.append((kp, vp)); tables.append(t.to(dev))
+    qkv = torch.randn((B, (H + 2 * Hkv) * 128), dtype=torch.float16, device=dev)
+    q, k, v = qkv.split([H * 128, Hkv * 128, Hkv * 128], dim=-1)
+    q, k, v = q.reshape(B, H, 128), k.reshape(B, Hkv, 128), v.reshape(B, Hkv, 128)
+    lens = torch.full((B,), L, dtype=torch.int32, device=dev)
+    bytes_ = B * (L - 1) * Hkv * (2 * dhb + 8)
+    row = []
+    for var in ((0, 1) if int4 else (1,)):
+        lib.qs_set_attention_variant(var)
+        us = timeit(lambda i: fa.single_query_attention(q, k, v, tables[i % NL], lens, None, 8192, 64, Hkv * dhb, L, 128, 5e5, True, int4, True), reps=16)
+        row.append(f"variant {var}: {us:7.2f} us {bytes_ / us / 1e3:7.0f} GB/s")
+    lib.qs_set_attention_variant(0)
+    print(f"KV{'4' if int4 else '8'} B={B} L={L}: " + "   ".join(row))

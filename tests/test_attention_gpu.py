@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from _helpers import dev
+from _helpers import dev, ulp_diff_f16
 from oracle import kvattn, synth
 
 pytestmark = pytest.mark.gpu
@@ -67,10 +67,23 @@ def run_case(gpu, B, H, Hkv, lengths, int4, seed):
     assert np.array_equal(dpool.v.cpu().numpy(), p_k.v), "V pages differ after decode (new token)"
     o = out.cpu().numpy().astype(np.float32)
     assert np.isfinite(o).all()
-    ek = np.abs(o - ref_k.astype(np.float32)).max()
-    ef = np.abs(o - ref_f.astype(np.float32)).max()
-    assert ek <= TOL and ef <= TOL, f"attention output error {ek:.2e} (kernel-order oracle) / {ef:.2e} (fp32 oracle)"
-    return ek, ef
+    # tolerance: 1e-3 absolute (north_star).  For sequences of 1-2 tokens the output is ~ a V row itself, |out| can
+    # exceed 1 where fp16 spacing is 9.8e-4 .. 1.95e-3: there the two oracle modes themselves differ by up to 2 ulp
+    # (fp16 hfma2 de-quantisation and fp16-rounded probabilities vs fp32), so <= 2 fp16 ulp is accepted as well.
+    o16 = out.cpu().numpy()
+    ek = np.abs(o - ref_k.astype(np.float32))
+    ef = np.abs(o - ref_f.astype(np.float32))
+    ok_k = (ek <= TOL) | (ulp_diff_f16(o16, ref_k) <= 2)
+    ok_f = (ef <= TOL) | (ulp_diff_f16(o16, ref_f) <= 2)
+    # every output must agree with at least one of the two oracle modes and stay inside their envelope
+    env = np.abs(ref_k.astype(np.float32) - ref_f.astype(np.float32)) + TOL
+    bad = int((~(ok_k | ok_f)).sum()) + int((ek > env).sum()) + int((ef > env).sum())
+    assert bad == 0, (f"{bad} outputs out of tolerance; max abs err {ek.max():.2e} (kernel-order oracle) / "
+                      f"{ef.max():.2e} (fp32 oracle)")
+    long_rows = pr["lengths"] >= 64        # realistic contexts: plain 1e-3
+    if long_rows.any():
+        assert ek[long_rows].max() <= TOL and ef[long_rows].max() <= TOL
+    return ek.max(), ef.max()
 
 
 @pytest.mark.parametrize("int4", [True, False])
@@ -127,6 +140,7 @@ def test_decode_matches_fp32_attention_at_benchmark_size(gpu):
         x = sc.float()[..., None] * (vals - zr.float()[..., None])
         return x.permute(0, 2, 1, 3, 4).reshape(B, Hkv, mb * 64, 128)[:, :, :L]   # includes the new token's slot
     Kd, Vd = gather(pools.k, tables[:, 0]), gather(pools.v, tables[:, 1])
+    Kd, Vd = Kd.clone(), Vd.clone()
     # rotate q like the kernel does (take it from a second prefill-style call on a copy: position L-1)
     qk = new.clone()
     seq1 = torch.ones((B,), dtype=torch.int32, device=gpu)
@@ -135,12 +149,14 @@ def test_decode_matches_fp32_attention_at_benchmark_size(gpu):
     fa.apply_bias_rope_update_kv_cache(qk, torch.full((B,), L, dtype=torch.int32, device=gpu), pad1, None, H, Hkv, L, 64,
                                        Hkv * 64, 128, ROPE, 8192, True, True, True)
     qr = qk[:, : H * 128].reshape(B, Hkv, H // Hkv, 128).float()
+    # the kernel uses the NEW token's rotated k and raw v un-quantised (Template.hpp:1356-1364, 2123-2153)
+    Kd[:, :, L - 1] = qk[:, H * 128:(H + Hkv) * 128].reshape(B, Hkv, 128).float()
+    Vd[:, :, L - 1] = new[:, (H + Hkv) * 128:].reshape(B, Hkv, 128).float()
     s = torch.einsum("bkgd,bktd->bkgt", qr, Kd) / (128 ** 0.5)
     p = torch.softmax(s, dim=-1)
     ref = torch.einsum("bkgt,bktd->bkgd", p, Vd).reshape(B, H, 128)
     err = (out.float() - ref).abs().max().item()
-    # the new token enters the reference quantised here (kernel uses it un-quantised): its weight is ~1/L
-    assert err < 3e-3, err
+    assert err < 1e-3, err
 
 
 def test_rejects_what_reference_rejects(gpu):

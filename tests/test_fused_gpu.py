@@ -67,8 +67,10 @@ def test_rms_norm_and_silu(gpu):
     w = r.uniform(0.5, 1.5, 4096).astype(np.float16)
     out = torch.empty((9, 4096), dtype=torch.float16, device=gpu)
     ln.rms_norm(out, dev(x), dev(w), 1e-5)
-    assert ulp_diff_f16(out.cpu().numpy(), fused.rms_norm(x, w, 1e-5)).max() <= 1
+    # half(x*rstd) can flip by one ulp with the fp32 summation order of the variance, the product by one more
+    assert ulp_diff_f16(out.cpu().numpy(), fused.rms_norm(x, w, 1e-5)).max() <= 2
     y = (r.standard_normal((6, 2 * 14336)) * 2).astype(np.float16)
     o2 = torch.empty((6, 14336), dtype=torch.float16, device=gpu)
     act.silu_and_mul(o2, dev(y))
-    assert ulp_diff_f16(o2.cpu().numpy(), fused.silu_and_mul(y)).max() <= 1
+    # expf differs by an fp32 ulp between libraries: half(silu) can flip by one ulp, the product by one more
+    assert ulp_diff_f16(o2.cpu().numpy(), fused.silu_and_mul(y)).max() <= 2
