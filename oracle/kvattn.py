@@ -155,7 +155,8 @@ def kv_dequantize(qbytes, scale, zero, int4, mode="kernel"):
     KV4 (Utils.h:2125-2213): nibble -> exact fp16 integer (magic-number trick, exact), then
         h = hfma2(h, half_rn(scale), half_rn(-scale*zero))   [scale, zero promoted to fp32 first]
     KV8 (Utils.h:2095-2107): half_rn( scale * (float(u8) - zero) ) in fp32.
-    mode="fp32": plain fp32 `scale*(q-zero)` for both (strict reference-free variant)."""
+    mode="fp32": plain fp32 `scale*(q-zero)` for both, rounded to fp16 (strict reference-free variant);
+    mode="exact": the same value NOT rounded to fp16 (float32 result): the mathematical de-quantisation."""
     q = np.asarray(qbytes, np.uint8)
     sc = np.asarray(scale, np.float16)
     zr = np.asarray(zero, np.float16)
@@ -167,6 +168,8 @@ def kv_dequantize(qbytes, scale, zero, int4, mode="kernel"):
         vals = q
     scf = sc.astype(np.float32)[..., None]
     zrf = zr.astype(np.float32)[..., None]
+    if mode == "exact":
+        return (scf * (vals.astype(np.float32) - zrf).astype(np.float32)).astype(np.float32)
     if mode == "fp32" or not int4:
         out = (scf * (vals.astype(np.float32) - zrf).astype(np.float32)).astype(np.float32)
         return out.astype(np.float16)
@@ -227,7 +230,9 @@ def decode_attention(q, k, v, block_tables, lengths, pool, rope_base, mode="kern
         the 16 threads of a key (Template.hpp:450-467), fp32 softmax with probabilities rounded to fp16
         (:1794-1832), fp32 accumulation of p(fp16)*v(fp16) per 16-token stripe and the final fp16-rounded
         tree reduction over the 16 stripes (:1901-1977, :2163-2187).
-    mode="fp32": everything after dequantisation in fp64/fp32 (strict mathematical definition)."""
+    mode="fp32": everything after dequantisation (to fp16 values) in fp64/fp32;
+    mode="exact": as "fp32" but the de-quantised cache is kept in float32 (no fp16 rounding of K/V values): the
+        mathematical definition of attention over the quantised cache."""
     q = np.asarray(q, np.float16); k = np.asarray(k, np.float16); v = np.asarray(v, np.float16)
     B, H, Dh = q.shape
     Hkv = k.shape[1]

@@ -503,7 +503,7 @@ int launch_decode(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Fl
 // KV4 fast path on the matrix cores (attention_mfma.hip)
 int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
                           const int64_t* kvp, const int* len, _Float16* out, int H, int Hkv, int64_t qs, int64_t kvs,
-                          int mb, int timestep, float base);
+                          int mb, int timestep, float base, int max_pos);
 static int g_attn_variant = 0;   // 0 = MFMA kernel for KV4 (default), 1 = VALU kernel everywhere (A/B tests)
 extern "C" void qs_set_attention_variant(int variant) { g_attn_variant = variant; }
 
@@ -535,7 +535,7 @@ extern "C" int qs_single_query_attention(const void* q, const void* k, const voi
     if (int4_kv_cache && g_attn_variant == 0)
         return qs_launch_decode_mfma(G, grid, st, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
                                      kv_pointers, length_per_sample, (_Float16*)out, num_heads, num_kv_heads,
-                                     q_stride0, kv_stride0, max_blocks, timestep, rotary_base);
+                                     q_stride0, kv_stride0, max_blocks, timestep, rotary_base, memory_max_seqlen);
     if (int4_kv_cache)
         return launch_decode<true>(G, grid, st, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
                                    kv_pointers, length_per_sample, (_Float16*)out, num_heads, num_kv_heads, q_stride0,

@@ -3,21 +3,24 @@
 // Same contract as decode_attention_kernel in attention.hip (reference: fused_attention.cpp:150-240,
 // decoderMaskedMultiheadAttentionTemplate.hpp:717-2222, ZINT4 variant); different mapping:
 //
-//   * one workgroup per (sequence, KV head); its NW waves each own whole 64-token pages (page p -> wave p % NW) and
-//     run QK -> online softmax -> PV on them WITHOUT any workgroup barrier; the partial (max, sum, out) triples are
-//     merged once at the end through LDS (flash-decoding inside the workgroup).
-//   * a page slice (4 KiB K + 4 KiB V + 512 B scales/zeros) is fetched lane-linearly (16 B per lane per load, fully
-//     coalesced), one page ahead, and parked in a wave-private LDS buffer.
-//   * Q.K^T on v_mfma_f32_16x16x32_f16: A = 16 tokens x 32 dims of the K page (lane (tok, kg) holds the 8 nibbles of
-//     one dword, exactly converted to fp16 integers 0..15), B = the G query heads (padded to 16 columns).
-//     score = ksc[tok] * (dot_raw - kzr[tok] * sum_d q_d) / sqrt(128): the per-token scale / zero point is applied to
-//     the 16x16 result instead of to 128 x 64 elements.
-//   * P.V on the same instruction: A = V^T (lane (8-dim group, kg) gathers one dword per token for 8 tokens and
-//     transposes the 8x8 fp16 block in registers with v_perm_b32), B = P'^T with P' = p * vsc[tok] (scale folded into
-//     the probabilities) and the zero-point term sum_t p_t vsc_t vzr_t subtracted from every output dim at the end.
-//   * integer nibbles are exact in fp16 and all accumulation is fp32, so the result is the mathematically exact
-//     attention over the de-quantised cache up to fp16 rounding of q, P' and the output (tighter than the reference's
-//     own fp16 arithmetic; parity bar: 1e-3 on the output, tests/test_attention_gpu.py).
+//   * one workgroup (NW = 8 wave64) per (sequence, KV head); every wave owns whole 64-token pages (page p -> wave
+//     p % NW) and runs QK -> online softmax -> PV on them WITHOUT any workgroup barrier; the partial (max, sum, out)
+//     triples are merged once at the end through LDS (flash-decoding inside the workgroup).  All G = H/Hkv query
+//     heads of the group are served from one read of the page (the reference re-reads it per query head).
+//   * page slices (4 KiB K + 4 KiB V + 2 x 256 B scales/zeros) travel HBM -> LDS by LDS-DMA (global_load_lds, 16 B per
+//     lane, lane-linear = fully coalesced) into wave-private buffers: no staging registers, completion tracked with
+//     counted s_waitcnt vmcnt.  K(p+NW) is requested when Q.K^T of page p is done, V(p+NW) when P.V is done.
+//   * Q.K^T on v_mfma_f32_16x16x32_f16: A = 16 tokens x 32 dims of the K page: lane (tok, kg) turns the 8 nibbles of a
+//     dword into fp16 with the magic-number trick and feeds them IN OFFSET FORM (1024+n, 1024+16n) - the offsets are
+//     removed from the 16x16 result with a per-head constant, the per-token scale / zero point likewise:
+//         score = ksc[tok] * (c_raw - Qoff[head] - kzr[tok] * qsum[head]) / sqrt(128)
+//     so the inner loop spends 5 VALU ops per 8 cache elements instead of 13.
+//   * P.V on the same instruction: A = V^T: lane (8-dim group, kg) reads one dword per token for its 8 tokens;
+//     v_perm_b32 pairs byte bb of two tokens (0x00BB00AA) and the two nibble masks give the fp16 pairs of dims 2bb and
+//     2bb+1 (exact integers 0..15), i.e. the 8x8 transposition costs one perm per 4 elements.  B = P'^T with
+//     P' = fp16(p * vsc[tok]); the zero-point term sum_t P'_t vzr_t is subtracted from every output dim at the end.
+//   * cache integers are exact in fp16 and every accumulation is fp32: the result is the exact attention over the
+//     de-quantised cache up to fp16 rounding of q, P' and the output (parity bar 1e-3, tests/test_attention_gpu.py).
 #include "common.h"
 
 namespace {
@@ -45,22 +48,6 @@ __device__ __forceinline__ void rope_pair(float a, float b, RopeCS cs, _Float16&
     const float rb = cs.c * b + cs.s * a;
     oa = (_Float16)ra;
     ob = (_Float16)rb;
-}
-
-// 8 nibbles of x -> fp16 integers, order (e0,e4),(e1,e5),(e2,e6),(e3,e7)   (exact)
-__device__ __forceinline__ void nib8_to_h2(u32 x, h2 (&o)[4]) {
-    const u32 t = x >> 8;
-    const u32 w0 = (x & 0x000F000Fu) | 0x64006400u;
-    const u32 w1 = (x & 0x00F000F0u) | 0x64006400u;
-    const u32 w2 = (t & 0x000F000Fu) | 0x64006400u;
-    const u32 w3 = (t & 0x00F000F0u) | 0x64006400u;
-    const h2 k1024 = {(_Float16)1024.f, (_Float16)1024.f};
-    const h2 k16 = {(_Float16)0.0625f, (_Float16)0.0625f};
-    const h2 km64 = {(_Float16)-64.f, (_Float16)-64.f};
-    o[0] = __builtin_bit_cast(h2, w0) - k1024;
-    o[1] = __builtin_elementwise_fma(__builtin_bit_cast(h2, w1), k16, km64);
-    o[2] = __builtin_bit_cast(h2, w2) - k1024;
-    o[3] = __builtin_elementwise_fma(__builtin_bit_cast(h2, w3), k16, km64);
 }
 
 struct QParams {
@@ -93,18 +80,22 @@ __device__ __forceinline__ u32 pack_h2(float a, float b) {
     const h2 v = {(_Float16)a, (_Float16)b};
     return __builtin_bit_cast(u32, v);
 }
+// (x & m) | c as ONE v_and_or_b32: m and c live in VGPRs (VOP3 takes no 32-bit literals, which is why the compiler
+// otherwise emits v_and + v_or with literal operands)
+__device__ __forceinline__ u32 and_or(u32 x, u32 m, u32 c) {
+    return (x & m) | c;
+}
 
 template <int G>
 __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
     const int64_t* __restrict__ kv_pointers, const int* __restrict__ lengths, _Float16* __restrict__ out,
     int num_heads, int num_kv_heads, int64_t q_stride0, int64_t kv_stride0, int max_blocks, int timestep,
-    float rope_base) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_k[NW][PAGE_TOK * DHB];
-    __shared__ __attribute__((aligned(16))) uint8_t s_v[NW][PAGE_TOK * DHB];
+    float rope_base, const float2* __restrict__ rope_tab, int rope_tab_len) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_kv[2 * NW * PAGE_TOK * DHB];   // [K | V][wave][4 KiB]
     __shared__ __attribute__((aligned(16))) _Float16 s_meta[NW][4][PAGE_TOK];   // k scale, k zero, v scale, v zero
     __shared__ __attribute__((aligned(16))) _Float16 s_q[16][DH];               // rotated q, rows >= G are zero
-    __shared__ __attribute__((aligned(16))) _Float16 s_qp[16][DH];              // s_q in MFMA operand (nibble) order
+    __shared__ __attribute__((aligned(16))) _Float16 s_qp[16][DH];              // Q.K^T B operand (see below)
     __shared__ __attribute__((aligned(16))) _Float16 s_knew[DH];
     __shared__ float s_cur[16];
     __shared__ float s_m[NW][G], s_l[NW][G];
@@ -118,10 +109,10 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     const int64_t* vtab = ktab + max_blocks;
     const float inv_sqrt = 0.08838834764831845f;
     const int li = lane & 15, tg = lane >> 4;
+    uint8_t* const s_kw = s_kv + wave * (PAGE_TOK * DHB);                // this wave's K page buffer
+    uint8_t* const s_vw = s_kv + (NW + wave) * (PAGE_TOK * DHB);         // this wave's V page buffer
 
-    // ---- page fetch: LDS-DMA (global_load_lds) straight into the wave-private buffers, no staging registers.
-    // K(p+1) is requested as soon as Q.K^T of page p has consumed the K buffer, V(p+1) after P.V of page p; each
-    // transfer has about half an iteration of cover.  Completion is tracked with counted s_waitcnt vmcnt.
+    // ---- page fetch by LDS-DMA ------------------------------------------------------------------------------------
     const int npages = (tl + PAGE_TOK - 1) >> 6;
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -130,7 +121,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         const uint8_t* kd = kbase + (size_t)hkv * PAGE_TOK * DHB + lane * 16;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            __builtin_amdgcn_global_load_lds((gptr_t)(kd + e * 1024), (lptr_t)(&s_k[wave][e * 1024]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(kd + e * 1024), (lptr_t)(s_kw + e * 1024), 16, 0, 0);
         const uint8_t* mb = kbase + (size_t)num_kv_heads * PAGE_TOK * DHB +
                             (size_t)((lane >> 5) * num_kv_heads + hkv) * PAGE_TOK * 2 + (lane & 31) * 4;
         __builtin_amdgcn_global_load_lds((gptr_t)mb, (lptr_t)(&s_meta[wave][0][0]), 4, 0, 0);
@@ -140,7 +131,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         const uint8_t* vd = vbase + (size_t)hkv * PAGE_TOK * DHB + lane * 16;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            __builtin_amdgcn_global_load_lds((gptr_t)(vd + e * 1024), (lptr_t)(&s_v[wave][e * 1024]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(vd + e * 1024), (lptr_t)(s_vw + e * 1024), 16, 0, 0);
         const uint8_t* mb = vbase + (size_t)num_kv_heads * PAGE_TOK * DHB +
                             (size_t)((lane >> 5) * num_kv_heads + hkv) * PAGE_TOK * 2 + (lane & 31) * 4;
         __builtin_amdgcn_global_load_lds((gptr_t)mb, (lptr_t)(&s_meta[wave][2][0]), 4, 0, 0);
@@ -155,7 +146,14 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     const _Float16* kb = k + (size_t)b * kv_stride0 + (size_t)hkv * DH;
     const _Float16* vb = v + (size_t)b * kv_stride0 + (size_t)hkv * DH;
     if (tid < 64) {
-        const RopeCS cs = rope_coef(tid, tl, rope_base, DH);
+        RopeCS cs;
+        if (rope_tab && tl < rope_tab_len) {
+            const float2 t = rope_tab[(size_t)tl * 64 + tid];   // same double-evaluated, float-rounded values
+            cs.c = t.x;
+            cs.s = t.y;
+        } else {
+            cs = rope_coef(tid, tl, rope_base, DH);
+        }
 #pragma unroll
         for (int h = 0; h < G; ++h) {
             _Float16 a, bb;
@@ -183,27 +181,49 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             __half* sc = reinterpret_cast<__half*>(pg + (size_t)num_kv_heads * PAGE_TOK * DHB);
             wave_quant_store4(vb[2 * lane], vb[2 * lane + 1], pg + ((size_t)hkv * PAGE_TOK + slot) * DHB,
                               sc + hkv * PAGE_TOK + slot, sc + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
+        } else if (wave == 2) {
+            // B operand of Q.K^T for lane (head li, kg = tg), MFMA w: dims 32tg + 8w + {0,4,1,5,2,6,3,7}; the positions
+            // that meet hi-nibble operands (1024 + 16 n) carry q/16
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const h8 x = *reinterpret_cast<const h8*>(&s_q[li][32 * tg + 8 * w]);
+                const _Float16 s16 = (_Float16)0.0625f;
+                *reinterpret_cast<h8*>(&s_qp[li][32 * tg + 8 * w]) =
+                    (h8){x[0], x[4], x[1] * s16, x[5] * s16, x[2], x[6], x[3] * s16, x[7] * s16};
+            }
         } else {
-            for (int h = wave - 2; h < G; h += NW - 2) {
+            for (int h = wave - 3; h < G; h += NW - 3) {
                 float d = (float)s_q[h][lane] * (float)s_knew[lane] + (float)s_q[h][64 + lane] * (float)s_knew[64 + lane];
                 d = wave_sum(d);
                 if (lane == 0) s_cur[h] = d * inv_sqrt;
             }
         }
     }
+    __syncthreads();
 
-    // ---- per-lane constants: B operand of Q.K^T (head li, dims 32 tg + 8 w + {0,4,1,5,2,6,3,7}) and sum_d q_d ----
-    // The operand is parked in LDS (s_qp) and re-read per page: 16 fewer live registers in the page loop.
-    float qsum = 0.f;
-    if (wave == 0) {
+    // per-lane constants of head li: qsum = sum_d q_eff_d and Qoff = sum over the operand of 1024 * q' (the offset that
+    // the 1024+n / 1024+16n operand form adds to the raw dot product); q_eff = what the MFMA effectively multiplies n by
+    float qsum, qoff;
+    {
+        float se = 0.f, so = 0.f;   // sums over lo-form / hi-form operand positions of this lane's 32 dims
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const h8 x = *reinterpret_cast<const h8*>(&s_q[li][32 * tg + 8 * w]);
-            *reinterpret_cast<h8*>(&s_qp[li][32 * tg + 8 * w]) = (h8){x[0], x[4], x[1], x[5], x[2], x[6], x[3], x[7]};
+            const h8 x = *reinterpret_cast<const h8*>(&s_qp[li][32 * tg + 8 * w]);
+            se += (float)x[0] + (float)x[1] + (float)x[4] + (float)x[5];
+            so += (float)x[2] + (float)x[3] + (float)x[6] + (float)x[7];
         }
+        se += __shfl_xor(se, 16, 64);
+        se += __shfl_xor(se, 32, 64);
+        so += __shfl_xor(so, 16, 64);
+        so += __shfl_xor(so, 32, 64);
+        qsum = se + 16.f * so;
+        qoff = 1024.f * (se + so);
     }
-    for (int d = 0; d < DH; ++d) qsum += (float)s_q[li][d];   // fp32 sum of the fp16 rotated q of head li
-    __syncthreads();
+    const float nqoff = -qoff;
+
+    // mask / magic constants parked in VGPRs so that (x & m) | c is one v_and_or_b32
+    u32 c_lo = 0x000F000Fu, c_hi = 0x00F000F0u, c_magic = 0x64006400u;
+    asm volatile("" : "+v"(c_lo), "+v"(c_hi), "+v"(c_magic));
 
     v4f acc[8];
 #pragma unroll
@@ -213,7 +233,9 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     for (int p = wave; p < npages; p += NW) {
         // K(p) landed?  Outstanding younger VMEM ops at this point: the 5 of V(p).
         asm volatile("s_waitcnt vmcnt(5) ; QS_LOOP_BEGIN" ::: "memory");
+        const bool more = p + NW < npages;
         const int valid = min(PAGE_TOK, tl - p * PAGE_TOK);
+        const bool full = valid == PAGE_TOK;   // wave-uniform: only the last page needs masking
 
         // ---------------- Q.K^T : 4 tiles of 16 tokens ----------------
         v4f sc[4];
@@ -222,28 +244,31 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         for (int w = 0; w < 4; ++w) qB[w] = *reinterpret_cast<const h8*>(&s_qp[li][32 * tg + 8 * w]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const v4u raw = *reinterpret_cast<const v4u*>(&s_k[wave][(16 * t + li) * DHB + 16 * tg]);
-            v4f c = {0.f, 0.f, 0.f, 0.f};
+            const v4u raw = *reinterpret_cast<const v4u*>(&s_kw[(16 * t + li) * DHB + 16 * tg]);
+            v4f c = {nqoff, nqoff, nqoff, nqoff};   // start at -Qoff: the operand offsets cancel inside the MFMA chain
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                h2 kk[4];
-                nib8_to_h2(raw[w], kk);
-                const h8 a = {kk[0][0], kk[0][1], kk[1][0], kk[1][1], kk[2][0], kk[2][1], kk[3][0], kk[3][1]};
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qB[w], c, 0, 0, 0);
+                const u32 x = raw[w], xs = x >> 8;
+                const v4u a4 = {and_or(x, c_lo, c_magic), and_or(x, c_hi, c_magic), and_or(xs, c_lo, c_magic),
+                                and_or(xs, c_hi, c_magic)};
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a4), qB[w], c, 0, 0, 0);
             }
-            // c[r] = dot_raw(token 16t + 4tg + r, head li); apply the token's scale / zero point
+            // c[r] = raw dot (+ offsets) of token 16t + 4tg + r with head li; undo offsets, apply scale / zero point
             const h4 ks = *reinterpret_cast<const h4*>(&s_meta[wave][0][16 * t + 4 * tg]);
             const h4 kz = *reinterpret_cast<const h4*>(&s_meta[wave][1][16 * t + 4 * tg]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int tok = 16 * t + 4 * tg + r;
-                const float s = (float)ks[r] * (c[r] - (float)kz[r] * qsum) * inv_sqrt;
-                sc[t][r] = tok < valid ? s : -3.0e38f;
-            }
+            for (int r = 0; r < 4; ++r)
+                sc[t][r] = ((float)ks[r] * inv_sqrt) * (c[r] - (float)kz[r] * qsum);
         }
-        // K buffer consumed (all ds_reads returned: their results fed the MFMAs above) -> request K(p+NW)
+        if (!full) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * t + 4 * tg + r >= valid) sc[t][r] = -3.0e38f;   // also discards NaN from garbage scales
+        }
+        // K buffer consumed -> request K(p+NW)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const bool more = p + NW < npages;
         if (more) dma_k(p + NW);
         // ---------------- online softmax (per head = per li; the 4 tg lanes of a head hold 16 tokens each) ---------
         float mx = sc[0][0];
@@ -256,14 +281,13 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __expf(m_run - m_new);
         m_run = m_new;
-        l_part *= alpha;
-        corr *= alpha;
         if (__any(alpha != 1.0f)) {
+            l_part *= alpha;
+            corr *= alpha;
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] *= alpha;
         }
-        // V(p) landed?  Younger VMEM ops: the 5 of K(p+NW) if it was requested.
-        if (more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        if (more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // V(p) landed (K(p+NW) may still be in flight)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ---------------- P.V : two half pages of 32 tokens ----------------
 #pragma unroll
@@ -277,27 +301,29 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
                 float pp[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int tok = 16 * t + 4 * tg + r;
                     const float pe = __expf(sc[t][r] - m_new);          // 0 for masked tokens
                     l_part += pe;
-                    // P' = p * v-scale, rounded to fp16 for the MFMA; the zero-point term uses the SAME rounded value
-                    const float ps = tok < valid ? (float)(_Float16)(pe * (float)vs[r]) : 0.f;
-                    corr += tok < valid ? ps * (float)vz[r] : 0.f;
+                    // P' = p * v-scale rounded to fp16 for the MFMA; the zero-point term uses the SAME rounded value
+                    float ps = (float)(_Float16)(pe * (float)vs[r]);
+                    float pz = ps * (float)vz[r];
+                    if (!full && 16 * t + 4 * tg + r >= valid) {        // garbage (possibly NaN) scales of unused slots
+                        ps = 0.f;
+                        pz = 0.f;
+                    }
+                    corr += pz;
                     pp[r] = ps;
                 }
                 pb[2 * tt] = pack_h2(pp[0], pp[1]);
                 pb[2 * tt + 1] = pack_h2(pp[2], pp[3]);
             }
             const h8 pB = __builtin_bit_cast(h8, (v4u){pb[0], pb[1], pb[2], pb[3]});
-            // V^T operand: lane (dim group li, kg = tg) gathers the dword of its 8 tokens; v_perm_b32 pairs byte bb of two
-            // tokens into one word (0x00BB00AA), whose low / high nibbles become the fp16 pairs of dims 2bb / 2bb+1
-            // through the exact magic-number conversion (no per-element shifts, only the raw dwords stay live).
             u32 raw[8];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
                 const int tok = 16 * (2 * hp + (jj >> 2)) + 4 * tg + (jj & 3);
-                raw[jj] = *reinterpret_cast<const u32*>(&s_v[wave][tok * DHB + 4 * li]);
+                raw[jj] = *reinterpret_cast<const u32*>(&s_vw[tok * DHB + 4 * li]);
             }
+
             const h2 k1024 = {(_Float16)1024.f, (_Float16)1024.f};
             const h2 k16 = {(_Float16)0.0625f, (_Float16)0.0625f};
             const h2 km64 = {(_Float16)-64.f, (_Float16)-64.f};
@@ -307,10 +333,9 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
 #pragma unroll
                 for (int pq = 0; pq < 4; ++pq) {
                     const u32 W = __builtin_amdgcn_perm(raw[2 * pq + 1], raw[2 * pq], 0x0c000c00u | bb | ((4u + bb) << 16));
-                    const u32 wl = (W & 0x000F000Fu) | 0x64006400u;
-                    const u32 wh = (W & 0x00F000F0u) | 0x64006400u;
-                    lo[pq] = __builtin_bit_cast(u32, __builtin_bit_cast(h2, wl) - k1024);
-                    hi[pq] = __builtin_bit_cast(u32, __builtin_elementwise_fma(__builtin_bit_cast(h2, wh), k16, km64));
+                    lo[pq] = __builtin_bit_cast(u32, __builtin_bit_cast(h2, and_or(W, c_lo, c_magic)) - k1024);
+                    hi[pq] = __builtin_bit_cast(
+                        u32, __builtin_elementwise_fma(__builtin_bit_cast(h2, and_or(W, c_hi, c_magic)), k16, km64));
                 }
                 const h8 a_lo = __builtin_bit_cast(h8, (v4u){lo[0], lo[1], lo[2], lo[3]});
                 const h8 a_hi = __builtin_bit_cast(h8, (v4u){hi[0], hi[1], hi[2], hi[3]});
@@ -327,9 +352,10 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     l_part += __shfl_xor(l_part, 32, 64);
     corr += __shfl_xor(corr, 16, 64);
     corr += __shfl_xor(corr, 32, 64);
-    __syncthreads();   // every wave is done with its page buffers: reuse s_k/s_v as the [NW][G][DH] fp32 merge area
-    float (*s_o)[G][DH] = reinterpret_cast<float (*)[G][DH]>(&s_k[0][0]);
-    static_assert(sizeof(float) * G * DH <= PAGE_TOK * DHB, "merge area [NW][G][DH] fp32 must fit s_k");
+    __syncthreads();   // every wave is done with its page buffers: reuse s_k as the [NW][G][DH+4] fp32 merge area
+    constexpr int OS = DH + 4;
+    float (*s_o)[G][OS] = reinterpret_cast<float (*)[G][OS]>(&s_kv[0]);
+    static_assert(sizeof(float) * NW * G * OS <= sizeof(s_kv), "merge area must fit the page buffers");
     if (li < G) {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -358,15 +384,69 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     }
 }
 
+// cos/sin table [max_pos][64] (float2), every entry double-evaluated and rounded once to float32: bit-identical to the
+// in-kernel path and to the oracle (oracle/kvattn.py rope_coef)
+__global__ void rope_table_kernel(float2* __restrict__ tab, int max_pos, float base) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= max_pos * 64) return;
+    const RopeCS cs = rope_coef(i & 63, i >> 6, base, DH);
+    tab[i] = make_float2(cs.c, cs.s);
+}
+
+struct RopeTable {
+    float2* tab = nullptr;
+    int len = 0;
+    float base = 0.f;
+    bool failed = false;
+};
+RopeTable g_rope[16];
+
 }  // namespace
+
+// Library-managed RoPE table (per device, per base).  Returns nullptr when it cannot be (re)built right now, e.g.
+// while the stream is being captured into a graph before the first eager call; callers then compute in-kernel.
+const float2* qs_rope_table(float base, int max_pos, hipStream_t st, int* len_out) {
+    int dev = 0;
+    *len_out = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    RopeTable& r = g_rope[dev];
+    if (max_pos > 32768) max_pos = 32768;
+    if (r.tab && r.base == base && r.len >= max_pos) {
+        *len_out = r.len;
+        return r.tab;
+    }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (r.tab) {
+        (void)hipFree(r.tab);
+        r.tab = nullptr;
+        r.len = 0;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, (size_t)max_pos * 64 * sizeof(float2)) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    r.tab = reinterpret_cast<float2*>(p);
+    r.len = max_pos;
+    r.base = base;
+    hipLaunchKernelGGL(rope_table_kernel, dim3((max_pos * 64 + 255) / 256), dim3(256), 0, st, r.tab, max_pos, base);
+    *len_out = r.len;
+    return r.tab;
+}
 
 // called from attention.hip's dispatcher for KV4
 int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
                           const int64_t* kvp, const int* len, _Float16* out, int H, int Hkv, int64_t qs, int64_t kvs,
-                          int mb, int timestep, float base) {
+                          int mb, int timestep, float base, int max_pos) {
+    int tab_len = 0;
+    const float2* tab = qs_rope_table(base, max_pos, st, &tab_len);
 #define QS_LAUNCH_G(GG)                                                                                             \
     hipLaunchKernelGGL((decode_attention_mfma_kernel<GG>), grid, dim3(NW * 64), 0, st, q, k, v, kvp, len, out, H, Hkv, \
-                       qs, kvs, mb, timestep, base)
+                       qs, kvs, mb, timestep, base, tab, tab_len)
     switch (G) {
         case 1: QS_LAUNCH_G(1); break;
         case 2: QS_LAUNCH_G(2); break;

@@ -26,6 +26,7 @@ for L in LS:
         kp[:, Hkv * 64 * dhb:] = torch.tensor([0x00, 0x34], dtype=torch.uint8, device=dev).repeat((pb - Hkv * 64 * dhb) // 2)
         vp[:, Hkv * 64 * dhb:] = torch.tensor([0x00, 0x34], dtype=torch.uint8, device=dev).repeat((pb - Hkv * 64 * dhb) // 2)
         perm = torch.randperm(nblocks).reshape(B, mb)
+        if os.environ.get('SAMEPAGE'): perm = perm * 0 + (perm % int(os.environ['SAMEPAGE']))
         t = torch.empty((B, 2, mb), dtype=torch.int64)
         t[:, 0] = kp.data_ptr() + perm * pb
         t[:, 1] = vp.data_ptr() + perm * pb
