@@ -54,17 +54,29 @@ def attn_bytes(B, H, Hkv, L, int4):
 
 
 def time_kernel(fn, reps, torch):
-    """Average duration (us) of `reps` launches issued by fn(i) on the current stream, HIP events on that stream."""
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for i in range(min(4, reps)):
+    """Average GPU duration (us) of one launch: `reps` launches issued by fn(i) are captured into a hipGraph (so no
+    host time sits between them, exactly as in the timed decode step) and the replays are bracketed by HIP events
+    recorded on the stream the graph - and therefore every kernel - runs on."""
+    for i in range(min(2, reps)):
         fn(i)
     torch.cuda.synchronize()
-    e0.record()
-    for i in range(reps):
-        fn(i)
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / reps
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            for i in range(reps):
+                fn(i)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(4):
+            g.replay()
+        e1.record(st)
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (4 * reps)
 
 
 def kernel_bench(eng, torch):
