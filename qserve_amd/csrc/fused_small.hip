@@ -40,19 +40,28 @@ __device__ __forceinline__ void store_q8(int8_t* p, const float (&v)[8], float m
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Row kernels keep the whole token row in registers (NC chunks of 8 fp16 per thread, hidden <= NC*2048): ONE global
+// read, all statistics from registers.  At decode batch sizes these kernels are pure latency (64 workgroups), so
+// every removed round trip to memory is ~1-2 us.
+template <int NC>
 __global__ __launch_bounds__(TPB) void quant_kernel(int8_t* __restrict__ out, const _Float16* __restrict__ in,
                                                     __half* __restrict__ sum_out, __half* __restrict__ scale_out,
                                                     int hidden) {
     __shared__ float sm[TPB / 64];
     const size_t base = (size_t)blockIdx.x * hidden;
+    h8 v[NC];
     float amax = 0.f, sum = 0.f;
-    for (int i = threadIdx.x * 8; i < hidden; i += TPB * 8) {
-        h8 v = load8(in + base + i);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float f = (float)v[j];
-            sum += f;
-            amax = fmaxf(amax, fabsf(f));
+    for (int c = 0; c < NC; ++c) {
+        const int i = (c * TPB + threadIdx.x) * 8;
+        if (i < hidden) {
+            v[c] = load8(in + base + i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = (float)v[c][j];
+                sum += f;
+                amax = fmaxf(amax, fabsf(f));
+            }
         }
     }
     amax = block_reduce(amax, sm, 1);
@@ -62,12 +71,15 @@ __global__ __launch_bounds__(TPB) void quant_kernel(int8_t* __restrict__ out, co
         if (sum_out) sum_out[blockIdx.x] = __float2half_rn(sum);         // :121
     }
     const float mul = 127.0f / amax;                                     // :78 (unrounded fp32 amax)
-    for (int i = threadIdx.x * 8; i < hidden; i += TPB * 8) {
-        h8 v = load8(in + base + i);
-        float f[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
-        store_q8(out + base + i, f, mul);
+    for (int c = 0; c < NC; ++c) {
+        const int i = (c * TPB + threadIdx.x) * 8;
+        if (i < hidden) {
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (float)v[c][j];
+            store_q8(out + base + i, f, mul);
+        }
     }
 }
 
@@ -77,6 +89,7 @@ __device__ __forceinline__ float ln_val(float x, float mean, float rstd, float g
     return (x - mean) * rstd * g;                                        // layernorm_kernels.cu:23
 }
 
+template <int NC>
 __global__ __launch_bounds__(TPB) void general_norm_quant_kernel(int8_t* __restrict__ out,
                                                                  const _Float16* __restrict__ in,
                                                                  const _Float16* __restrict__ gamma,
@@ -85,44 +98,53 @@ __global__ __launch_bounds__(TPB) void general_norm_quant_kernel(int8_t* __restr
                                                                  int hidden) {
     __shared__ float sm[TPB / 64];
     const size_t base = (size_t)blockIdx.x * hidden;
+    h8 v[NC], g[NC];
     float s = 0.f;
-    for (int i = threadIdx.x * 8; i < hidden; i += TPB * 8) {
-        h8 v = load8(in + base + i);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += (float)v[j];
+    for (int c = 0; c < NC; ++c) {
+        const int i = (c * TPB + threadIdx.x) * 8;
+        if (i < hidden) {
+            v[c] = load8(in + base + i);
+            g[c] = load8(gamma + i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)v[c][j];
+        }
     }
     const float mean = block_reduce(s, sm, 0) / hidden;                  // :248
     float vs = 0.f;
-    for (int i = threadIdx.x * 8; i < hidden; i += TPB * 8) {
-        h8 v = load8(in + base + i);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float d = (float)v[j] - mean;
-            vs += d * d;
+    for (int c = 0; c < NC; ++c)
+        if ((c * TPB + threadIdx.x) * 8 < hidden) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = (float)v[c][j] - mean;
+                vs += d * d;
+            }
         }
-    }
     const float rstd_e = 1.0f / sqrtf(block_reduce(vs, sm, 0) / hidden + eps);   // :271 (rsqrtf there)
     float amax = (float)(_Float16)1e-6f, sum = 0.f;                      // :285-286 (amax, sum start values)
-    for (int i = threadIdx.x * 8; i < hidden; i += TPB * 8) {
-        h8 v = load8(in + base + i);
-        h8 g = load8(gamma + i);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            _Float16 hv = (_Float16)ln_val((float)v[j], mean, rstd_e, (float)g[j]);   // cast to T = half, :292
-            amax = fmaxf(amax, fabsf((float)hv));
-            sum += (float)hv;
+    for (int c = 0; c < NC; ++c)
+        if ((c * TPB + threadIdx.x) * 8 < hidden) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 hv = (_Float16)ln_val((float)v[c][j], mean, rstd_e, (float)g[c][j]);   // cast to half, :292
+                amax = fmaxf(amax, fabsf((float)hv));
+                sum += (float)hv;
+            }
         }
-    }
     amax = block_reduce(amax, sm, 1);
     if (sum_out) sum = block_reduce(sum, sm, 0);
     const float mul = 127.f / amax;                                      // :308
-    for (int i = threadIdx.x * 8; i < hidden; i += TPB * 8) {
-        h8 v = load8(in + base + i);
-        h8 g = load8(gamma + i);
-        float f[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = ln_val((float)v[j], mean, rstd_e, (float)g[j]);   // fp32, :315
-        store_q8(out + base + i, f, mul);
+    for (int c = 0; c < NC; ++c) {
+        const int i = (c * TPB + threadIdx.x) * 8;
+        if (i < hidden) {
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = ln_val((float)v[c][j], mean, rstd_e, (float)g[c][j]);   // fp32, :315
+            store_q8(out + base + i, f, mul);
+        }
     }
     if (threadIdx.x == 0) {
         scale_out[blockIdx.x] = __float2half_rn(amax / 127.f);           // :322
@@ -159,7 +181,7 @@ __global__ __launch_bounds__(TPB) void rms_norm_kernel(_Float16* __restrict__ ou
 __global__ __launch_bounds__(TPB) void silu_and_mul_kernel(_Float16* __restrict__ out,
                                                            const _Float16* __restrict__ in, int d) {
     const size_t ib = (size_t)blockIdx.x * 2 * d, ob = (size_t)blockIdx.x * d;
-    for (int i = threadIdx.x * 8; i < d; i += TPB * 8) {
+    for (int i = (blockIdx.y * TPB + threadIdx.x) * 8; i < d; i += gridDim.y * TPB * 8) {
         h8 x = load8(in + ib + i);
         h8 y = load8(in + ib + d + i);
         h8 o;
@@ -189,8 +211,18 @@ extern "C" int qs_invoke_quant(int8_t* out, const void* input, void* input_sum, 
     QS_REQUIRE(out && input && scale, "invoke_quant: null pointer");
     QS_REQUIRE(hidden > 0 && hidden % 8 == 0, "invoke_quant: hidden=%d must be a positive multiple of 8", hidden);
     if (num_tokens <= 0) return QS_OK;
-    hipLaunchKernelGGL(quant_kernel, dim3(num_tokens), dim3(TPB), 0, (hipStream_t)stream, out,
-                       (const _Float16*)input, (__half*)input_sum, (__half*)scale, hidden);
+    QS_REQUIRE(hidden <= 8 * TPB * 8, "invoke_quant: hidden=%d larger than %d is not supported", hidden, 8 * TPB * 8);
+    const int nc = (hidden + TPB * 8 - 1) / (TPB * 8);
+#define QS_Q(NC)                                                                                          \
+    hipLaunchKernelGGL(quant_kernel<NC>, dim3(num_tokens), dim3(TPB), 0, (hipStream_t)stream, out,          \
+                       (const _Float16*)input, (__half*)input_sum, (__half*)scale, hidden)
+    switch (nc) {
+        case 1: QS_Q(1); break;
+        case 2: QS_Q(2); break;
+        case 3: case 4: QS_Q(4); break;
+        default: QS_Q(8); break;
+    }
+#undef QS_Q
     return qs_launch_status("invoke_quant");
 }
 
@@ -199,9 +231,19 @@ extern "C" int qs_rms_norm_general(int8_t* out, const void* input, const void* w
     QS_REQUIRE(out && input && weight && scaling, "rms_norm_general: null pointer");
     QS_REQUIRE(hidden > 0 && hidden % 8 == 0, "rms_norm_general: hidden=%d must be a positive multiple of 8", hidden);
     if (num_tokens <= 0) return QS_OK;
-    hipLaunchKernelGGL(general_norm_quant_kernel, dim3(num_tokens), dim3(TPB), 0, (hipStream_t)stream, out,
-                       (const _Float16*)input, (const _Float16*)weight, (__half*)input_sum, (__half*)scaling, epsilon,
-                       hidden);
+    QS_REQUIRE(hidden <= 8 * TPB * 8, "rms_norm_general: hidden=%d larger than %d is not supported", hidden, 8 * TPB * 8);
+    const int nc = (hidden + TPB * 8 - 1) / (TPB * 8);
+#define QS_N(NC)                                                                                                   \
+    hipLaunchKernelGGL(general_norm_quant_kernel<NC>, dim3(num_tokens), dim3(TPB), 0, (hipStream_t)stream, out,     \
+                       (const _Float16*)input, (const _Float16*)weight, (__half*)input_sum, (__half*)scaling, epsilon, \
+                       hidden)
+    switch (nc) {
+        case 1: QS_N(1); break;
+        case 2: QS_N(2); break;
+        case 3: case 4: QS_N(4); break;
+        default: QS_N(8); break;
+    }
+#undef QS_N
     return qs_launch_status("rms_norm_general");
 }
 
@@ -219,7 +261,9 @@ extern "C" int qs_silu_and_mul(void* out, const void* input, int num_tokens, int
     QS_REQUIRE(out && input, "silu_and_mul: null pointer");
     QS_REQUIRE(d > 0 && d % 8 == 0, "silu_and_mul: d=%d must be a positive multiple of 8", d);
     if (num_tokens <= 0) return QS_OK;
-    hipLaunchKernelGGL(silu_and_mul_kernel, dim3(num_tokens), dim3(TPB), 0, (hipStream_t)stream, (_Float16*)out,
+    int chunks = (d + TPB * 8 - 1) / (TPB * 8);
+    if (chunks > 16) chunks = 16;
+    hipLaunchKernelGGL(silu_and_mul_kernel, dim3(num_tokens, chunks), dim3(TPB), 0, (hipStream_t)stream, (_Float16*)out,
                        (const _Float16*)input, d);
     return qs_launch_status("silu_and_mul");
 }

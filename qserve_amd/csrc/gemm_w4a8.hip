@@ -82,7 +82,7 @@ struct Stage {
 };
 
 template <int MT, int MODE, int OUTK, int NSTAGE>
-__global__ __launch_bounds__(256, 2) void w4a8_gemm_splitk(const int8_t* __restrict__ A, const uint8_t* __restrict__ W,
+__global__ __launch_bounds__(MT <= 2 ? 512 : 256, 2) void w4a8_gemm_splitk(const int8_t* __restrict__ A, const uint8_t* __restrict__ W,
                                                         const int8_t* __restrict__ zeros,
                                                         const int8_t* __restrict__ scales8,
                                                         const __half* __restrict__ wscales,
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_splitk(const int8_t* __restr
                                                         const __half* __restrict__ wszs,
                                                         const __half* __restrict__ assums, void* __restrict__ out,
                                                         int* __restrict__ slabs, unsigned* __restrict__ counters,
-                                                        int M, int N, int K) {
+                                                        int M, int N, int K, int mblocks) {
     extern __shared__ __attribute__((aligned(16))) int red[];   // [NW][MT*16][64] ; red[0] doubles as the "last" flag
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -98,8 +98,18 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_splitk(const int8_t* __restr
     const int NW = blockDim.x >> 6;
     const int li = lane & 15, g = lane >> 4;
     const int tsel = li >> 3, c = li & 7;
-    const int T0 = blockIdx.x * 2;
-    const int m0 = blockIdx.y * (16 * MT);
+    // (unit, token block) of this workgroup.  mblocks > 0 selects the XCD-aware 1-D mapping used when M is split over
+    // workgroups: the observed dispatch puts workgroup b on XCD b % 8, so the `mblocks` workgroups that stream the SAME
+    // 64 channels are made adjacent on ONE XCD (b, b+8, b+16, ...) and the weights are fetched from HBM once and
+    // served to the others by that XCD's L2.  Placement affects speed only, never results.
+    int unit = blockIdx.x, mblk = blockIdx.y;
+    if (mblocks > 0) {
+        const int b = blockIdx.x, slot = b >> 3;
+        mblk = slot % mblocks;
+        unit = (slot / mblocks) * 8 + (b & 7);
+    }
+    const int T0 = unit * 2;
+    const int m0 = mblk * (16 * MT);
     const int KT = K >> 5;
     const int nsteps_all = K >> 7;
     const int S = gridDim.z, z = blockIdx.z;
@@ -267,16 +277,16 @@ __global__ __launch_bounds__(256, 2) void w4a8_gemm_splitk(const int8_t* __restr
                 } else {
                     h4 o;
                     const float sa = __half2float(ascales[m]);
+                    const h4 ws4 = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wscales) + n);
                     if (MODE == 0) {
                         const float ss = __half2float(assums[m]);
+                        const h4 wz4 = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wszs) + n);
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            o[r] = (_Float16)epi_per_chn(s[r], __half2float(wscales[n + r]), sa,
-                                                         __half2float(wszs[n + r]), ss);
+                            o[r] = (_Float16)epi_per_chn(s[r], (float)ws4[r], sa, (float)wz4[r], ss);
                     } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            o[r] = (_Float16)epi_per_group(s[r], __half2float(wscales[n + r]), sa);
+                        for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(s[r], (float)ws4[r], sa);
                     }
                     *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(out) + (size_t)m * N + n) = o;
                 }
@@ -323,7 +333,7 @@ Workspace* get_workspace() {
 template <int MT, int MODE, int OUTK, int NSTAGE>
 int launch_splitk(const int8_t* A, const uint8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
                   const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K, int NW,
-                  int S, hipStream_t stream) {
+                  int S, bool xcd_map, hipStream_t stream) {
     auto kern = w4a8_gemm_splitk<MT, MODE, OUTK, NSTAGE>;
     size_t smem = NW > 1 ? (size_t)NW * MT * 16 * 64 * sizeof(int) : 16;
     static size_t configured = 0;   // per instantiation
@@ -337,6 +347,12 @@ int launch_splitk(const int8_t* A, const uint8_t* W, const int8_t* zeros, const 
         configured = smem;
     }
     dim3 grid(N / 64, (M + 16 * MT - 1) / (16 * MT), 1);
+    int mblocks = 0;
+    if (xcd_map && grid.y > 1 && grid.x % 8 == 0 && S == 1) {   // 1-D XCD-aware mapping (see kernel)
+        mblocks = grid.y;
+        grid.x *= grid.y;
+        grid.y = 1;
+    }
     int* slabs = nullptr;
     unsigned* counters = nullptr;
     if (S > 1) {
@@ -352,7 +368,7 @@ int launch_splitk(const int8_t* A, const uint8_t* W, const int8_t* zeros, const 
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, stream, A, W, zeros, scales8,
                        reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
                        reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, slabs,
-                       counters, M, N, K);
+                       counters, M, N, K, mblocks);
     return qs_launch_status("w4a8 gemm");
 }
 
@@ -371,22 +387,48 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const uint8_t* Wu = reinterpret_cast<const uint8_t*>(W);
     const int nsteps = K / 128;
-    // heuristic: 4 waves per block; enough blocks (tiles x S) to put >= ~2 blocks on each of the 256 CUs while every
-    // wave still gets >= 2 k-steps
-    int NW = nsteps >= 4 ? 4 : (nsteps >= 2 ? 2 : 1);
-    const int mtile = M <= 16 ? 1 : M <= 32 ? 2 : M <= 48 ? 3 : 4;
-    const long tiles = (long)(N / 64) * ((M + 16 * mtile - 1) / (16 * mtile));
+    // Heuristic (measured, scripts/bench_gemm*.py):
+    //  * every 64-channel unit is one workgroup whose waves split K (exact int32 reduction in LDS);
+    //  * few units (N/64 < 256 = CUs): the token dimension is split over workgroups as well (16 tokens each, XCD-aware
+    //    mapping so that the co-streaming workgroups share an L2) - more CUs pull the same weight bytes, no reduction
+    //    traffic, 1/4 of the accumulators per wave;
+    //  * cross-block split-K (S > 1) stays off: the release/acquire fences cost more than they save at these sizes.
+    const int units = N / 64;
+    int mtile = M <= 16 ? 1 : M <= 32 ? 2 : M <= 48 ? 3 : 4;
+    bool xcd_map = false;
+    if (units < 256 && units % 8 == 0 && M > 16) {
+        // fewest token blocks that still give >= 192 workgroups (measured: N=6144 -> 2 blocks of 32, N=4096 -> 4 of 16)
+        const int mt_all = (M + 15) / 16;
+        mtile = 1;
+        for (int cand = 4; cand >= 1; cand >>= 1)
+            if (cand <= mt_all && (long)units * ((mt_all + cand - 1) / cand) >= 192) {
+                mtile = cand;
+                break;
+            }
+        xcd_map = mtile < mt_all;
+    }
+    int NW = nsteps >= 16 && mtile <= 2 ? 8 : nsteps >= 4 ? 4 : (nsteps >= 2 ? 2 : 1);
     int S = 1;
-    while (tiles * S < 384 && S < 8 && nsteps / (S * 2) >= NW * 2) S *= 2;
-    if (g_variant >= 1000 && g_variant < 100000) {   // A/B: variant = 1000 + 10*S + NW
-        S = (g_variant - 1000) / 10;
-        NW = (g_variant - 1000) % 10;
+    if (g_variant >= 1000 && g_variant < 100000) {   // A/B: variant = 1000 + 100*mtile_override + 10*S + NW
+        const int v = g_variant - 1000;
+        NW = v % 10;
+        S = (v / 10) % 10;
+        const int mo = v / 100;
+        if (mo >= 1 && mo <= 4) {
+            mtile = mo;
+            xcd_map = mo < (M + 15) / 16;
+        } else if (mo == 9) {        // 9 = classic mapping, one workgroup per unit
+            mtile = M <= 16 ? 1 : M <= 32 ? 2 : M <= 48 ? 3 : 4;
+            xcd_map = false;
+        }
         if (S < 1) S = 1;
         if (NW < 1) NW = 1;
-        if (NW > 4) NW = 4;
+        if (NW > (mtile <= 2 ? 8 : 4)) NW = mtile <= 2 ? 8 : 4;
+        if (NW == 3 || NW == 5 || NW == 6 || NW == 7) NW = 4;
     }
+    if (NW > nsteps) NW = 1;
 #define QS_GO(MTV) \
-    return launch_splitk<MTV, MODE, OUTK, 2>(A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, NW, S, stream)
+    return launch_splitk<MTV, MODE, OUTK, 2>(A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, NW, S, xcd_map, stream)
     if (mtile == 1) QS_GO(1);
     if (mtile == 2) QS_GO(2);
     if (mtile == 3) QS_GO(3);

@@ -22,6 +22,13 @@ import qserve_backend.qgemm_w4a8_per_chn as gemm_chn
 import qserve_backend.qgemm_w4a8_per_group as gemm_grp
 
 from . import tp as tpmod
+from ._lib import check as _check, lib as _lib
+
+
+def residual_add_(a, b):
+    """a += b (fp16), the residual add the reference does with a torch add (llama_w4a8_unpad.py:348,360)."""
+    _check(_lib.qs_residual_add(a.data_ptr(), b.data_ptr(), a.numel(), torch.cuda.current_stream().cuda_stream),
+           "residual_add")
 
 LLAMA3_8B = dict(name="Llama-3-8B", hidden=4096, heads=32, kv_heads=8, inter=14336, layers=32, vocab=128256,
                  rope_theta=5e5, eps=1e-5)
@@ -160,7 +167,7 @@ class DecodeEngine:
                 fused_kernels.invoke_quant(qo, attn, self.q_scale)
             L["o"](qo, self.q_scale, self.q_sum, self.proj_out)
             tpmod.all_reduce_sum_(self.proj_out)
-            h.add_(self.proj_out)
+            residual_add_(h, self.proj_out)
             if fuse_sum:
                 layernorm_ops.rms_norm_general_fuse_sum(qa, h, L["ln2"], self.q_sum, self.q_scale, cfg["eps"], True)
             else:
@@ -173,7 +180,7 @@ class DecodeEngine:
                 fused_kernels.invoke_quant(self.q_mlp, self.mlp_act, self.q_scale)
             L["down"](self.q_mlp, self.q_scale, self.q_sum, self.proj_out)
             tpmod.all_reduce_sum_(self.proj_out)
-            h.add_(self.proj_out)
+            residual_add_(h, self.proj_out)
         layernorm_ops.rms_norm(self.final, h, self.norm_w, cfg["eps"])
         if self.with_lm_head:
             logits = torch.matmul(self.final, self.lm_head.t())      # un-quantised fp16 lm_head (:392,476)
