@@ -372,6 +372,13 @@ int launch_splitk(const int8_t* A, const uint8_t* W, const int8_t* zeros, const 
     return qs_launch_status("w4a8 gemm");
 }
 
+}  // namespace
+// many-channel decode kernel (gemm_w4a8_lds.hip)
+int qs_launch_gemm_pair(int mode, int outk, const int8_t* A, const uint8_t* W, const int8_t* zeros,
+                        const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
+                        const void* assums, void* out, int M, int N, int K, hipStream_t stream);
+namespace {
+
 template <int MODE, int OUTK>
 int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
              const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K,
@@ -394,6 +401,11 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
     //    traffic, 1/4 of the accumulators per wave;
     //  * cross-block split-K (S > 1) stays off: the release/acquire fences cost more than they save at these sizes.
     const int units = N / 64;
+    // many channels: LDS-shared activation tiles + LDS-DMA rings (gemm_w4a8_lds.hip); variant 2000 forces the
+    // split-K kernel, 2001 forces the LDS kernel (A/B tests)
+    if (((units >= 256 && M > 16 && g_variant != 2000) || g_variant == 2001) && N % 128 == 0 && K >= 256)
+        return qs_launch_gemm_pair(MODE, OUTK, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,
+                                   stream);
     int mtile = M <= 16 ? 1 : M <= 32 ? 2 : M <= 48 ? 3 : 4;
     bool xcd_map = false;
     if (units < 256 && units % 8 == 0 && M > 16) {
