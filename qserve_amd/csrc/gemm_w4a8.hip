@@ -377,6 +377,10 @@ int launch_splitk(const int8_t* A, const uint8_t* W, const int8_t* zeros, const 
 int qs_launch_gemm_pair(int mode, int outk, const int8_t* A, const uint8_t* W, const int8_t* zeros,
                         const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
                         const void* assums, void* out, int M, int N, int K, hipStream_t stream);
+// compute-bound tiled kernel (gemm_w4a8_tiled.hip)
+int qs_launch_gemm_tiled(int mode, int outk, const int8_t* A, const uint8_t* W, const int8_t* zeros,
+                         const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
+                         const void* assums, void* out, int M, int N, int K, hipStream_t stream);
 namespace {
 
 template <int MODE, int OUTK>
@@ -401,6 +405,12 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
     //    traffic, 1/4 of the accumulators per wave;
     //  * cross-block split-K (S > 1) stays off: the release/acquire fences cost more than they save at these sizes.
     const int units = N / 64;
+    // compute-bound shapes (prefill): 256x256 LDS-tiled kernel (gemm_w4a8_tiled.hip); variant 3000 disables it,
+    // 3001 forces it
+    if (((M >= 256 && g_variant != 3000 && (g_variant < 1000 || g_variant >= 3000)) || g_variant == 3001) &&
+        N % 256 == 0 && K >= 256)
+        return qs_launch_gemm_tiled(MODE, OUTK, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,
+                                    stream);
     // many channels: LDS-shared activation tiles + LDS-DMA rings (gemm_w4a8_lds.hip); variant 2000 forces the
     // split-K kernel, 2001 forces the LDS kernel (A/B tests)
     if (((units >= 256 && M > 16 && g_variant != 2000) || g_variant == 2001) && N % 128 == 0 && K >= 256)
@@ -450,7 +460,11 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
 
 }  // namespace
 
-extern "C" void qs_set_gemm_variant(int variant) { g_variant = variant; }
+extern int g_tiled_dbg;
+extern "C" void qs_set_gemm_variant(int variant) {
+    if (variant >= 3100 && variant < 3200) { g_tiled_dbg = variant - 3100; return; }
+    g_variant = variant;
+}
 
 extern "C" int qs_w4a8_per_chn_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscales,
                                     const void* ascales, const void* w_szs, const void* a_ssums, void* out_feats,

@@ -44,6 +44,57 @@ def test_per_group_vs_oracle(gpu, M, N, K, valid):
     assert ulp_diff_f16(out.cpu().numpy(), out_ref).max() == 0
 
 
+TILED = [(256, 256, 256), (300, 512, 384), (513, 256, 1024), (1000, 768, 512)]   # prefill-sized: LDS-tiled kernel
+
+
+@pytest.mark.parametrize("M,N,K", TILED)
+def test_tiled_per_channel_vs_oracle(gpu, M, N, K):
+    import qserve_backend.qgemm_w4a8_per_chn as op
+    pr = synth.per_channel_problem(M, N, K, seed=M + N + K)
+    acc_ref, out_ref = w4a8.gemm_per_chn(pr["A"], pr["qweight"], pr["wscales"], pr["ascales"], pr["w_szs"], pr["a_ssums"])
+    A, W = dev(pr["A"]), dev(pr["qweight"])
+    acc = torch.full((M + 3, N), -7, dtype=torch.int32, device=gpu)
+    op.gemm_forward_acc(A, W, acc[:M])
+    assert np.array_equal(acc[:M].cpu().numpy(), acc_ref)
+    assert torch.all(acc[M:] == -7), "rows beyond M were written"
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+    op.gemm_forward_cuda(A, W, dev(pr["wscales"]), dev(pr["ascales"]), dev(pr["w_szs"]), dev(pr["a_ssums"]), out)
+    assert ulp_diff_f16(out.cpu().numpy(), out_ref).max() == 0
+
+
+@pytest.mark.parametrize("M,N,K", TILED)
+@pytest.mark.parametrize("valid", [True, False])
+def test_tiled_per_group_vs_oracle(gpu, M, N, K, valid):
+    import qserve_backend.qgemm_w4a8_per_group as op
+    pr = synth.per_group_problem(M, N, K, seed=M * 3 + N + K, valid=valid)
+    acc_ref, out_ref = w4a8.gemm_per_group(pr["A"], pr["qweight"], pr["s2_zeros"], pr["s2_scales"], pr["wscales"], pr["ascales"])
+    A, W, Z, S = dev(pr["A"]), dev(pr["qweight"]), dev(pr["s2_zeros"]), dev(pr["s2_scales"])
+    acc = torch.full((M, N), -7, dtype=torch.int32, device=gpu)
+    op.gemm_forward_acc(A, W, Z, S, acc)
+    assert np.array_equal(acc.cpu().numpy(), acc_ref)
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+    op.gemm_forward_cuda(A, W, Z, S, dev(pr["wscales"]), dev(pr["ascales"]), out)
+    assert ulp_diff_f16(out.cpu().numpy(), out_ref).max() == 0
+
+
+def test_tiled_kernel_equals_decode_kernel(gpu):
+    """Same problem through both code paths (variant 3000 = tiled kernel off, 3001 = forced with the 128-token tile)."""
+    import qserve_backend.qgemm_w4a8_per_group as op
+    from qserve_amd import _lib
+    pr = synth.per_group_problem(96, 512, 640, seed=5)
+    A, W, Z, S = dev(pr["A"]), dev(pr["qweight"]), dev(pr["s2_zeros"]), dev(pr["s2_scales"])
+    outs = []
+    try:
+        for v in (3000, 3001):
+            _lib.lib.qs_set_gemm_variant(v)
+            out = torch.full((96, 512), float("nan"), dtype=torch.float16, device=gpu)
+            op.gemm_forward_cuda(A, W, Z, S, dev(pr["wscales"]), dev(pr["ascales"]), out)
+            outs.append(out.cpu().numpy())
+    finally:
+        _lib.lib.qs_set_gemm_variant(-1)
+    assert np.array_equal(outs[0].view(np.uint16), outs[1].view(np.uint16))
+
+
 def test_rows_beyond_M_untouched_and_empty_batch(gpu):
     import qserve_backend.qgemm_w4a8_per_chn as op
     pr = synth.per_channel_problem(5, 64, 128, seed=9)
