@@ -460,11 +460,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
 
 }  // namespace
 
-extern int g_tiled_dbg;
-extern "C" void qs_set_gemm_variant(int variant) {
-    if (variant >= 3100 && variant < 3200) { g_tiled_dbg = variant - 3100; return; }
-    g_variant = variant;
-}
+extern "C" void qs_set_gemm_variant(int variant) { g_variant = variant; }
 
 extern "C" int qs_w4a8_per_chn_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscales,
                                     const void* ascales, const void* w_szs, const void* a_ssums, void* out_feats,

@@ -1,27 +1,30 @@
 // gemm_w4a8_tiled.hip -- compute-bound W4A8 GEMM (prefill shapes, BASELINE config 1 = 4096^3): INT8 MFMA, both operands
-// staged through LDS by LDS-DMA.
+// staged through LDS by LDS-DMA, software-pipelined so that LDS reads, DMA issue and operand unpacking all hide under
+// the MFMA stream.
 //
 // Same arithmetic and operand mapping as the decode kernels (gemm_w4a8.hip header; reference kernels
 // kernels/csrc/qgemm/w4a8_per_chn/gemm_cuda.cu:303-594 with its 128x128x64 tile for M > 256, and
 // w4a8_per_group/gemm_cuda.cu:328-628).  Tile geometry chosen for CDNA4, not translated from the reference:
 //   * workgroup = 8 wave64 (512 threads) computes 256 tokens x 256 channels; wave (wm, wn) owns 128 tokens x one
-//     64-channel unit: 8 m-tiles x 4 row classes of v_mfma_i32_16x16x64_i8 accumulators (128 VGPRs), 64 MFMAs per
-//     128-wide k-step against 20 ds_read_b128.
-//   * a k-step moves 32 KiB of activations + 16 KiB of packed weights (+512 B of per-group scales) into a 3-deep LDS
-//     ring with global_load_lds (no staging registers); one raw s_barrier per k-step, counted s_waitcnt vmcnt so that two
-//     k-steps stay in flight across the barrier.  Per CU this is ~24 B/clk of fill at 100 % MFMA rate - right at what
-//     one CU's memory path sustains, which is why the tile is not smaller.
-//   * activation image XOR-swizzled via the DMA source address (conflict-free 16-row operand reads); weight image is
-//     the checkpoint's own tile order (the 64-byte c-rows the operand unpacking wants).
+//     64-channel unit: 8 m-tiles x 4 row classes of v_mfma_i32_16x16x64_i8 accumulators (128 VGPRs).
+//   * pipeline stage = 64 k ("half-step", one MFMA k-slice): 16 KiB of activations + 8 KiB of packed weights (+512 B of
+//     per-group scales) in a 6-deep LDS ring filled by global_load_lds.  One raw s_barrier per stage; counted
+//     s_waitcnt vmcnt keeps four stages (~97 KiB per CU) in flight across it.
+//   * inside a stage every wave runs 32 MFMAs; between them it issues the LDS reads of operands needed 3 m-tiles ahead
+//     (rolling into the next stage), the next stage's weight nibbles + their unpacking, and its share of the DMA for
+//     the stage five ahead - pinned in that order with sched_barrier so the matrix pipe never waits at a stage edge.
+//   * LDS images are bank-conflict free by construction: the DMA writes lane-linear, so the permutation is applied to
+//     the per-lane SOURCE address (activations: 16-byte chunk ^ ((row>>2)&3); weights: [tile][chunk e][k32 ^ tile][c]).
 //   * per-group: level-2 dequant in registers exactly as in the decode kernels (bit-faithful to the reference).
 #include "common.h"
+#include <type_traits>
 
-int g_tiled_dbg = 0;
 namespace {
 
-constexpr int NS = 3;                      // LDS ring depth (k-steps)
+constexpr int NS = 6;                      // LDS ring depth (stages of 64 k)
+constexpr int PD = 4;                      // operand LDS reads run this many m-tiles ahead of the MFMAs
 constexpr int BN = 256;                    // channels per workgroup (4 units)
-constexpr int WSTEP = BN * 64;             // packed weight bytes per k-step = 16 KiB
+constexpr int WSTAGE = BN * 32;            // packed weight bytes per stage = 8 KiB
 
 __device__ __forceinline__ u32 vadd4(u32 a, u32 b) {
     return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
@@ -53,6 +56,7 @@ __device__ __forceinline__ float epi_per_group(int acc, float ws, float sa) {
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef u32 v2u __attribute__((ext_vector_type(2)));
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -63,9 +67,10 @@ __device__ __forceinline__ void raw_barrier() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
+#define QS_PIN() __builtin_amdgcn_sched_barrier(0)
 
 // MT = m-tiles per wave (8 -> 256-token workgroup tile, 4 -> 128)
-template <int MT, int MODE, int OUTK, int DBG = 0>
+template <int MT, int MODE, int OUTK>
 __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restrict__ A, const uint8_t* __restrict__ W,
                                                           const int8_t* __restrict__ zeros,
                                                           const int8_t* __restrict__ scales8,
@@ -74,15 +79,15 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
                                                           const __half* __restrict__ wszs,
                                                           const __half* __restrict__ assums, void* __restrict__ out,
                                                           int M, int N, int K, int nbm) {
-    constexpr int dbg = DBG;
     constexpr int BM = 32 * MT;                       // tokens per workgroup
-    constexpr int ASTEP = BM * 128;                   // activation bytes per k-step
-    constexpr int NA = ASTEP / 8192;                  // 8 KiB all-thread DMA instructions for the activation tile
-    constexpr int NDMA = NA + 2 + (MODE == 1 ? 1 : 0);
+    constexpr int ASTAGE = BM * 64;                   // activation bytes per stage
+    constexpr int NA = ASTAGE / 8192;                 // 8 KiB all-thread DMA instructions for the activation image
+    constexpr int NDMA = NA + 1 + (MODE == 1 ? 1 : 0);
+    static_assert(NDMA <= MT && MT % PD == 0, "pipeline slots");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* const a_ring = smem;                     // [NS][ASTEP]
-    uint8_t* const w_ring = smem + NS * ASTEP;        // [NS][WSTEP]
-    uint8_t* const m_ring = w_ring + NS * WSTEP;      // [NS][512]: 256 scales | 256 zeros (storage order)
+    uint8_t* const a_ring = smem;                     // [NS][ASTAGE]  rows of 64 B, chunk position p holds chunk p^((r>>2)&3)
+    uint8_t* const w_ring = smem + NS * ASTAGE;       // [NS][unit 4][tile 2][e 4][k32^tile 2][c 8][16 B]
+    uint8_t* const m_ring = w_ring + NS * WSTAGE;     // [NS][512]: 256 scales | 256 zeros (storage order)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,45 +97,83 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     // tile coordinates: consecutive workgroups walk M first inside a band of channels (weights of the band stay in L2)
     const int bm = blockIdx.x % nbm, bn = blockIdx.x / nbm;
     const int m0 = bm * BM, n0 = bn * BN;
-    const int m0l = (dbg & 4) ? 0 : m0, n0l = (dbg & 4) ? 0 : n0;
     const int KT = K >> 5;
-    const int nsteps = K >> 7;
+    const int nh = K >> 6;                            // stages
 
-    // ---- DMA sources --------------------------------------------------------------------------------------------
-    const int8_t* a_src[NA];
+    // ---- DMA sources: per-lane 32-bit byte offsets; the stage advance (64 k) goes into the scalar base ---------------
+    // (inline asm rather than __builtin_amdgcn_global_load_lds: the compiler books the builtin as a FLAT access and
+    // from then on degrades every counted LDS wait in the loop to lgkmcnt(0))
+    u32 a_off[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int r = (i * 8 + wave) * 8 + (lane >> 3);          // row of the tile this lane copies in instruction i
-        int row = m0l + r;
+        const int r = (i * 8 + wave) * 16 + (lane >> 2);          // row this lane copies in instruction i
+        int row = m0 + r;
         row = row < M ? row : M - 1;
-        a_src[i] = A + (size_t)row * K + (((lane & 7) ^ (r & 7)) * 16);
+        a_off[i] = (u32)row * (u32)K + (((lane & 3) ^ ((r >> 2) & 3)) * 16);
     }
-    const uint8_t* w_src[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int q = j * 8 + wave;                               // 1 KiB piece: unit q>>2, e = q&3
-        const int unit = q >> 2, e = q & 3;
-        w_src[j] = W + ((size_t)(n0l / 32 + unit * 2 + (e >> 1)) * KT + 2 * (e & 1)) * 512 + lane * 16;
+    u32 w_off;
+    {
+        const int unit = wave >> 1, t = wave & 1;                  // this wave copies tile row 2*unit+t of the band
+        const int e = lane >> 4, kk = ((lane >> 3) & 1) ^ t, cc = lane & 7;
+        w_off = ((u32)(n0 / 32 + unit * 2 + t) * (u32)KT + kk) * 512u + cc * 64 + e * 16;
     }
-    const int8_t* m_src = ((wave & 1) ? zeros : scales8) + n0 + lane * 4;
+    const int8_t* const m_base = ((wave & 1) ? zeros : scales8) + n0;
+    const u32 m_off = lane * 4;
+    const u32 lds0 = (u32)(size_t)(lptr_t)smem;
 
-    // one DMA instruction of k-step ks (pieces 0..NDMA-1); spread over the MFMA stream of the previous step so the
-    // memory system sees a steady trickle instead of a burst after every barrier
-    auto issue_piece = [&](int ks, int p) {
-        const int slot = ks % NS;
-        if (p < NA)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[p] + (size_t)ks * 128),
-                                             (lptr_t)(a_ring + slot * ASTEP + (p * 8 + wave) * 1024), 16, 0, 0);
-        else if (p < NA + 2)
-            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[p - NA] + (size_t)ks * 2048),
-                                             (lptr_t)(w_ring + slot * WSTEP + ((p - NA) * 8 + wave) * 1024), 16, 0, 0);
-        else if (MODE == 1)
-            __builtin_amdgcn_global_load_lds((gptr_t)(m_src + (size_t)ks * N),
-                                             (lptr_t)(m_ring + slot * 512 + (wave & 1) * 256), 4, 0, 0);
+    auto dma16 = [&](u32 voff, const void* sbase, u32 lds_addr) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
+                     : "memory");
     };
-    auto issue = [&](int ks) {
+    auto dma4 = [&](u32 voff, const void* sbase, u32 lds_addr) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
+                     : "memory");
+    };
+    auto issue_piece = [&](int u, int slot, int p) {
+        if (p < NA)
+            dma16(a_off[p], A + (size_t)u * 64, lds0 + slot * ASTAGE + (p * 8 + wave) * 1024);
+        else if (p == NA)
+            dma16(w_off, W + (size_t)u * 1024, lds0 + NS * ASTAGE + slot * WSTAGE + wave * 1024);
+        else if (MODE == 1)
+            dma4(m_off, m_base + (size_t)(u >> 1) * N, lds0 + NS * (ASTAGE + WSTAGE) + slot * 512 + (wave & 1) * 256);
+    };
+
+    // ---- LDS operand readers ----------------------------------------------------------------------------------------
+    const int w_rd = wn * 2048 + tsel * 1024 + (((g >> 1) ^ tsel)) * 128 + c * 16 + (g & 1) * 8;   // + e*256
+    const int m_rd = wn * 64 + (tsel * 8 + c) * 4;
+    const int a_rd = (wm * 16 * MT + li) * 64 + ((g ^ ((li >> 2) & 3)) * 16);                      // + mt*1024
+    auto read_b = [&](int slot, int mt) -> v4i {
+        return *reinterpret_cast<const v4i*>(a_ring + slot * ASTAGE + a_rd + mt * 1024);
+    };
+    struct Raw {
+        v2u r[4];
+        u32 sdw, zdw;
+    };
+    auto read_w = [&](int slot) -> Raw {
+        Raw q;
 #pragma unroll
-        for (int p = 0; p < NDMA; ++p) issue_piece(ks, p);
+        for (int e = 0; e < 4; ++e) q.r[e] = *reinterpret_cast<const v2u*>(w_ring + slot * WSTAGE + w_rd + e * 256);
+        q.sdw = 0;
+        q.zdw = 0;
+        if (MODE == 1) {
+            q.sdw = *reinterpret_cast<const u32*>(m_ring + slot * 512 + m_rd);
+            q.zdw = *reinterpret_cast<const u32*>(m_ring + slot * 512 + 256 + m_rd);
+        }
+        return q;
+    };
+    auto build = [&](const Raw& q, int cl) -> v4i {
+        u32 s = 0, zb = 0;
+        if (MODE == 1) {
+            s = (q.sdw >> (8 * cl)) & 0xFFu;
+            zb = ((q.zdw >> (8 * cl)) & 0xFFu) * 0x01010101u;
+        }
+        v4i a;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const u32 raw = (cl & 1) ? q.r[e].y : q.r[e].x;
+            a[e] = (int)((cl & 2) ? unpack_hi<MODE>(raw, s, zb) : unpack_lo<MODE>(raw, s, zb));
+        }
+        return a;
     };
 
     v4i acc[MT][4];
@@ -139,82 +182,87 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
 #pragma unroll
         for (int cl = 0; cl < 4; ++cl) acc[mt][cl] = (v4i){0, 0, 0, 0};
 
+    // ---- prologue: stages 0..NS-2 in flight, operands of stage 0 in registers ---------------------------------------
 #pragma unroll
     for (int j = 0; j < NS - 1; ++j)
-        if (j < nsteps) issue(j);
+        if (j < nh) {
+#pragma unroll
+            for (int p = 0; p < NDMA; ++p) issue_piece(j, j, p);
+        }
+    if (nh >= NS - 1) wait_vm<(NS - 2) * NDMA>();
+    else wait_vm<0>();
+    raw_barrier();
+    v4i a0[4], a1[4], bq[PD];
+    {
+        const Raw q0 = read_w(0);
+#pragma unroll
+        for (int t = 0; t < PD; ++t) bq[t] = read_b(0, t);
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl) a0[cl] = build(q0, cl);
+    }
 
-    for (int ks = 0; ks < nsteps; ++ks) {
-        if (ks + 1 < nsteps) wait_vm<(NS - 2) * NDMA>();
+    // One stage = 4*MT MFMAs of this wave.  `ac` holds the unpacked weight operands of stage u, `an` receives those of
+    // stage u+1; bq is the rolling activation-operand buffer (tile t lives in bq[t % PD], PD divides MT).
+    auto stage = [&](auto pref_static, bool pref_rt, int u, int slot, v4i(&ac)[4], v4i(&an)[4]) {
+        const int slot_n = slot + 1 == NS ? 0 : slot + 1;
+        const int slot_d = slot == 0 ? NS - 1 : slot - 1;          // (u + NS - 1) % NS
+        Raw qn;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const v4i b_use = bq[mt % PD];
+            if (mt + PD < MT) bq[mt % PD] = read_b(slot, mt + PD);
+            else bq[mt % PD] = read_b(slot_n, mt + PD - MT);
+            if (mt == 0) qn = read_w(slot_n);
+            if (mt < NDMA) {
+                if (decltype(pref_static)::value) issue_piece(u + NS - 1, slot_d, mt);
+                else if (pref_rt) issue_piece(u + NS - 1, slot_d, mt);
+            }
+            if (MT == 8 && mt >= 2 && mt < 6) an[mt - 2] = build(qn, mt - 2);
+            if (MT == 4 && mt >= 2) {
+                an[2 * (mt - 2)] = build(qn, 2 * (mt - 2));
+                an[2 * (mt - 2) + 1] = build(qn, 2 * (mt - 2) + 1);
+            }
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl)
+                acc[mt][cl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ac[cl], b_use, acc[mt][cl], 0, 0, 0);
+            QS_PIN();
+        }
+    };
+    // barrier(u): stage u+1 has landed (this wave's pieces by the counted wait; the barrier extends that to every
+    // wave's) while later stages stay in flight, and every wave is done reading stage u-1, whose slot is refilled next
+    auto tail_wait = [&](int u) {
+        const int rem = nh - 1 - u;
+        if (rem >= NS - 2) wait_vm<(NS - 3) * NDMA>();
+        else if (rem == 3) wait_vm<2 * NDMA>();
+        else if (rem == 2) wait_vm<1 * NDMA>();
         else wait_vm<0>();
-        raw_barrier();                                   // every wave's pieces of step ks landed; step ks-1 fully consumed
-        const bool pref = ks + NS - 1 < nsteps && !(dbg & 2);
-        const int slot = ks % NS;
-        const uint8_t* wb = w_ring + slot * WSTEP + wn * 4096 + (tsel * 4 + g) * 512 + c * 64;
-        v4u ch[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ch[e] = *reinterpret_cast<const v4u*>(wb + e * 16);
-        u32 sdw = 0, zdw = 0;
-        if (MODE == 1) {
-            sdw = *reinterpret_cast<const u32*>(m_ring + slot * 512 + wn * 64 + (tsel * 8 + c) * 4);
-            zdw = *reinterpret_cast<const u32*>(m_ring + slot * 512 + 256 + wn * 64 + (tsel * 8 + c) * 4);
-        }
-        const uint8_t* ab = a_ring + slot * ASTEP + wm * (16 * MT * 128);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            v4i b[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int r = 16 * mt + li;               // (r & 7) == (li & 7): the swizzle key survives the wm offset
-                b[mt] = *reinterpret_cast<const v4i*>(ab + r * 128 + (((2 * g + h) ^ (r & 7)) * 16));
-            }
-            u32 rx[4], ry[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                rx[e] = h ? ch[e].z : ch[e].x;
-                ry[e] = h ? ch[e].w : ch[e].y;
-            }
-#pragma unroll
-            for (int cl = 0; cl < 4; ++cl) {
-                u32 s = 0, zb = 0;
-                if (MODE == 1) {
-                    s = (sdw >> (8 * cl)) & 0xFFu;
-                    zb = ((zdw >> (8 * cl)) & 0xFFu) * 0x01010101u;
-                }
-                v4i a;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const u32 raw = (cl & 1) ? ry[e] : rx[e];
-                    a[e] = (int)((cl & 2) ? unpack_hi<MODE>(raw, s, zb) : unpack_lo<MODE>(raw, s, zb));
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    if (!(dbg & 1)) acc[mt][cl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b[mt], acc[mt][cl], 0, 0, 0);
-                    else acc[mt][cl][0] += a[0] + b[mt][0];
-                if (pref && h * 4 + cl < NDMA) issue_piece(ks + NS - 1, h * 4 + cl);
-            }
-        }
+    };
+    int u = 0, slot = 0;
+    for (; u + NS < nh; u += 2) {                      // steady state: both stages of the pair prefetch, no branches
+        wait_vm<(NS - 3) * NDMA>();
+        raw_barrier();
+        stage(std::true_type{}, true, u, slot, a0, a1);
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        wait_vm<(NS - 3) * NDMA>();
+        raw_barrier();
+        stage(std::true_type{}, true, u + 1, slot, a1, a0);
+        slot = slot + 1 == NS ? 0 : slot + 1;
+    }
+    for (; u < nh; u += 2) {                           // drain
+        tail_wait(u);
+        raw_barrier();
+        stage(std::false_type{}, u + NS - 1 < nh, u, slot, a0, a1);
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        tail_wait(u + 1);
+        raw_barrier();
+        stage(std::false_type{}, u + NS < nh, u + 1, slot, a1, a0);
+        slot = slot + 1 == NS ? 0 : slot + 1;
     }
 
     // ---- fused epilogue -----------------------------------------------------------------------------------------
     // all scale loads first (one latency), then a store-only tail the memory pipe can stream
     const int ncol0 = n0 + wn * 64 + 32 * (g >> 1) + 4 * (g & 1);
     const int mrow0 = m0 + wm * (16 * MT) + li;
-    h4 ws4[4], wz4[4];
-    _Float16 sa_h[MT], ss_h[MT];
-    if (OUTK == 0) {
-#pragma unroll
-        for (int cl = 0; cl < 4; ++cl) {
-            ws4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wscales) + ncol0 + 8 * cl);
-            if (MODE == 0) wz4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wszs) + ncol0 + 8 * cl);
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            int m = mrow0 + 16 * mt;
-            m = m < M ? m : M - 1;
-            sa_h[mt] = reinterpret_cast<const _Float16*>(ascales)[m];
-            if (MODE == 0) ss_h[mt] = reinterpret_cast<const _Float16*>(assums)[m];
-        }
-    }
     if (OUTK == 1) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -225,6 +273,20 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
                 *reinterpret_cast<v4i*>(reinterpret_cast<int*>(out) + (size_t)m * N + ncol0 + 8 * cl) = acc[mt][cl];
         }
         return;
+    }
+    h4 ws4[4], wz4[4];
+    _Float16 sa_h[MT], ss_h[MT];
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl) {
+        ws4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wscales) + ncol0 + 8 * cl);
+        if (MODE == 0) wz4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wszs) + ncol0 + 8 * cl);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = mrow0 + 16 * mt;
+        m = m < M ? m : M - 1;
+        sa_h[mt] = reinterpret_cast<const _Float16*>(ascales)[m];
+        if (MODE == 0) ss_h[mt] = reinterpret_cast<const _Float16*>(assums)[m];
     }
     // fp16 tile of this wave (16*MT tokens x 64 channels) goes through LDS so that every store instruction writes
     // whole 128-byte rows (the accumulator layout would scatter 8-byte pieces over 32 lines per instruction)
@@ -259,13 +321,15 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     }
 }
 
-template <int MT, int MODE, int OUTK, int DBG = 0>
+template <int MT, int MODE, int OUTK>
 int launch_tiled(const int8_t* A, const uint8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
                  const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K,
                  hipStream_t stream) {
-    auto kern = w4a8_gemm_tiled<MT, MODE, OUTK, DBG>;
+    auto kern = w4a8_gemm_tiled<MT, MODE, OUTK>;
     constexpr int BM = 32 * MT;
-    const size_t smem = (size_t)NS * (BM * 128 + WSTEP + 512);
+    size_t smem = (size_t)NS * (BM * 64 + WSTAGE + 512);
+    const size_t stage_out = (size_t)8 * 16 * MT * 144;          // epilogue staging aliases the rings
+    if (smem < stage_out) smem = stage_out;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -287,22 +351,13 @@ int launch_tiled(const int8_t* A, const uint8_t* W, const int8_t* zeros, const i
 
 }  // namespace
 
-// Entry used by the dispatcher in gemm_w4a8.hip.  Preconditions (checked there): N % 256 == 0, K % 128 == 0.
+// Entry used by the dispatcher in gemm_w4a8.hip.  Preconditions (checked there): N % 256 == 0, K % 128 == 0, K >= 256.
 int qs_launch_gemm_tiled(int mode, int outk, const int8_t* A, const uint8_t* W, const int8_t* zeros,
                          const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
                          const void* assums, void* out, int M, int N, int K, hipStream_t stream) {
 #define QS_T(MTV, MODEV, OUTV) \
     return launch_tiled<MTV, MODEV, OUTV>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, stream)
     const bool big = M > 128;
-    if (mode == 0 && outk == 0 && big) {
-        switch (g_tiled_dbg) {
-        case 1: return launch_tiled<8, 0, 0, 1>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, stream);
-        case 2: return launch_tiled<8, 0, 0, 2>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, stream);
-        case 3: return launch_tiled<8, 0, 0, 3>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, stream);
-        case 4: return launch_tiled<8, 0, 0, 4>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, stream);
-        default: break;
-        }
-    }
     if (mode == 0 && outk == 0) { if (big) QS_T(8, 0, 0); QS_T(4, 0, 0); }
     if (mode == 0 && outk == 1) { if (big) QS_T(8, 0, 1); QS_T(4, 0, 1); }
     if (mode == 1 && outk == 0) { if (big) QS_T(8, 1, 0); QS_T(4, 1, 0); }
