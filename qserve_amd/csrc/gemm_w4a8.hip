@@ -380,7 +380,7 @@ int qs_launch_gemm_pair(int mode, int outk, const int8_t* A, const uint8_t* W, c
 // compute-bound tiled kernel (gemm_w4a8_tiled.hip)
 int qs_launch_gemm_tiled(int mode, int outk, const int8_t* A, const uint8_t* W, const int8_t* zeros,
                          const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
-                         const void* assums, void* out, int M, int N, int K, hipStream_t stream);
+                         const void* assums, void* out, int M, int N, int K, int mtile, hipStream_t stream);
 namespace {
 
 template <int MODE, int OUTK>
@@ -405,12 +405,22 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
     //    traffic, 1/4 of the accumulators per wave;
     //  * cross-block split-K (S > 1) stays off: the release/acquire fences cost more than they save at these sizes.
     const int units = N / 64;
-    // compute-bound shapes (prefill): 256x256 LDS-tiled kernel (gemm_w4a8_tiled.hip); variant 3000 disables it,
-    // 3001 forces it
-    if (((M >= 256 && g_variant != 3000 && (g_variant < 1000 || g_variant >= 3000)) || g_variant == 3001) &&
-        N % 256 == 0 && K >= 256)
-        return qs_launch_gemm_tiled(MODE, OUTK, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,
-                                    stream);
+    // compute-bound shapes (prefill): LDS-tiled kernel (gemm_w4a8_tiled.hip), 256- or 128-token tiles, taken once the
+    // tiles fill the chip; variant 3000 disables it, 3001 / 3002 force the 256- / 128-token tile
+    if (N % 256 == 0 && K >= 256 && (size_t)M * K < (1ull << 32) && (size_t)N * K / 2 < (1ull << 32)) {
+        int tmt = 0;
+        if (g_variant == 3001) tmt = 8;
+        else if (g_variant == 3002) tmt = 4;
+        else if (g_variant < 1000 || g_variant > 3002) {
+            const long nb = N / 256;
+            // measured crossovers (scripts/bench_gemm_big.py, N=4096..28672): the tiles must (nearly) fill 256 CUs
+            if (((M + 255) / 256) * nb >= 192) tmt = 8;
+            else if (M >= 512 && ((M + 127) / 128) * nb >= (MODE == 0 ? 96 : 192)) tmt = 4;
+        }
+        if (tmt)
+            return qs_launch_gemm_tiled(MODE, OUTK, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,
+                                        tmt, stream);
+    }
     // many channels: LDS-shared activation tiles + LDS-DMA rings (gemm_w4a8_lds.hip); variant 2000 forces the
     // split-K kernel, 2001 forces the LDS kernel (A/B tests)
     if (((units >= 256 && M > 16 && g_variant != 2000) || g_variant == 2001) && N % 128 == 0 && K >= 256)
@@ -460,7 +470,14 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
 
 }  // namespace
 
-extern "C" void qs_set_gemm_variant(int variant) { g_variant = variant; }
+extern int g_tiled_dbg;   // gemm_w4a8_tiled.hip: timing experiments (3100 + bits)
+extern "C" void qs_set_gemm_variant(int variant) {
+    if (variant >= 3100 && variant < 3200) {
+        g_tiled_dbg = variant - 3100;
+        return;
+    }
+    g_variant = variant;
+}
 
 extern "C" int qs_w4a8_per_chn_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscales,
                                     const void* ascales, const void* w_szs, const void* a_ssums, void* out_feats,

@@ -19,6 +19,7 @@
 #include "common.h"
 #include <type_traits>
 
+int g_tiled_dbg = 0;   // qs_set_gemm_variant(3100 + bits): 1 no MFMA, 2 no DMA, 4 no operand reads, 8 no barrier
 namespace {
 
 constexpr int NS = 6;                      // LDS ring depth (stages of 64 k)
@@ -70,7 +71,7 @@ __device__ __forceinline__ void raw_barrier() {
 #define QS_PIN() __builtin_amdgcn_sched_barrier(0)
 
 // MT = m-tiles per wave (8 -> 256-token workgroup tile, 4 -> 128)
-template <int MT, int MODE, int OUTK>
+template <int MT, int MODE, int OUTK, int DBG = 0>
 __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restrict__ A, const uint8_t* __restrict__ W,
                                                           const int8_t* __restrict__ zeros,
                                                           const int8_t* __restrict__ scales8,
@@ -210,11 +211,14 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const v4i b_use = bq[mt % PD];
-            if (mt + PD < MT) bq[mt % PD] = read_b(slot, mt + PD);
-            else bq[mt % PD] = read_b(slot_n, mt + PD - MT);
+            if (!(DBG & 4)) {
+                if (mt + PD < MT) bq[mt % PD] = read_b(slot, mt + PD);
+                else bq[mt % PD] = read_b(slot_n, mt + PD - MT);
+            }
             if (mt == 0) qn = read_w(slot_n);
             if (mt < NDMA) {
-                if (decltype(pref_static)::value) issue_piece(u + NS - 1, slot_d, mt);
+                if (DBG & 2) {
+                } else if (decltype(pref_static)::value) issue_piece(u + NS - 1, slot_d, mt);
                 else if (pref_rt) issue_piece(u + NS - 1, slot_d, mt);
             }
             if (MT == 8 && mt >= 2 && mt < 6) an[mt - 2] = build(qn, mt - 2);
@@ -224,7 +228,8 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
             }
 #pragma unroll
             for (int cl = 0; cl < 4; ++cl)
-                acc[mt][cl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ac[cl], b_use, acc[mt][cl], 0, 0, 0);
+                if (!(DBG & 1)) acc[mt][cl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ac[cl], b_use, acc[mt][cl], 0, 0, 0);
+                else acc[mt][cl][0] += ac[cl][0] ^ b_use[cl];
             QS_PIN();
         }
     };
@@ -239,12 +244,12 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     };
     int u = 0, slot = 0;
     for (; u + NS < nh; u += 2) {                      // steady state: both stages of the pair prefetch, no branches
-        wait_vm<(NS - 3) * NDMA>();
-        raw_barrier();
+        wait_vm<(DBG & 2) ? 0 : (NS - 3) * NDMA>();
+        if (!(DBG & 8)) raw_barrier();
         stage(std::true_type{}, true, u, slot, a0, a1);
         slot = slot + 1 == NS ? 0 : slot + 1;
-        wait_vm<(NS - 3) * NDMA>();
-        raw_barrier();
+        wait_vm<(DBG & 2) ? 0 : (NS - 3) * NDMA>();
+        if (!(DBG & 8)) raw_barrier();
         stage(std::true_type{}, true, u + 1, slot, a1, a0);
         slot = slot + 1 == NS ? 0 : slot + 1;
     }
@@ -321,11 +326,11 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     }
 }
 
-template <int MT, int MODE, int OUTK>
+template <int MT, int MODE, int OUTK, int DBG = 0>
 int launch_tiled(const int8_t* A, const uint8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
                  const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K,
                  hipStream_t stream) {
-    auto kern = w4a8_gemm_tiled<MT, MODE, OUTK>;
+    auto kern = w4a8_gemm_tiled<MT, MODE, OUTK, DBG>;
     constexpr int BM = 32 * MT;
     size_t smem = (size_t)NS * (BM * 64 + WSTAGE + 512);
     const size_t stage_out = (size_t)8 * 16 * MT * 144;          // epilogue staging aliases the rings
@@ -354,10 +359,18 @@ int launch_tiled(const int8_t* A, const uint8_t* W, const int8_t* zeros, const i
 // Entry used by the dispatcher in gemm_w4a8.hip.  Preconditions (checked there): N % 256 == 0, K % 128 == 0, K >= 256.
 int qs_launch_gemm_tiled(int mode, int outk, const int8_t* A, const uint8_t* W, const int8_t* zeros,
                          const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
-                         const void* assums, void* out, int M, int N, int K, hipStream_t stream) {
+                         const void* assums, void* out, int M, int N, int K, int mtile, hipStream_t stream) {
 #define QS_T(MTV, MODEV, OUTV) \
     return launch_tiled<MTV, MODEV, OUTV>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, stream)
-    const bool big = M > 128;
+    const bool big = mtile == 0 ? M > 128 : mtile == 8;
+    if (mode == 0 && outk == 0 && big && g_tiled_dbg) {   // timing experiments only (results are wrong by design)
+#define QS_D(D) case D: return launch_tiled<8, 0, 0, D>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, stream)
+        switch (g_tiled_dbg) {
+            QS_D(1); QS_D(2); QS_D(3); QS_D(4); QS_D(6); QS_D(8); QS_D(10); QS_D(14);
+        default: break;
+        }
+#undef QS_D
+    }
     if (mode == 0 && outk == 0) { if (big) QS_T(8, 0, 0); QS_T(4, 0, 0); }
     if (mode == 0 && outk == 1) { if (big) QS_T(8, 0, 1); QS_T(4, 0, 1); }
     if (mode == 1 && outk == 0) { if (big) QS_T(8, 1, 0); QS_T(4, 1, 0); }

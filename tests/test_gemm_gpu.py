@@ -47,8 +47,17 @@ def test_per_group_vs_oracle(gpu, M, N, K, valid):
 TILED = [(256, 256, 256), (300, 512, 384), (513, 256, 1024), (1000, 768, 512)]   # prefill-sized: LDS-tiled kernel
 
 
+@pytest.fixture(params=[3001, 3002], ids=["tile256", "tile128"])
+def tiled_variant(request):
+    """The dispatcher only picks the tiled kernel for chip-filling shapes; force it for oracle-sized ones."""
+    from qserve_amd import _lib
+    _lib.lib.qs_set_gemm_variant(request.param)
+    yield request.param
+    _lib.lib.qs_set_gemm_variant(-1)
+
+
 @pytest.mark.parametrize("M,N,K", TILED)
-def test_tiled_per_channel_vs_oracle(gpu, M, N, K):
+def test_tiled_per_channel_vs_oracle(gpu, tiled_variant, M, N, K):
     import qserve_backend.qgemm_w4a8_per_chn as op
     pr = synth.per_channel_problem(M, N, K, seed=M + N + K)
     acc_ref, out_ref = w4a8.gemm_per_chn(pr["A"], pr["qweight"], pr["wscales"], pr["ascales"], pr["w_szs"], pr["a_ssums"])
@@ -64,7 +73,7 @@ def test_tiled_per_channel_vs_oracle(gpu, M, N, K):
 
 @pytest.mark.parametrize("M,N,K", TILED)
 @pytest.mark.parametrize("valid", [True, False])
-def test_tiled_per_group_vs_oracle(gpu, M, N, K, valid):
+def test_tiled_per_group_vs_oracle(gpu, tiled_variant, M, N, K, valid):
     import qserve_backend.qgemm_w4a8_per_group as op
     pr = synth.per_group_problem(M, N, K, seed=M * 3 + N + K, valid=valid)
     acc_ref, out_ref = w4a8.gemm_per_group(pr["A"], pr["qweight"], pr["s2_zeros"], pr["s2_scales"], pr["wscales"], pr["ascales"])
@@ -85,7 +94,7 @@ def test_tiled_kernel_equals_decode_kernel(gpu):
     A, W, Z, S = dev(pr["A"]), dev(pr["qweight"]), dev(pr["s2_zeros"]), dev(pr["s2_scales"])
     outs = []
     try:
-        for v in (3000, 3001):
+        for v in (3000, 3001, 3002):
             _lib.lib.qs_set_gemm_variant(v)
             out = torch.full((96, 512), float("nan"), dtype=torch.float16, device=gpu)
             op.gemm_forward_cuda(A, W, Z, S, dev(pr["wscales"]), dev(pr["ascales"]), out)
@@ -93,6 +102,7 @@ def test_tiled_kernel_equals_decode_kernel(gpu):
     finally:
         _lib.lib.qs_set_gemm_variant(-1)
     assert np.array_equal(outs[0].view(np.uint16), outs[1].view(np.uint16))
+    assert np.array_equal(outs[0].view(np.uint16), outs[2].view(np.uint16))
 
 
 def test_rows_beyond_M_untouched_and_empty_batch(gpu):
@@ -152,9 +162,10 @@ def test_config1_4096_cubed_per_channel(gpu):
     assert torch.equal(acc.to(torch.int64), ref)
 
 
-def test_per_group_full_size_exact_on_device(gpu):
+@pytest.mark.parametrize("M", [128, 2048])     # decode kernel / LDS-tiled kernel (dispatcher's own choice)
+def test_per_group_full_size_exact_on_device(gpu, M):
     import qserve_backend.qgemm_w4a8_per_group as op
-    N, K, M = 4096, 4096, 128
+    N, K = 4096, 4096
     pr = synth.per_group_problem(M, N, K, seed=11)
     A, W, Z, S = dev(pr["A"]), dev(pr["qweight"]), dev(pr["s2_zeros"]), dev(pr["s2_scales"])
     acc = torch.empty((M, N), dtype=torch.int32, device=gpu)
