@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-bench", action="store_true")
+    ap.add_argument("--op-by-op", action="store_true",
+                    help="issue the reference's ops one by one (no fused pairs) in the timed step")
     return ap.parse_args()
 
 
@@ -169,7 +171,8 @@ def main():
     from qserve_amd import decode as D
     cfg = {"llama3-8b": D.LLAMA3_8B, "qwen1.5-72b": D.QWEN15_72B, "tiny": D.TINY}[args.model]
     eng = D.DecodeEngine(cfg, args.batch, args.prompt_len, args.max_new, group_size=args.group_size,
-                         int4_kv=not args.kv8, device=dev, tp_rank=rank, tp_world=world)
+                         int4_kv=not args.kv8, device=dev, tp_rank=rank, tp_world=world,
+                         fuse_pairs=not args.op_by_op)
     eng.prefill_cache(args.prompt_len)
     graphed = False
     if not args.no_graph:
@@ -181,7 +184,8 @@ def main():
                 print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             eng.graph = None
             eng.lengths.fill_(args.prompt_len + 1)
-    assert args.warmup + args.steps + 2 <= args.max_new, "steps exceed the page budget (prompt_len + max_new)"
+    steps2 = 0 if args.op_by_op else min(args.steps, 32)      # secondary timing of the op-by-op sequence
+    assert args.warmup + args.steps + steps2 + 8 <= args.max_new, "steps exceed the page budget (prompt_len + max_new)"
 
     for _ in range(args.warmup):
         eng.run()
@@ -202,6 +206,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = dt / args.steps * 1e3
+
+    # the same model with every reference op issued on its own (fused pairs off): reported next to the headline value
+    ms_op = None
+    if steps2 and graphed and world == 1:
+        eng.fuse_pairs = False
+        eng.capture()
+        for _ in range(2):
+            eng.run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps2):
+            eng.run()
+        torch.cuda.synchronize()
+        ms_op = (time.perf_counter() - t0) / steps2 * 1e3
+        eng.fuse_pairs = True
 
     roof, kernels = None, None
     if not args.no_kernel_bench:
@@ -243,7 +262,11 @@ def main():
                                    f"KV{'8' if args.kv8 else '4'} decode step, bs={args.batch}, context "
                                    f"{args.prompt_len}->+{args.max_new} (BASELINE.json configs[1])",
                        "global_batch": args.batch, "context_start": args.prompt_len + 1 + args.warmup,
-                       "parallelism": f"tp{world}", "hipgraph": graphed, "layers": cfg["layers"]},
+                       "parallelism": f"tp{world}", "hipgraph": graphed, "layers": cfg["layers"],
+                       "op_sequence": "reference ops one by one" if args.op_by_op else
+                       "reference ops; (residual add, layer norm) and (silu_and_mul, quant) issued as bit-identical "
+                       "fused pairs (qserve_amd/fused.py)",
+                       "op_by_op_tokens_per_s": round(args.batch / (ms_op / 1e3), 1) if ms_op else None},
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernels": kernels,

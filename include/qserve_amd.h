@@ -133,6 +133,18 @@ int qs_silu_and_mul(void* out, const void* input, int num_tokens, int d, qs_stre
 /* fp16 residual add (the reference does this with a torch add, llama_w4a8_unpad.py:348,360): a += b */
 int qs_residual_add(void* a, const void* b, int64_t numel, qs_stream_t stream);
 
+/* Pair fusions for the decode loop (no reference counterpart; each is BIT-IDENTICAL to the two calls it replaces and
+ * exists because at decode batch sizes every one of these row kernels is a fixed ~5 us latency chain):
+ *   qs_add_residual_rms_norm_general == qs_residual_add(hidden_io, delta) ; qs_rms_norm_general(out, hidden_io, ...)
+ *        (llama_w4a8_unpad.py:348-351 / :360 + next layer's :337 - the torch add followed by the layer norm)
+ *   qs_silu_and_mul_quant            == qs_silu_and_mul(tmp, input) ; qs_invoke_quant(out, tmp, ...)
+ *        (llama_w4a8_unpad.py:84-91: act_fn then invoke_quant(_fuse_sum)); `input_sum` may be NULL as above. */
+int qs_add_residual_rms_norm_general(int8_t* out, void* hidden_io, const void* delta, const void* weight,
+                                     void* input_sum, void* scaling, float epsilon, int num_tokens, int hidden,
+                                     qs_stream_t stream);
+int qs_silu_and_mul_quant(int8_t* out, const void* input, void* input_sum, void* scale, int num_tokens, int d,
+                          qs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,8 +14,9 @@ namespace {
 
 constexpr int TPB = 256;
 
+template <int NT = TPB>
 __device__ __forceinline__ float block_reduce(float v, float* sm, int op) {
-    // op 0 = sum, 1 = max ; returns the result to every thread
+    // op 0 = sum, 1 = max ; returns the result to every thread (NT threads per workgroup)
     v = op == 0 ? wave_sum(v) : wave_max(v);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     __syncthreads();   // protect sm reuse
@@ -23,9 +24,12 @@ __device__ __forceinline__ float block_reduce(float v, float* sm, int op) {
     __syncthreads();
     float r = sm[0];
 #pragma unroll
-    for (int w = 1; w < TPB / 64; ++w) r = op == 0 ? r + sm[w] : fmaxf(r, sm[w]);
+    for (int w = 1; w < NT / 64; ++w) r = op == 0 ? r + sm[w] : fmaxf(r, sm[w]);
     return r;
 }
+// rows wider than this are handled by 1024-thread workgroups (same rule in invoke_quant and silu_and_mul_quant, so the
+// two associate their fp32 statistics identically)
+constexpr int WIDE_ROW = 4096;
 
 __device__ __forceinline__ h8 load8(const _Float16* p) { return *reinterpret_cast<const h8*>(p); }
 
@@ -43,17 +47,17 @@ __device__ __forceinline__ void store_q8(int8_t* p, const float (&v)[8], float m
 // Row kernels keep the whole token row in registers (NC chunks of 8 fp16 per thread, hidden <= NC*2048): ONE global
 // read, all statistics from registers.  At decode batch sizes these kernels are pure latency (64 workgroups), so
 // every removed round trip to memory is ~1-2 us.
-template <int NC>
-__global__ __launch_bounds__(TPB) void quant_kernel(int8_t* __restrict__ out, const _Float16* __restrict__ in,
+template <int NC, int NT>
+__global__ __launch_bounds__(NT) void quant_kernel(int8_t* __restrict__ out, const _Float16* __restrict__ in,
                                                     __half* __restrict__ sum_out, __half* __restrict__ scale_out,
                                                     int hidden) {
-    __shared__ float sm[TPB / 64];
+    __shared__ float sm[NT / 64];
     const size_t base = (size_t)blockIdx.x * hidden;
     h8 v[NC];
     float amax = 0.f, sum = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const int i = (c * TPB + threadIdx.x) * 8;
+        const int i = (c * NT + threadIdx.x) * 8;
         if (i < hidden) {
             v[c] = load8(in + base + i);
 #pragma unroll
@@ -64,8 +68,8 @@ __global__ __launch_bounds__(TPB) void quant_kernel(int8_t* __restrict__ out, co
             }
         }
     }
-    amax = block_reduce(amax, sm, 1);
-    if (sum_out) sum = block_reduce(sum, sm, 0);
+    amax = block_reduce<NT>(amax, sm, 1);
+    if (sum_out) sum = block_reduce<NT>(sum, sm, 0);
     if (threadIdx.x == 0) {
         scale_out[blockIdx.x] = __float2half_rn(amax / 127.0f);          // fused_kernels.cu:72
         if (sum_out) sum_out[blockIdx.x] = __float2half_rn(sum);         // :121
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(TPB) void quant_kernel(int8_t* __restrict__ out, co
     const float mul = 127.0f / amax;                                     // :78 (unrounded fp32 amax)
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const int i = (c * TPB + threadIdx.x) * 8;
+        const int i = (c * NT + threadIdx.x) * 8;
         if (i < hidden) {
             float f[8];
 #pragma unroll
@@ -204,6 +208,129 @@ __global__ __launch_bounds__(TPB) void residual_add_kernel(_Float16* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Pair fusions for the decode loop.  At batch 64 every one of the row kernels above is a ~4.7 us latency chain
+// (launch -> load -> reduce -> store), so two adjacent ops in one launch cost the same as one.  Both fusions replicate
+// the intermediate fp16 rounding of the op pair they replace, i.e. they are bit-identical to calling the two ops.
+//
+//   add_residual_norm_quant : hidden += delta (fp16 add, written back) ; rms_norm_general(_fuse_sum)(hidden)
+template <int NC>
+__global__ __launch_bounds__(TPB) void add_residual_norm_quant_kernel(int8_t* __restrict__ out,
+                                                                      _Float16* __restrict__ hidden_io,
+                                                                      const _Float16* __restrict__ delta,
+                                                                      const _Float16* __restrict__ gamma,
+                                                                      __half* __restrict__ sum_out,
+                                                                      __half* __restrict__ scale_out, float eps,
+                                                                      int hidden) {
+    __shared__ float sm[TPB / 64];
+    const size_t base = (size_t)blockIdx.x * hidden;
+    h8 v[NC], g[NC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i = (c * TPB + threadIdx.x) * 8;
+        if (i < hidden) {
+            v[c] = load8(hidden_io + base + i) + load8(delta + base + i);    // residual_add_kernel's fp16 add
+            g[c] = load8(gamma + i);
+            *reinterpret_cast<h8*>(hidden_io + base + i) = v[c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)v[c][j];
+        }
+    }
+    const float mean = block_reduce(s, sm, 0) / hidden;
+    float vs = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if ((c * TPB + threadIdx.x) * 8 < hidden) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = (float)v[c][j] - mean;
+                vs += d * d;
+            }
+        }
+    const float rstd_e = 1.0f / sqrtf(block_reduce(vs, sm, 0) / hidden + eps);
+    float amax = (float)(_Float16)1e-6f, sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if ((c * TPB + threadIdx.x) * 8 < hidden) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 hv = (_Float16)ln_val((float)v[c][j], mean, rstd_e, (float)g[c][j]);
+                amax = fmaxf(amax, fabsf((float)hv));
+                sum += (float)hv;
+            }
+        }
+    amax = block_reduce(amax, sm, 1);
+    if (sum_out) sum = block_reduce(sum, sm, 0);
+    const float mul = 127.f / amax;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i = (c * TPB + threadIdx.x) * 8;
+        if (i < hidden) {
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = ln_val((float)v[c][j], mean, rstd_e, (float)g[c][j]);
+            store_q8(out + base + i, f, mul);
+        }
+    }
+    if (threadIdx.x == 0) {
+        scale_out[blockIdx.x] = __float2half_rn(amax / 127.f);
+        if (sum_out) sum_out[blockIdx.x] = __float2half_rn(sum);
+    }
+}
+
+//   silu_mul_quant : act = silu_and_mul(input) rounded to fp16 (never written) ; invoke_quant(_fuse_sum)(act)
+// Same thread -> element mapping and reduction order as quant_kernel, so the fp32 statistics associate identically.
+template <int NC, int NT>
+__global__ __launch_bounds__(NT) void silu_mul_quant_kernel(int8_t* __restrict__ out, const _Float16* __restrict__ in,
+                                                             __half* __restrict__ sum_out,
+                                                             __half* __restrict__ scale_out, int d) {
+    __shared__ float sm[NT / 64];
+    const size_t ib = (size_t)blockIdx.x * 2 * d, ob = (size_t)blockIdx.x * d;
+    h8 x[NC], y[NC], o[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {                     // all loads first: 2*NC 16-byte requests in flight per thread
+        const int i = (c * NT + threadIdx.x) * 8;
+        if (i < d) {
+            x[c] = load8(in + ib + i);
+            y[c] = load8(in + ib + d + i);
+        }
+    }
+    float amax = 0.f, sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i = (c * NT + threadIdx.x) * 8;
+        if (i < d) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xf = (float)x[c][j];
+                const _Float16 sl = (_Float16)(xf / (1.0f + expf(-xf)));    // silu_and_mul_kernel
+                o[c][j] = (_Float16)((float)sl * (float)y[c][j]);
+                const float f = (float)o[c][j];
+                sum += f;                                                    // quant_kernel's statistics
+                amax = fmaxf(amax, fabsf(f));
+            }
+        }
+    }
+    amax = block_reduce<NT>(amax, sm, 1);
+    if (sum_out) sum = block_reduce<NT>(sum, sm, 0);
+    if (threadIdx.x == 0) {
+        scale_out[blockIdx.x] = __float2half_rn(amax / 127.0f);
+        if (sum_out) sum_out[blockIdx.x] = __float2half_rn(sum);
+    }
+    const float mul = 127.0f / amax;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i = (c * NT + threadIdx.x) * 8;
+        if (i < d) {
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (float)o[c][j];
+            store_q8(out + ob + i, f, mul);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int qs_invoke_quant(int8_t* out, const void* input, void* input_sum, void* scale, int num_tokens,
@@ -211,16 +338,18 @@ extern "C" int qs_invoke_quant(int8_t* out, const void* input, void* input_sum, 
     QS_REQUIRE(out && input && scale, "invoke_quant: null pointer");
     QS_REQUIRE(hidden > 0 && hidden % 8 == 0, "invoke_quant: hidden=%d must be a positive multiple of 8", hidden);
     if (num_tokens <= 0) return QS_OK;
-    QS_REQUIRE(hidden <= 8 * TPB * 8, "invoke_quant: hidden=%d larger than %d is not supported", hidden, 8 * TPB * 8);
-    const int nc = (hidden + TPB * 8 - 1) / (TPB * 8);
-#define QS_Q(NC)                                                                                          \
-    hipLaunchKernelGGL(quant_kernel<NC>, dim3(num_tokens), dim3(TPB), 0, (hipStream_t)stream, out,          \
+    QS_REQUIRE(hidden <= 32768, "invoke_quant: hidden=%d larger than 32768 is not supported", hidden);
+#define QS_Q(NC, NT)                                                                                      \
+    hipLaunchKernelGGL((quant_kernel<NC, NT>), dim3(num_tokens), dim3(NT), 0, (hipStream_t)stream, out,     \
                        (const _Float16*)input, (__half*)input_sum, (__half*)scale, hidden)
-    switch (nc) {
-        case 1: QS_Q(1); break;
-        case 2: QS_Q(2); break;
-        case 3: case 4: QS_Q(4); break;
-        default: QS_Q(8); break;
+    if (hidden > WIDE_ROW) {
+        if (hidden <= 8192) QS_Q(1, 1024);
+        else if (hidden <= 16384) QS_Q(2, 1024);
+        else QS_Q(4, 1024);
+    } else {
+        const int nc = (hidden + TPB * 8 - 1) / (TPB * 8);
+        if (nc == 1) QS_Q(1, TPB);
+        else QS_Q(2, TPB);
     }
 #undef QS_Q
     return qs_launch_status("invoke_quant");
@@ -278,4 +407,51 @@ extern "C" int qs_residual_add(void* a, const void* b, int64_t numel, qs_stream_
     hipLaunchKernelGGL(residual_add_kernel, dim3(blocks), dim3(TPB), 0, (hipStream_t)stream, (_Float16*)a,
                        (const _Float16*)b, n8);
     return qs_launch_status("residual_add");
+}
+
+/* ---- pair fusions (bit-identical to the two ops they replace; see the kernels) ---------------------------------- */
+extern "C" int qs_add_residual_rms_norm_general(int8_t* out, void* hidden_io, const void* delta, const void* weight,
+                                                void* input_sum, void* scaling, float epsilon, int num_tokens,
+                                                int hidden, qs_stream_t stream) {
+    QS_REQUIRE(out && hidden_io && delta && weight && scaling, "add_residual_rms_norm_general: null pointer");
+    QS_REQUIRE(hidden > 0 && hidden % 8 == 0, "add_residual_rms_norm_general: hidden=%d must be a positive multiple of 8",
+               hidden);
+    if (num_tokens <= 0) return QS_OK;
+    QS_REQUIRE(hidden <= 8 * TPB * 8, "add_residual_rms_norm_general: hidden=%d larger than %d is not supported", hidden,
+               8 * TPB * 8);
+    const int nc = (hidden + TPB * 8 - 1) / (TPB * 8);
+#define QS_N(NC)                                                                                                      \
+    hipLaunchKernelGGL(add_residual_norm_quant_kernel<NC>, dim3(num_tokens), dim3(TPB), 0, (hipStream_t)stream, out,   \
+                       (_Float16*)hidden_io, (const _Float16*)delta, (const _Float16*)weight, (__half*)input_sum,      \
+                       (__half*)scaling, epsilon, hidden)
+    switch (nc) {
+        case 1: QS_N(1); break;
+        case 2: QS_N(2); break;
+        case 3: case 4: QS_N(4); break;
+        default: QS_N(8); break;
+    }
+#undef QS_N
+    return qs_launch_status("add_residual_rms_norm_general");
+}
+
+extern "C" int qs_silu_and_mul_quant(int8_t* out, const void* input, void* input_sum, void* scale, int num_tokens,
+                                     int d, qs_stream_t stream) {
+    QS_REQUIRE(out && input && scale, "silu_and_mul_quant: null pointer");
+    QS_REQUIRE(d > 0 && d % 8 == 0, "silu_and_mul_quant: d=%d must be a positive multiple of 8", d);
+    if (num_tokens <= 0) return QS_OK;
+    QS_REQUIRE(d <= 32768, "silu_and_mul_quant: d=%d larger than 32768 is not supported", d);
+#define QS_S(NC, NT)                                                                                                \
+    hipLaunchKernelGGL((silu_mul_quant_kernel<NC, NT>), dim3(num_tokens), dim3(NT), 0, (hipStream_t)stream, out,       \
+                       (const _Float16*)input, (__half*)input_sum, (__half*)scale, d)
+    if (d > WIDE_ROW) {                                  // same geometry rule as qs_invoke_quant
+        if (d <= 8192) QS_S(1, 1024);
+        else if (d <= 16384) QS_S(2, 1024);
+        else QS_S(4, 1024);
+    } else {
+        const int nc = (d + TPB * 8 - 1) / (TPB * 8);
+        if (nc == 1) QS_S(1, TPB);
+        else QS_S(2, TPB);
+    }
+#undef QS_S
+    return qs_launch_status("silu_and_mul_quant");
 }

@@ -7,6 +7,10 @@ It issues exactly the op sequence of the reference's model code for `is_prompt=F
     -> residual add -> rms_norm_general_fuse_sum -> gate_up GEMM -> silu_and_mul -> invoke_quant_fuse_sum
     -> down GEMM -> residual add;   then rms_norm, fp16 lm_head, greedy sampling.
 
+With `fuse_pairs=True` (default) the adjacent pairs (residual add, layer norm) and (silu_and_mul, quant) are issued as
+one launch each (qserve_amd/fused.py) - same arithmetic, same intermediate fp16 roundings, bit-identical tensors
+(tests/test_fused_gpu.py, tests/test_decode_gpu.py); `fuse_pairs=False` issues the reference's ops one by one.
+
 Weights are synthetic (random packed nibbles / scales of the right shapes, distinct per layer so nothing is
 served from cache); the KV cache is filled by the prefill writer.  Tensor parallelism: rank r owns
 H/tp query heads, Hkv/tp KV heads and the matching column / row shards; the partial outputs of o_proj and
@@ -21,6 +25,7 @@ import qserve_backend.layernorm_ops as layernorm_ops
 import qserve_backend.qgemm_w4a8_per_chn as gemm_chn
 import qserve_backend.qgemm_w4a8_per_group as gemm_grp
 
+from . import fused as fusedmod
 from . import tp as tpmod
 from ._lib import check as _check, lib as _lib
 
@@ -64,8 +69,11 @@ class W4A8Linear:
 
 class DecodeEngine:
     def __init__(self, cfg, batch, prompt_len, max_new, group_size=-1, int4_kv=True, device="cuda:0", seed=0,
-                 tp_rank=0, tp_world=1, with_lm_head=True):
+                 tp_rank=0, tp_world=1, with_lm_head=True, fuse_pairs=True):
         self.cfg, self.B, self.dev = cfg, batch, torch.device(device)
+        # fuse_pairs: issue (residual add + layer norm) and (silu_and_mul + quant) as one launch each
+        # (qserve_amd/fused.py: bit-identical to the op pairs; False = the reference's exact op-by-op sequence)
+        self.fuse_pairs = fuse_pairs
         self.tp_rank, self.tp_world = tp_rank, tp_world
         self.group_size, self.int4 = group_size, int4_kv
         H, Hkv = cfg["heads"], cfg["kv_heads"]
@@ -149,11 +157,26 @@ class DecodeEngine:
             torch.index_select(self.embed, 0, self.tokens, out=self.hidden)
         h = self.hidden
         qa, qo = self.q_act, self.q_attn
-        for li, L in enumerate(self.layers):
+        fuse = self.fuse_pairs
+        sums = self.q_sum if fuse_sum else None
+
+        def norm_quant(x, w):
             if fuse_sum:
-                layernorm_ops.rms_norm_general_fuse_sum(qa, h, L["ln1"], self.q_sum, self.q_scale, cfg["eps"], True)
+                layernorm_ops.rms_norm_general_fuse_sum(qa, x, w, self.q_sum, self.q_scale, cfg["eps"], True)
             else:
-                layernorm_ops.rms_norm_general(qa, h, L["ln1"], self.q_scale, cfg["eps"], True)
+                layernorm_ops.rms_norm_general(qa, x, w, self.q_scale, cfg["eps"], True)
+
+        def add_norm_quant(x, delta, w):
+            if fuse:
+                fusedmod.add_residual_rms_norm_general(qa, x, delta, w, self.q_scale, cfg["eps"], sums)
+            else:
+                residual_add_(x, delta)
+                norm_quant(x, w)
+
+        nl = len(self.layers)
+        for li, L in enumerate(self.layers):
+            if li == 0:
+                norm_quant(h, L["ln1"])
             L["qkv"](qa, self.q_scale, self.q_sum, self.qkv_buf)
             q, k, v = self.qkv_buf.split([self.H * 128, self.Hkv * 128, self.Hkv * 128], dim=-1)
             attn = fused_attention.single_query_attention(
@@ -167,20 +190,22 @@ class DecodeEngine:
                 fused_kernels.invoke_quant(qo, attn, self.q_scale)
             L["o"](qo, self.q_scale, self.q_sum, self.proj_out)
             tpmod.all_reduce_sum_(self.proj_out)
-            residual_add_(h, self.proj_out)
-            if fuse_sum:
-                layernorm_ops.rms_norm_general_fuse_sum(qa, h, L["ln2"], self.q_sum, self.q_scale, cfg["eps"], True)
-            else:
-                layernorm_ops.rms_norm_general(qa, h, L["ln2"], self.q_scale, cfg["eps"], True)
+            add_norm_quant(h, self.proj_out, L["ln2"])
             L["gate_up"](qa, self.q_scale, self.q_sum, self.gate_up_buf)
-            activation_ops.silu_and_mul(self.mlp_act, self.gate_up_buf)
-            if fuse_sum:
-                fused_kernels.invoke_quant_fuse_sum(self.q_mlp, self.mlp_act, self.q_sum, self.q_scale)
+            if fuse:
+                fusedmod.silu_and_mul_quant(self.q_mlp, self.gate_up_buf, self.q_scale, sums)
             else:
-                fused_kernels.invoke_quant(self.q_mlp, self.mlp_act, self.q_scale)
+                activation_ops.silu_and_mul(self.mlp_act, self.gate_up_buf)
+                if fuse_sum:
+                    fused_kernels.invoke_quant_fuse_sum(self.q_mlp, self.mlp_act, self.q_sum, self.q_scale)
+                else:
+                    fused_kernels.invoke_quant(self.q_mlp, self.mlp_act, self.q_scale)
             L["down"](self.q_mlp, self.q_scale, self.q_sum, self.proj_out)
             tpmod.all_reduce_sum_(self.proj_out)
-            residual_add_(h, self.proj_out)
+            if li + 1 < nl:
+                add_norm_quant(h, self.proj_out, self.layers[li + 1]["ln1"])   # next layer's input norm
+            else:
+                residual_add_(h, self.proj_out)
         layernorm_ops.rms_norm(self.final, h, self.norm_w, cfg["eps"])
         if self.with_lm_head:
             logits = torch.matmul(self.final, self.lm_head.t())      # un-quantised fp16 lm_head (:392,476)

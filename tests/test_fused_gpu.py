@@ -74,3 +74,76 @@ def test_rms_norm_and_silu(gpu):
     act.silu_and_mul(o2, dev(y))
     # expf differs by an fp32 ulp between libraries: half(silu) can flip by one ulp, the product by one more
     assert ulp_diff_f16(o2.cpu().numpy(), fused.silu_and_mul(y)).max() <= 2
+
+
+# ---- pair fusions (qserve_amd/fused.py): bit-identical to the two reference ops they replace -------------------------
+@pytest.mark.parametrize("T,H", [(1, 64), (4, 4096), (64, 4096), (3, 8192), (2, 1000 * 8)])
+@pytest.mark.parametrize("with_sum", [True, False])
+def test_add_residual_norm_equals_op_pair(gpu, T, H, with_sum):
+    import qserve_backend.layernorm_ops as ln
+    from qserve_amd import fused as fz
+    from qserve_amd.decode import residual_add_
+    r = np.random.default_rng(T * 7 + H)
+    h0 = dev((r.standard_normal((T, H)) * 3).astype(np.float16))
+    d = dev((r.standard_normal((T, H)) * 2).astype(np.float16))
+    w = dev(r.uniform(0.5, 1.5, H).astype(np.float16))
+
+    def bufs():
+        return (torch.empty((T, H), dtype=torch.int8, device=gpu), torch.full((T,), -1, dtype=torch.float16, device=gpu),
+                torch.full((T,), -1, dtype=torch.float16, device=gpu))
+    # reference sequence: torch-style add, then the norm op
+    h_ref = h0.clone()
+    q_ref, sc_ref, sm_ref = bufs()
+    residual_add_(h_ref, d)
+    assert torch.equal(h_ref, h0 + d)                      # the add itself is the plain fp16 add
+    if with_sum:
+        ln.rms_norm_general_fuse_sum(q_ref, h_ref, w, sm_ref, sc_ref, 1e-5, True)
+    else:
+        ln.rms_norm_general(q_ref, h_ref, w, sc_ref, 1e-5, True)
+    h = h0.clone()
+    q, sc, sm = bufs()
+    fz.add_residual_rms_norm_general(q, h, d, w, sc, 1e-5, sm if with_sum else None)
+    assert torch.equal(h, h_ref) and torch.equal(q, q_ref)
+    assert torch.equal(sc.view(torch.int16), sc_ref.view(torch.int16))
+    assert torch.equal(sm.view(torch.int16), sm_ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("T,D", [(1, 64), (5, 512), (64, 14336), (3, 24576 // 2), (2, 11008)])
+@pytest.mark.parametrize("with_sum", [True, False])
+def test_silu_mul_quant_equals_op_pair(gpu, T, D, with_sum):
+    import qserve_backend.activation_ops as act
+    import qserve_backend.fused_kernels as fk
+    from qserve_amd import fused as fz
+    x = dev((np.random.default_rng(T + D).standard_normal((T, 2 * D)) * 2).astype(np.float16))
+    tmp = torch.empty((T, D), dtype=torch.float16, device=gpu)
+    act.silu_and_mul(tmp, x)
+    q_ref = torch.empty((T, D), dtype=torch.int8, device=gpu)
+    sc_ref = torch.full((T,), -1, dtype=torch.float16, device=gpu)
+    sm_ref = torch.full((T,), -1, dtype=torch.float16, device=gpu)
+    if with_sum:
+        fk.invoke_quant_fuse_sum(q_ref, tmp, sm_ref, sc_ref)
+    else:
+        fk.invoke_quant(q_ref, tmp, sc_ref)
+    q, sc, sm = torch.empty_like(q_ref), torch.full_like(sc_ref, -1), torch.full_like(sm_ref, -1)
+    fz.silu_and_mul_quant(q, x, sc, sm if with_sum else None)
+    assert torch.equal(q, q_ref)
+    assert torch.equal(sc.view(torch.int16), sc_ref.view(torch.int16))
+    assert torch.equal(sm.view(torch.int16), sm_ref.view(torch.int16))
+
+
+def test_decode_step_fused_pairs_equals_op_by_op(gpu):
+    """Whole decode steps (tiny Llama, 2 layers, both weight granularities): fused-pair engine == op-by-op engine."""
+    from qserve_amd.decode import TINY, DecodeEngine
+    for gs in (-1, 128):
+        outs = []
+        for fuse in (False, True):
+            eng = DecodeEngine(TINY, batch=5, prompt_len=70, max_new=4, group_size=gs, device="cuda:0", seed=3,
+                               fuse_pairs=fuse)
+            eng.prefill_cache(70)
+            toks = []
+            for _ in range(3):
+                eng.step()
+                toks.append(eng.tokens.clone())
+            outs.append((eng.hidden.clone(), eng.final.clone(), torch.stack(toks)))
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b)
