@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Workload for the PMC passes (scripts/gpu_pmc.sh): the step's dominant kernels at bench.py's shapes, eager launches,
+weights / KV pools rotating over 32 layers exactly as in the decode step (nothing is served from the Infinity Cache)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from qserve_amd import decode as D
+import qserve_backend.fused_attention as fa
+
+eng = D.DecodeEngine(D.LLAMA3_8B, 64, 1024, 512, with_lm_head=False)
+eng.prefill_cache(1024)
+eng.lengths.fill_(1100)
+B, nl = eng.B, len(eng.layers)
+q, k, v = eng.qkv_buf.split([eng.H * 128, eng.Hkv * 128, eng.Hkv * 128], dim=-1)
+q, k, v = q.reshape(B, eng.H, 128), k.reshape(B, eng.Hkv, 128), v.reshape(B, eng.Hkv, 128)
+eng.qkv_buf.normal_()
+eng.q_act.random_(-127, 128)
+eng.q_mlp.random_(-127, 128)
+eng.q_scale.fill_(0.01)
+eng.q_sum.fill_(1.0)
+for rep in range(2):
+    for i in range(nl):
+        L = eng.layers[i]
+        L["qkv"](eng.q_act, eng.q_scale, eng.q_sum, eng.qkv_buf)
+        L["gate_up"](eng.q_act, eng.q_scale, eng.q_sum, eng.gate_up_buf)
+        L["down"](eng.q_mlp, eng.q_scale, eng.q_sum, eng.proj_out)
+        fa.single_query_attention(q, k, v, eng.tables[i], eng.lengths, None, 8192, 64, eng.size_per_token,
+                                  eng.max_len, 128, eng.cfg["rope_theta"], True, eng.int4, True)
+torch.cuda.synchronize()
+print("pmc workload done")
