@@ -532,7 +532,9 @@ extern "C" int qs_single_query_attention(const void* q, const void* k, const voi
     dim3 grid(num_kv_heads, batch);
     const int G = num_heads / num_kv_heads;
     hipStream_t st = (hipStream_t)stream;
-    if (int4_kv_cache && g_attn_variant == 0)
+    // the matrix-core kernel caches a sequence's page addresses in LDS (192 pages = 12288 tokens per sequence); longer
+    // page tables take the VALU kernel
+    if (int4_kv_cache && g_attn_variant == 0 && max_blocks <= 192)
         return qs_launch_decode_mfma(G, grid, st, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
                                      kv_pointers, length_per_sample, (_Float16*)out, num_heads, num_kv_heads,
                                      q_stride0, kv_stride0, max_blocks, timestep, rotary_base, memory_max_seqlen);

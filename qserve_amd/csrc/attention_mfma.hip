@@ -29,6 +29,7 @@ constexpr int PAGE_TOK = 64;
 constexpr int DH = 128;
 constexpr int DHB = 64;        // KV4 bytes per token per head
 constexpr int NW = 8;          // waves per workgroup
+constexpr int MAXP = 192;      // page-table entries cached in LDS per sequence (dispatcher: max_blocks <= MAXP)
 
 struct RopeCS {
     float c, s;
@@ -86,6 +87,8 @@ __device__ __forceinline__ u32 and_or(u32 x, u32 m, u32 c) {
     return (x & m) | c;
 }
 
+typedef __attribute__((address_space(3))) const uint8_t* lds_u8;   // 32-bit LDS address (keeps ds_read, not flat_load)
+
 template <int G>
 __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
@@ -94,7 +97,8 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     float rope_base, const float2* __restrict__ rope_tab, int rope_tab_len) {
     __shared__ __attribute__((aligned(16))) uint8_t s_kv[2 * NW * PAGE_TOK * DHB];   // [K | V][wave][4 KiB]
     __shared__ __attribute__((aligned(16))) _Float16 s_meta[NW][4][PAGE_TOK];   // k scale, k zero, v scale, v zero
-    __shared__ __attribute__((aligned(16))) _Float16 s_q[16][DH];               // rotated q, rows >= G are zero
+    __shared__ __attribute__((aligned(16))) _Float16 s_q[G][DH];                // rotated q of the G heads
+    __shared__ int64_t s_ptab[2][MAXP];                                         // page addresses of this sequence
     __shared__ __attribute__((aligned(16))) _Float16 s_qp[16][DH];              // Q.K^T B operand (see below)
     __shared__ __attribute__((aligned(16))) _Float16 s_knew[DH];
     __shared__ float s_cur[16];
@@ -116,29 +120,38 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     const int npages = (tl + PAGE_TOK - 1) >> 6;
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    auto dma_k = [&](int p) {     // 4 x 1 KiB data + 256 B (scales | zeros): 5 VMEM instructions
-        const uint8_t* kbase = reinterpret_cast<const uint8_t*>(ktab[p]);
-        const uint8_t* kd = kbase + (size_t)hkv * PAGE_TOK * DHB + lane * 16;
+    // Page addresses inside the loop come from the LDS copy (s_ptab, filled in phase A): a global load there would sit
+    // in the same in-order vmcnt queue as the LDS-DMA and make K(p+NW) wait for V(p) to land.
+    auto page_addr = [&](int which, int p) -> int64_t {      // in-loop lookup (the dispatcher guarantees p < MAXP)
+        return s_ptab[which][p];
+    };
+    auto dma_k = [&](int64_t page) {     // 4 x 1 KiB data + 256 B (scales | zeros): 5 VMEM instructions
+        const uint8_t* kbase = reinterpret_cast<const uint8_t*>(page);
+        const uint8_t* kd = kbase + (u32)(hkv * PAGE_TOK * DHB + lane * 16);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             __builtin_amdgcn_global_load_lds((gptr_t)(kd + e * 1024), (lptr_t)(s_kw + e * 1024), 16, 0, 0);
-        const uint8_t* mb = kbase + (size_t)num_kv_heads * PAGE_TOK * DHB +
-                            (size_t)((lane >> 5) * num_kv_heads + hkv) * PAGE_TOK * 2 + (lane & 31) * 4;
+        const uint8_t* mb = kbase + (u32)(num_kv_heads * PAGE_TOK * DHB +
+                                          ((lane >> 5) * num_kv_heads + hkv) * PAGE_TOK * 2 + (lane & 31) * 4);
         __builtin_amdgcn_global_load_lds((gptr_t)mb, (lptr_t)(&s_meta[wave][0][0]), 4, 0, 0);
     };
-    auto dma_v = [&](int p) {
-        const uint8_t* vbase = reinterpret_cast<const uint8_t*>(vtab[p]);
-        const uint8_t* vd = vbase + (size_t)hkv * PAGE_TOK * DHB + lane * 16;
+    auto dma_v = [&](int64_t page) {
+        const uint8_t* vbase = reinterpret_cast<const uint8_t*>(page);
+        const uint8_t* vd = vbase + (u32)(hkv * PAGE_TOK * DHB + lane * 16);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             __builtin_amdgcn_global_load_lds((gptr_t)(vd + e * 1024), (lptr_t)(s_vw + e * 1024), 16, 0, 0);
-        const uint8_t* mb = vbase + (size_t)num_kv_heads * PAGE_TOK * DHB +
-                            (size_t)((lane >> 5) * num_kv_heads + hkv) * PAGE_TOK * 2 + (lane & 31) * 4;
+        const uint8_t* mb = vbase + (u32)(num_kv_heads * PAGE_TOK * DHB +
+                                          ((lane >> 5) * num_kv_heads + hkv) * PAGE_TOK * 2 + (lane & 31) * 4);
         __builtin_amdgcn_global_load_lds((gptr_t)mb, (lptr_t)(&s_meta[wave][2][0]), 4, 0, 0);
     };
     if (wave < npages) {
-        dma_k(wave);
-        dma_v(wave);
+        dma_k(ktab[wave]);
+        dma_v(vtab[wave]);
+    }
+    for (int i = tid; i < 2 * MAXP; i += NW * 64) {
+        const int pi = i >> 1;
+        if (pi < npages) s_ptab[i & 1][pi] = (i & 1) ? vtab[pi] : ktab[pi];
     }
 
     // ---- phase A: RoPE of the G query heads and of k; quantise + store the new token's K and V ------------------
@@ -165,8 +178,6 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         rope_pair((float)kb[tid], (float)kb[64 + tid], cs, a, bb);
         s_knew[tid] = a;
         s_knew[64 + tid] = bb;
-    } else {
-        for (int i = tid - 64; i < (16 - G) * DH; i += NW * 64 - 64) s_q[G + i / DH][i % DH] = (_Float16)0.f;
     }
     __syncthreads();
     {
@@ -186,7 +197,8 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             // that meet hi-nibble operands (1024 + 16 n) carry q/16
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                const h8 x = *reinterpret_cast<const h8*>(&s_q[li][32 * tg + 8 * w]);
+                h8 x = {0, 0, 0, 0, 0, 0, 0, 0};                       // heads >= G: zero rows of the operand
+                if (li < G) x = *reinterpret_cast<const h8*>(&s_q[li][32 * tg + 8 * w]);
                 const _Float16 s16 = (_Float16)0.0625f;
                 *reinterpret_cast<h8*>(&s_qp[li][32 * tg + 8 * w]) =
                     (h8){x[0], x[4], x[1] * s16, x[5] * s16, x[2], x[6], x[3] * s16, x[7] * s16};
@@ -237,14 +249,26 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         const int valid = min(PAGE_TOK, tl - p * PAGE_TOK);
         const bool full = valid == PAGE_TOK;   // wave-uniform: only the last page needs masking
 
+        // one opaque per-lane base per buffer: every operand read below is base + immediate (without this the compiler
+        // hoists a dozen loop-invariant address registers out of the loop and spills them)
+        // (the lane id itself is re-derived here with v_mbcnt so that no per-lane address survives across iterations:
+        // with 128 VGPRs the allocator otherwise spills one and reloads it - a scratch load whose vmcnt(0) wait would
+        // also drain the LDS-DMA queue)
+        u32 lid;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
+        const int li_ = lid & 15, tg_ = lid >> 4;
+        const lds_u8 kl = (lds_u8)s_kw + (li_ * DHB + 16 * tg_);
+        const lds_u8 vl = (lds_u8)s_vw + ((4 * tg_) * DHB + 4 * li_);
+        const lds_u8 ml = (lds_u8)(&s_meta[wave][0][0]) + 8 * tg_;
+        const lds_u8 ql = (lds_u8)(&s_qp[0][0]) + (li_ * (DH * 2) + 64 * tg_);
         // ---------------- Q.K^T : 4 tiles of 16 tokens ----------------
         v4f sc[4];
         h8 qB[4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) qB[w] = *reinterpret_cast<const h8*>(&s_qp[li][32 * tg + 8 * w]);
+        for (int w = 0; w < 4; ++w) qB[w] = *(const __attribute__((address_space(3))) h8*)(ql + 16 * w);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const v4u raw = *reinterpret_cast<const v4u*>(&s_kw[(16 * t + li) * DHB + 16 * tg]);
+            const v4u raw = *(const __attribute__((address_space(3))) v4u*)(kl + 16 * t * DHB);
             v4f c = {nqoff, nqoff, nqoff, nqoff};   // start at -Qoff: the operand offsets cancel inside the MFMA chain
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -254,8 +278,8 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
                 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a4), qB[w], c, 0, 0, 0);
             }
             // c[r] = raw dot (+ offsets) of token 16t + 4tg + r with head li; undo offsets, apply scale / zero point
-            const h4 ks = *reinterpret_cast<const h4*>(&s_meta[wave][0][16 * t + 4 * tg]);
-            const h4 kz = *reinterpret_cast<const h4*>(&s_meta[wave][1][16 * t + 4 * tg]);
+            const h4 ks = *(const __attribute__((address_space(3))) h4*)(ml + 2 * (16 * t));
+            const h4 kz = *(const __attribute__((address_space(3))) h4*)(ml + 2 * (PAGE_TOK + 16 * t));
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 sc[t][r] = ((float)ks[r] * inv_sqrt) * (c[r] - (float)kz[r] * qsum);
@@ -265,11 +289,11 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (16 * t + 4 * tg + r >= valid) sc[t][r] = -3.0e38f;   // also discards NaN from garbage scales
+                    if (16 * t + 4 * tg_ + r >= valid) sc[t][r] = -3.0e38f;   // also discards NaN from garbage scales
         }
         // K buffer consumed -> request K(p+NW)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (more) dma_k(p + NW);
+        if (more) dma_k(page_addr(0, p + NW));
         // ---------------- online softmax (per head = per li; the 4 tg lanes of a head hold 16 tokens each) ---------
         float mx = sc[0][0];
 #pragma unroll
@@ -296,8 +320,8 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const int t = 2 * hp + tt;
-                const h4 vs = *reinterpret_cast<const h4*>(&s_meta[wave][2][16 * t + 4 * tg]);
-                const h4 vz = *reinterpret_cast<const h4*>(&s_meta[wave][3][16 * t + 4 * tg]);
+                const h4 vs = *(const __attribute__((address_space(3))) h4*)(ml + 2 * (2 * PAGE_TOK + 16 * t));
+                const h4 vz = *(const __attribute__((address_space(3))) h4*)(ml + 2 * (3 * PAGE_TOK + 16 * t));
                 float pp[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -306,7 +330,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
                     // P' = p * v-scale rounded to fp16 for the MFMA; the zero-point term uses the SAME rounded value
                     float ps = (float)(_Float16)(pe * (float)vs[r]);
                     float pz = ps * (float)vz[r];
-                    if (!full && 16 * t + 4 * tg + r >= valid) {        // garbage (possibly NaN) scales of unused slots
+                    if (!full && 16 * t + 4 * tg_ + r >= valid) {        // garbage (possibly NaN) scales of unused slots
                         ps = 0.f;
                         pz = 0.f;
                     }
@@ -320,8 +344,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             u32 raw[8];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                const int tok = 16 * (2 * hp + (jj >> 2)) + 4 * tg + (jj & 3);
-                raw[jj] = *reinterpret_cast<const u32*>(&s_vw[tok * DHB + 4 * li]);
+                raw[jj] = *(const __attribute__((address_space(3))) u32*)(vl + (16 * (2 * hp + (jj >> 2)) + (jj & 3)) * DHB);
             }
 
             const h2 k1024 = {(_Float16)1024.f, (_Float16)1024.f};
@@ -344,7 +367,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0) ; QS_LOOP_END" ::: "memory");
-        if (more) dma_v(p + NW);
+        if (more) dma_v(page_addr(1, p + NW));
     }
 
     // ---- per-wave partials -> LDS.  Lane (head li, tg) holds out dims 8*(4tg + r) + e in acc[e][r] ---------------
