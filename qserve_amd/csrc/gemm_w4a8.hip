@@ -377,6 +377,10 @@ int launch_splitk(const int8_t* A, const uint8_t* W, const int8_t* zeros, const 
 int qs_launch_gemm_pair(int mode, int outk, const int8_t* A, const uint8_t* W, const int8_t* zeros,
                         const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
                         const void* assums, void* out, int M, int N, int K, hipStream_t stream);
+// decode ring kernel (gemm_w4a8_ring.hip)
+int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, const uint8_t* W, const int8_t* zeros,
+                        const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
+                        const void* assums, void* out, int M, int N, int K, int mblocks, hipStream_t stream);
 // compute-bound tiled kernel (gemm_w4a8_tiled.hip)
 int qs_launch_gemm_tiled(int mode, int outk, const int8_t* A, const uint8_t* W, const int8_t* zeros,
                          const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
@@ -420,6 +424,38 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         if (tmt)
             return qs_launch_gemm_tiled(MODE, OUTK, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,
                                         tmt, stream);
+    }
+    // decode shapes: LDS-DMA ring kernel with operands read one stage ahead (gemm_w4a8_ring.hip); variant 4000
+    // disables it (A/B tests against the two older decode kernels below)
+    if (g_variant >= 4100 && g_variant < 4200) {       // tests: force geometry 4100 + 10*mt + wn (mt tiles, wn units)
+        const int mt = (g_variant - 4100) / 10, wn = (g_variant - 4100) % 10;
+        const int mb = ((M + 15) / 16 + mt - 1) / mt;
+        QS_REQUIRE((mt == 1 || mt == 2 || mt == 4) && (wn == 1 || wn == 2) && !(mt == 1 && wn == 2) &&
+                       N % (64 * wn) == 0 && (K / 64) % (16 / wn) == 0 && (mb == 1 || (N / (64 * wn)) % 8 == 0),
+                   "w4a8 gemm: forced ring geometry mt=%d wn=%d does not fit M=%d N=%d K=%d", mt, wn, M, N, K);
+        return qs_launch_gemm_ring(MODE, OUTK, mt, wn, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N,
+                                   K, mb, stream);
+    }
+    if (M <= 64 && M > 16 && g_variant != 4000 && (g_variant < 1000 || g_variant >= 4000) &&
+        (size_t)M * K < (1ull << 32) && (size_t)N * K / 2 < (1ull << 32)) {
+        const int mt_all = (M + 15) / 16;
+        if (units >= 256 && N % 128 == 0 && (K / 64) % 8 == 0)          // many channels: 2 units x 4 K-groups
+            return qs_launch_gemm_ring(MODE, OUTK, mt_all <= 2 ? 2 : 4, 2, A, Wu, zeros, scales8, wscales, ascales,
+                                       wszs, assums, out, M, N, K, 1, stream);
+        if (units < 256 && units % 8 == 0 && (K / 64) % 16 == 0) {      // few channels: 1 unit x 8 K-groups, M split
+            int mt = 1;
+            for (int cand = 4; cand >= 1; cand >>= 1) {
+                if (cand > mt_all && cand > 1) continue;
+                const int mb = (mt_all + cand - 1) / cand;
+                if (units * mb >= 192 || cand == 1) {
+                    mt = cand;
+                    break;
+                }
+            }
+            const int mb = (mt_all + mt - 1) / mt;
+            return qs_launch_gemm_ring(MODE, OUTK, mt, 1, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out,
+                                       M, N, K, mb, stream);
+        }
     }
     // many channels: LDS-shared activation tiles + LDS-DMA rings (gemm_w4a8_lds.hip); variant 2000 forces the
     // split-K kernel, 2001 forces the LDS kernel (A/B tests)

@@ -16,6 +16,7 @@
 //   * the two K-halves are summed exactly (int32) through LDS; fused fp32 epilogue as before.
 #include "common.h"
 
+extern int g_tiled_dbg;   // gemm_w4a8_tiled.hip: qs_set_gemm_variant(3100 + bits) timing experiments
 namespace {
 
 constexpr int NS = 4;                 // ring depth (k-steps)
@@ -64,7 +65,7 @@ __device__ __forceinline__ void raw_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int MT, int MODE, int OUTK>
+template <int MT, int MODE, int OUTK, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void w4a8_gemm_pair(const int8_t* __restrict__ A, const uint8_t* __restrict__ W,
                                                          const int8_t* __restrict__ zeros,
                                                          const int8_t* __restrict__ scales8,
@@ -98,39 +99,48 @@ __global__ __launch_bounds__(256, 1) void w4a8_gemm_pair(const int8_t* __restric
     uint8_t* const w_my = w_ring + wave * NS * WBYTES;
     uint8_t* const m_my = m_ring + wave * NS * 256;
 
-    // ---- DMA sources (per lane) ----------------------------------------------------------------------------------
+    // ---- DMA sources: per-lane 32-bit byte offsets; the k-step advance goes into the scalar base ----------------------
+    // (inline asm rather than __builtin_amdgcn_global_load_lds: the compiler books the builtin as a FLAT access and
+    // from then on degrades every counted LDS wait in the loop to lgkmcnt(0))
     // activations: instruction i of this wave covers rows 8*(u*MT + i) .. +8 of the tile; lane -> (row, chunk);
     // LDS slot (row, pos) receives global chunk pos ^ (row & 7)   [swizzle on the source side]
-    const int8_t* a_src[APART];
+    u32 a_off[APART];
 #pragma unroll
     for (int i = 0; i < APART; ++i) {
         const int r = 8 * (u * MT + i) + (lane >> 3);
         int row = m0 + r;
         row = row < M ? row : M - 1;
-        a_src[i] = A + (size_t)row * K + (((lane & 7) ^ (r & 7)) * 16);
+        a_off[i] = (u32)row * (u32)K + (((lane & 7) ^ (r & 7)) * 16);
     }
     // weights: instruction e covers 1 KiB = n32 tile (T0 + (e >> 1)), k32 tiles 4*ks + 2*(e & 1) + {0, 1}
-    const uint8_t* w_src[4];
+    u32 w_off[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-        w_src[e] = W + ((size_t)(T0 + (e >> 1)) * KT + 2 * (e & 1)) * 512 + lane * 16;
-    const int meta_col = T0 * 32 + (lane & 15) * 4;     // per-group: 16 dwords of scales (lanes 0-15) | zeros (16-31)
+    for (int e = 0; e < 4; ++e) w_off[e] = ((u32)(T0 + (e >> 1)) * (u32)KT + 2 * (e & 1)) * 512u + lane * 16;
+    // per-group: 16 dwords of scales (lanes 0-15) | zeros (16-31); the zeros table is addressed relative to scales8
+    const u32 m_off = (u32)(T0 * 32 + (lane & 15) * 4);
+    const int8_t* const m_base = (lane & 16) ? zeros : scales8;
+    const u32 lds0 = (u32)(size_t)(lptr_t)smem;
+    const u32 a_lds = lds0 + kh * NS * ATILE, w_lds = lds0 + 2 * NS * ATILE + wave * NS * WBYTES,
+              m_lds = lds0 + 2 * NS * ATILE + 4 * NS * WBYTES + wave * NS * 256;
 
+    auto dma16 = [&](u32 voff, const void* sbase, u32 lds_addr) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
+                     : "memory");
+    };
     auto issue = [&](int j) {   // DMA everything of local step j into ring slot j % NS
         // workgroups walk their k-range from different starting points (integer accumulation is order-free): without
         // the rotation all ~224 workgroups request the same activation lines from L2 at the same moment
         const int ks = ks_begin + (j + rot) % nloc, slot = j % NS;
 #pragma unroll
         for (int i = 0; i < APART; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + (size_t)ks * 128),
-                                             (lptr_t)(a_my + slot * ATILE + (u * MT + i) * 1024), 16, 0, 0);
+            dma16(a_off[i], A + (size_t)ks * 128, a_lds + slot * ATILE + (u * MT + i) * 1024);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[e] + (size_t)ks * 2048),
-                                             (lptr_t)(w_my + slot * WBYTES + e * 1024), 16, 0, 0);
+        for (int e = 0; e < 4; ++e) dma16(w_off[e], W + (size_t)ks * 2048, w_lds + slot * WBYTES + e * 1024);
         if (MODE == 1) {
-            const int8_t* src = ((lane & 16) ? zeros : scales8) + (size_t)ks * N + meta_col;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(m_my + slot * 256), 4, 0, 0);
+            // scales / zeros live in different allocations: the (divergent) base stays a per-lane 64-bit address
+            const int8_t* src = m_base + (size_t)ks * N + m_off;
+            const u32 ml = m_lds + slot * 256;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(ml) : "memory");
         }
     };
 
@@ -149,11 +159,12 @@ __global__ __launch_bounds__(256, 1) void w4a8_gemm_pair(const int8_t* __restric
     for (int j = 0; j < rounds; ++j) {
         // own DMAs of step j complete?  younger steps in flight: min(NS-2, nloc-1-j)
         const int younger = nloc - 1 - j;
-        if (younger >= NS - 2) wait_vm<(NS - 2) * NDMA>();
+        if (DBG & 2) wait_vm<0>();
+        else if (younger >= NS - 2) wait_vm<(NS - 2) * NDMA>();
         else if (younger == 1) wait_vm<NDMA>();
         else wait_vm<0>();
         raw_barrier();                      // partner's half of the tile landed too; everyone is done with step j-1
-        if (j + NS - 1 < nloc) issue(j + NS - 1);
+        if (j + NS - 1 < nloc && !(DBG & 2)) issue(j + NS - 1);
         if (j < nloc) {
             const int slot = j % NS;
             const uint8_t* wb = w_my + slot * WBYTES + (tsel * 4 + g) * 512 + c * 64;
@@ -195,13 +206,33 @@ __global__ __launch_bounds__(256, 1) void w4a8_gemm_pair(const int8_t* __restric
                     }
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        acc[mt][cl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b[mt], acc[mt][cl], 0, 0, 0);
+                        if (!(DBG & 1)) acc[mt][cl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b[mt], acc[mt][cl], 0, 0, 0);
+                        else acc[mt][cl][0] += a[0] ^ b[mt][cl];
                 }
             }
         }
     }
 
     // ---- sum the two K-halves through LDS (rings are dead: every wave drained its DMAs and passed the last round) -----
+    const int ncol0 = 32 * (T0 + (g >> 1)) + 4 * (g & 1);
+    // epilogue operands are requested now so that their latency overlaps the reduction (and nothing but stores is left
+    // after it: a load between stores would wait for the stores, vmcnt being one in-order counter)
+    h4 ws4[4], wz4[4];
+    _Float16 sa_h[MT], ss_h[MT];
+    if (OUTK == 0 && kh == 0) {
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl) {
+            ws4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wscales) + ncol0 + 8 * cl);
+            if (MODE == 0) wz4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wszs) + ncol0 + 8 * cl);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            int m = m0 + 16 * mt + li;
+            m = m < M ? m : M - 1;
+            sa_h[mt] = reinterpret_cast<const _Float16*>(ascales)[m];
+            if (MODE == 0) ss_h[mt] = reinterpret_cast<const _Float16*>(assums)[m];
+        }
+    }
     __syncthreads();
     int* red = reinterpret_cast<int*>(smem);       // [2 units][MT*16][64]
     constexpr int NP = MT * 4;
@@ -216,45 +247,60 @@ __global__ __launch_bounds__(256, 1) void w4a8_gemm_pair(const int8_t* __restric
     __syncthreads();
     if (kh == 1) return;
 
-    const int ncol0 = 32 * (T0 + (g >> 1)) + 4 * (g & 1);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mt][cl][r] += red[((u * NP + mt * 4 + cl) * 4 + r) * 64 + lane];
+    if (OUTK == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + 16 * mt + li;
+            if (m >= M) continue;
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl)
+                *reinterpret_cast<v4i*>(reinterpret_cast<int*>(out) + (size_t)m * N + ncol0 + 8 * cl) = acc[mt][cl];
+        }
+        return;
+    }
+    // fp16 tile of this wave (16*MT tokens x 64 channels) through LDS: every store instruction then writes whole
+    // 128-byte rows instead of 8-byte pieces scattered over 32 lines.  The staging area sits behind the reduction slab.
+    constexpr int RS = 144;
+    uint8_t* const st = smem + 2 * NP * 4 * 64 * 4 + u * (16 * MT * RS);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        const float sa = (float)sa_h[mt];
+        const float ss = MODE == 0 ? (float)ss_h[mt] : 0.f;
 #pragma unroll
         for (int cl = 0; cl < 4; ++cl) {
-            v4i s = acc[mt][cl];
+            const v4i s = acc[mt][cl];
+            h4 o;
+            if (MODE == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[r] += red[((u * NP + mt * 4 + cl) * 4 + r) * 64 + lane];
-            const int m = m0 + 16 * mt + li;
-            const int n = ncol0 + 8 * cl;
-            if (m < M) {
-                if (OUTK == 1) {
-                    *reinterpret_cast<v4i*>(reinterpret_cast<int*>(out) + (size_t)m * N + n) = s;
-                } else {
-                    h4 o;
-                    const float sa = __half2float(ascales[m]);
-                    const h4 ws4 = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wscales) + n);
-                    if (MODE == 0) {
-                        const float ss = __half2float(assums[m]);
-                        const h4 wz4 = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wszs) + n);
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(s[r], (float)ws4[cl][r], sa, (float)wz4[cl][r], ss);
+            } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            o[r] = (_Float16)epi_per_chn(s[r], (float)ws4[r], sa, (float)wz4[r], ss);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(s[r], (float)ws4[r], sa);
-                    }
-                    *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(out) + (size_t)m * N + n) = o;
-                }
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(s[r], (float)ws4[cl][r], sa);
             }
+            *reinterpret_cast<h4*>(st + (16 * mt + li) * RS + (32 * (g >> 1) + 8 * cl + 4 * (g & 1)) * 2) = o;
         }
+    }
+    _Float16* const orow = reinterpret_cast<_Float16*>(out) + 64 * (T0 / 2) + (lane & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 2 * MT; ++i) {
+        const int r = i * 8 + (lane >> 3);
+        const int m = m0 + r;
+        const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane & 7) * 16);
+        if (m < M) *reinterpret_cast<v4u*>(orow + (size_t)m * N) = v;
     }
 }
 
-template <int MT, int MODE, int OUTK>
+template <int MT, int MODE, int OUTK, int DBG = 0>
 int launch_pair(const int8_t* A, const uint8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
                 const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K,
                 hipStream_t stream) {
-    auto kern = w4a8_gemm_pair<MT, MODE, OUTK>;
+    auto kern = w4a8_gemm_pair<MT, MODE, OUTK, DBG>;
     const size_t smem = (size_t)2 * NS * (16 * MT * 128) + 4 * NS * WBYTES + 4 * NS * 256;
     static bool configured = false;
     if (!configured) {
@@ -280,6 +326,11 @@ int qs_launch_gemm_pair(int mode, int outk, const int8_t* A, const uint8_t* W, c
                         const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
                         const void* assums, void* out, int M, int N, int K, hipStream_t stream) {
     const int mtile = M <= 16 ? 1 : M <= 32 ? 2 : M <= 48 ? 3 : 4;
+    if (mode == 0 && outk == 0 && mtile == 4 && g_tiled_dbg) {   // timing experiments only (wrong results by design)
+        if (g_tiled_dbg == 1) return launch_pair<4, 0, 0, 1>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, stream);
+        if (g_tiled_dbg == 2) return launch_pair<4, 0, 0, 2>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, stream);
+        if (g_tiled_dbg == 3) return launch_pair<4, 0, 0, 3>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, stream);
+    }
 #define QS_P(MTV, MODEV, OUTV) \
     return launch_pair<MTV, MODEV, OUTV>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, stream)
 #define QS_PM(MODEV, OUTV)        \

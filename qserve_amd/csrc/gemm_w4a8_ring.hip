@@ -1,0 +1,409 @@
+// gemm_w4a8_ring.hip -- decode-shape W4A8 GEMM (M <= 64 tokens per workgroup): weight streaming through LDS-DMA rings
+// with operand reads software-pipelined one stage ahead of the matrix cores.
+//
+// Same arithmetic, operand mapping and epilogue as the other W4A8 kernels (gemm_w4a8.hip header; reference kernels
+// kernels/csrc/qgemm/w4a8_per_chn/gemm_cuda.cu:303-594, w4a8_per_group/gemm_cuda.cu:328-628).  Measured on MI355X
+// (qs_set_gemm_variant 3100+ experiments): the earlier decode kernels spend most of their time NOT streaming - one
+// wave per SIMD, LDS-read latency exposed after every barrier, bank-conflicted weight reads.  Here:
+//   * a workgroup = 8 wave64 = KG K-groups x WN channel units (64 channels each); a group's WN waves share the
+//     activation tile of their stage; groups take the 64-wide k-stages round-robin (stage u belongs to group u % KG),
+//     so together they read every weight row contiguously;
+//   * every byte goes HBM/L2 -> LDS by LDS-DMA (asm global_load_lds, 16 B per lane) into an NS-deep ring per group;
+//     one raw s_barrier per round; counted s_waitcnt vmcnt keeps NS-2 stages per group in flight across it;
+//   * while the MFMAs of stage i run, the wave already reads stage i+1's activation operands and weight nibbles from
+//     LDS and unpacks them (registers double-buffered by unrolling the round loop by two), and issues its share of
+//     the DMA for stage i+NS-1;
+//   * LDS images are bank-conflict free (permutation applied on the DMA source side, as in gemm_w4a8_tiled.hip);
+//   * the KG partial int32 tiles are summed exactly through LDS, the fp32 epilogue is fused, its scale operands are
+//     requested before the reduction, and the fp16 tile leaves through LDS as whole 128-byte rows.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+__device__ __forceinline__ u32 vadd4(u32 a, u32 b) {
+    return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
+}
+template <int MODE>
+__device__ __forceinline__ u32 unpack_lo(u32 raw, u32 s, u32 zb) {
+    u32 u = raw & 0x0F0F0F0Fu;
+    if (MODE == 1) u = vadd4(u * s, zb);
+    return u;
+}
+template <int MODE>
+__device__ __forceinline__ u32 unpack_hi(u32 raw, u32 s, u32 zb) {
+    u32 u = (raw >> 4) & 0x0F0F0F0Fu;
+    if (MODE == 1) u = vadd4(u * s, zb);
+    return u;
+}
+__device__ __forceinline__ float epi_per_chn(int acc, float ws, float sa, float wz, float ss) {
+#pragma clang fp contract(off)
+    float t = (float)acc * ws;
+    t = t * sa;
+    const float u = wz * ss;
+    return t - u;
+}
+__device__ __forceinline__ float epi_per_group(int acc, float ws, float sa) {
+#pragma clang fp contract(off)
+    const float sc = ws * sa;
+    return (float)acc * sc;
+}
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef u32 v2u __attribute__((ext_vector_type(2)));
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void raw_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// MT m-tiles (16 tokens each) per wave = tokens per workgroup / 16; WN units per workgroup; KG = 8 / WN K-groups.
+template <int MT, int WN, int MODE, int OUTK>
+__global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restrict__ A, const uint8_t* __restrict__ W,
+                                                         const int8_t* __restrict__ zeros,
+                                                         const int8_t* __restrict__ scales8,
+                                                         const __half* __restrict__ wscales,
+                                                         const __half* __restrict__ ascales,
+                                                         const __half* __restrict__ wszs,
+                                                         const __half* __restrict__ assums, void* __restrict__ out,
+                                                         int M, int N, int K, int mblocks, int ns) {
+    constexpr int KG = 8 / WN;
+    constexpr int ASTAGE = 16 * MT * 64;              // activation bytes per stage (64 k)
+    constexpr int WSTAGE = WN * 2048;                 // packed weight bytes per stage
+    constexpr int MSTAGE = MODE == 1 ? 256 : 0;       // per-group scales | zeros of the WN units (<= 2 x 128 B)
+    constexpr int GSTAGE = ASTAGE + WSTAGE + MSTAGE;  // ring slot of one group
+    constexpr int NPIECE = MT + 2 * WN;               // 1 KiB DMA pieces per group and stage
+    static_assert(NPIECE % WN == 0, "pieces must split evenly over the waves of a group");
+    constexpr int NDMA = NPIECE / WN + (MODE == 1 ? 1 : 0);   // VMEM instructions per wave and stage
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave / WN, wn = wave % WN;
+    const int li = lane & 15, g = lane >> 4;
+    const int tsel = li >> 3, c = li & 7;
+    // workgroup -> (channel block, token block); token blocks of one channel block sit on ONE XCD (b % 8) so that the
+    // weights are fetched from HBM once and re-served by that XCD's L2
+    int nblk = blockIdx.x, mblk = 0;
+    if (mblocks > 1) {
+        const int b = blockIdx.x, slot = b >> 3;
+        mblk = slot % mblocks;
+        nblk = (slot / mblocks) * 8 + (b & 7);
+    }
+    const int unit0 = nblk * WN;                      // first 64-channel unit of the workgroup
+    const int m0 = mblk * (16 * MT);
+    const int KT = K >> 5;
+    const int nloc = (K >> 6) / KG;                   // stages per group (dispatcher: (K/64) % KG == 0)
+
+    uint8_t* const ring = smem + kg * ns * GSTAGE;    // this group's ring: slot s = [A | W | meta]
+    const u32 ring_lds = (u32)(size_t)(lptr_t)ring;
+
+    // ---- DMA sources: per-lane 32-bit offsets, stage advance in the scalar base ------------------------------------
+    // pieces of a group-stage: 0..MT-1 activations (16 rows x 64 B, chunk position p holds chunk p ^ ((row>>2)&3)),
+    // MT..MT+2WN-1 weights (tile t of unit q: [e 4][k32 ^ t 2][c 8][16 B]); this wave takes pieces wn, wn+WN, ...
+    u32 p_off[NPIECE / WN];
+    bool p_isw[NPIECE / WN];
+    u32 p_lds[NPIECE / WN];
+#pragma unroll
+    for (int j = 0; j < NPIECE / WN; ++j) {
+        const int p = wn + j * WN;
+        if (p < MT) {
+            int row = m0 + 16 * p + (lane >> 2);
+            row = row < M ? row : M - 1;
+            p_off[j] = (u32)row * (u32)K + (((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+            p_isw[j] = false;
+            p_lds[j] = p * 1024;
+        } else {
+            const int q = p - MT, unit = q >> 1, t = q & 1;
+            const int e = lane >> 4, kk = ((lane >> 3) & 1) ^ t, cc = lane & 7;
+            p_off[j] = ((u32)((unit0 + unit) * 2 + t) * (u32)KT + kk) * 512u + cc * 64 + e * 16;
+            p_isw[j] = true;
+            p_lds[j] = ASTAGE + q * 1024;
+        }
+    }
+    // per-group meta: 16*WN dwords of scales (lanes 0-31) | zeros (lanes 32-63); surplus lanes repeat valid addresses
+    const int8_t* const m_base = ((lane & 32) ? zeros : scales8) + unit0 * 64 + ((lane & 31) & (16 * WN - 1)) * 4;
+
+    auto dma16 = [&](u32 voff, const void* sbase, u32 lds_addr) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
+                     : "memory");
+    };
+    auto issue = [&](int i, int slot) {               // group-local stage i -> global stage u = i*KG + kg
+        const int u = i * KG + kg;
+        const u32 dst = ring_lds + slot * GSTAGE;
+#pragma unroll
+        for (int j = 0; j < NPIECE / WN; ++j) {
+            const void* sb = p_isw[j] ? static_cast<const void*>(W + (size_t)u * 1024)
+                                      : static_cast<const void*>(A + (size_t)u * 64);
+            dma16(p_off[j], sb, dst + p_lds[j]);
+        }
+        if (MODE == 1) {
+            const int8_t* src = m_base + (size_t)(u >> 1) * N;
+            const u32 ml = dst + ASTAGE + WSTAGE;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(ml) : "memory");
+        }
+    };
+
+    // ---- LDS operand readers -------------------------------------------------------------------------------------
+    const int a_rd = li * 64 + ((g ^ ((li >> 2) & 3)) * 16);                                       // + mt*1024
+    const int w_rd = ASTAGE + wn * 2048 + tsel * 1024 + (((g >> 1) ^ tsel)) * 128 + c * 16 + (g & 1) * 8;   // + e*256
+    const int m_rd = ASTAGE + WSTAGE + wn * 64 + (tsel * 8 + c) * 4;                               // zeros at +128
+    struct Raw {
+        v2u r[4];
+        u32 sdw, zdw;
+    };
+    struct Ops {
+        v4i a[4];
+        v4i b[MT];
+    };
+    auto read_raw = [&](int slot) -> Raw {
+        const uint8_t* s = ring + slot * GSTAGE;
+        Raw q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q.r[e] = *reinterpret_cast<const v2u*>(s + w_rd + e * 256);
+        q.sdw = 0;
+        q.zdw = 0;
+        if (MODE == 1) {
+            q.sdw = *reinterpret_cast<const u32*>(s + m_rd);
+            q.zdw = *reinterpret_cast<const u32*>(s + m_rd + 128);
+        }
+        return q;
+    };
+    auto read_b = [&](int slot, int mt) -> v4i {
+        return *reinterpret_cast<const v4i*>(ring + slot * GSTAGE + a_rd + mt * 1024);
+    };
+    auto build = [&](const Raw& q, int cl) -> v4i {
+        u32 s = 0, zb = 0;
+        if (MODE == 1) {
+            s = (q.sdw >> (8 * cl)) & 0xFFu;
+            zb = ((q.zdw >> (8 * cl)) & 0xFFu) * 0x01010101u;
+        }
+        v4i a;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const u32 raw = (cl & 1) ? q.r[e].y : q.r[e].x;
+            a[e] = (int)((cl & 2) ? unpack_hi<MODE>(raw, s, zb) : unpack_lo<MODE>(raw, s, zb));
+        }
+        return a;
+    };
+
+    v4i acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl) acc[mt][cl] = (v4i){0, 0, 0, 0};
+
+    // ---- prologue: stages 0..ns-2 in flight, operands of stage 0 in registers ---------------------------------------
+    for (int j = 0; j < ns - 1; ++j)
+        if (j < nloc) issue(j, j);
+    // wait for stage 0: younger stages outstanding = min(ns-1, nloc) - 1
+    {
+        const int young = (nloc < ns - 1 ? nloc : ns - 1) - 1;
+        if (young >= 3) wait_vm<3 * NDMA>();
+        else if (young == 2) wait_vm<2 * NDMA>();
+        else if (young == 1) wait_vm<1 * NDMA>();
+        else wait_vm<0>();
+    }
+    raw_barrier();
+    Ops o0, o1;
+    {
+        const Raw q0 = read_raw(0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) o0.b[mt] = read_b(0, mt);
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl) o0.a[cl] = build(q0, cl);
+    }
+
+    // One round: MFMAs of stage i from `cur`; meanwhile operands of stage i+1 -> `nxt`, DMA of stage i+ns-1.
+    auto round = [&](int i, int slot, const Ops& cur, Ops& nxt) {
+        const int slot_n = slot + 1 == ns ? 0 : slot + 1;
+        const int slot_d = slot == 0 ? ns - 1 : slot - 1;
+        const Raw qn = read_raw(slot_n);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) nxt.b[mt] = read_b(slot_n, mt);
+        if (i + ns - 1 < nloc) issue(i + ns - 1, slot_d);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl)
+                acc[mt][cl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a[cl], cur.b[mt], acc[mt][cl], 0, 0, 0);
+            if (mt == 0) {
+#pragma unroll
+                for (int cl = 0; cl < 4; ++cl) nxt.a[cl] = build(qn, cl);
+            }
+        }
+    };
+    // barrier(i): stage i+1 landed for every wave of the group (own pieces by the counted wait), everybody is done
+    // reading stage i-1 (its slot is refilled by the DMA issued in round i)
+    auto wait_next = [&](int i) {
+        const int rem = nloc - 1 - i;                 // stages after i
+        const int young = (rem < ns - 2 ? rem : ns - 2) - 1;   // stages allowed to stay in flight beyond i+1
+        if (young >= 3) wait_vm<3 * NDMA>();
+        else if (young == 2) wait_vm<2 * NDMA>();
+        else if (young == 1) wait_vm<1 * NDMA>();
+        else wait_vm<0>();
+    };
+    int slot = 0;
+    for (int i = 0; i < nloc; i += 2) {               // nloc is even (dispatcher)
+        wait_next(i);
+        raw_barrier();
+        round(i, slot, o0, o1);
+        slot = slot + 1 == ns ? 0 : slot + 1;
+        wait_next(i + 1);
+        raw_barrier();
+        round(i + 1, slot, o1, o0);
+        slot = slot + 1 == ns ? 0 : slot + 1;
+    }
+
+    // ---- reduce the KG partial tiles through LDS, fused epilogue -----------------------------------------------------
+    const int ncol0 = (unit0 + wn) * 64 + 32 * (g >> 1) + 4 * (g & 1);
+    h4 ws4[4], wz4[4];
+    _Float16 sa_h[MT], ss_h[MT];
+    if (OUTK == 0 && kg == 0) {                        // requested now: their latency overlaps the reduction
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl) {
+            ws4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wscales) + ncol0 + 8 * cl);
+            if (MODE == 0) wz4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wszs) + ncol0 + 8 * cl);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            int m = m0 + 16 * mt + li;
+            m = m < M ? m : M - 1;
+            sa_h[mt] = reinterpret_cast<const _Float16*>(ascales)[m];
+            if (MODE == 0) ss_h[mt] = reinterpret_cast<const _Float16*>(assums)[m];
+        }
+    }
+    __syncthreads();                                   // rings are dead (every wave drained its DMA queue)
+    constexpr int NP = MT * 4;
+    int* const red = reinterpret_cast<int*>(smem);     // [KG-1][WN][NP*4][64]
+    if (kg > 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    red[((((kg - 1) * WN + wn) * NP + mt * 4 + cl) * 4 + r) * 64 + lane] = acc[mt][cl][r];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int k2 = 0; k2 < KG - 1; ++k2)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[mt][cl][r] += red[(((k2 * WN + wn) * NP + mt * 4 + cl) * 4 + r) * 64 + lane];
+    if (OUTK == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + 16 * mt + li;
+            if (m >= M) continue;
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl)
+                *reinterpret_cast<v4i*>(reinterpret_cast<int*>(out) + (size_t)m * N + ncol0 + 8 * cl) = acc[mt][cl];
+        }
+        return;
+    }
+    constexpr int RS = 144;                            // staged fp16 row: 128 B + 16 (keeps 16-byte alignment)
+    uint8_t* const st = smem + (KG - 1) * WN * NP * 4 * 64 * 4 + wn * (16 * MT * RS);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const float sa = (float)sa_h[mt];
+        const float ss = MODE == 0 ? (float)ss_h[mt] : 0.f;
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl) {
+            const v4i s = acc[mt][cl];
+            h4 o;
+            if (MODE == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(s[r], (float)ws4[cl][r], sa, (float)wz4[cl][r], ss);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(s[r], (float)ws4[cl][r], sa);
+            }
+            *reinterpret_cast<h4*>(st + (16 * mt + li) * RS + (32 * (g >> 1) + 8 * cl + 4 * (g & 1)) * 2) = o;
+        }
+    }
+    _Float16* const orow = reinterpret_cast<_Float16*>(out) + (unit0 + wn) * 64 + (lane & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 2 * MT; ++i) {
+        const int r = i * 8 + (lane >> 3);
+        const int m = m0 + r;
+        const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane & 7) * 16);
+        if (m < M) *reinterpret_cast<v4u*>(orow + (size_t)m * N) = v;
+    }
+}
+
+template <int MT, int WN, int MODE, int OUTK>
+int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
+                const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K,
+                int mblocks, hipStream_t stream) {
+    auto kern = w4a8_gemm_ring<MT, WN, MODE, OUTK>;
+    constexpr int KG = 8 / WN;
+    constexpr int GSTAGE = 16 * MT * 64 + WN * 2048 + (MODE == 1 ? 256 : 0);
+    // ring depth: as deep as 144 KiB of LDS allows (<= 6), never deeper than a group's stage count + 1
+    int ns = (144 * 1024) / (KG * GSTAGE);
+    if (ns > 6) ns = 6;
+    const int nloc = (K / 64) / KG;
+    if (ns > nloc + 1) ns = nloc + 1;
+    if (ns < 3) ns = 3;                                // the slot read ahead and the slot refilled must differ
+    size_t smem = (size_t)KG * ns * GSTAGE;
+    const size_t tail = (size_t)(KG - 1) * WN * MT * 4 * 4 * 64 * 4 + (size_t)WN * 16 * MT * 144;   // reduction + staging
+    if (smem < tail) smem = tail;
+    static size_t configured = 0;
+    if (configured < smem) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        if (e != hipSuccess) {
+            qs_set_error("w4a8 gemm (ring): cannot reserve LDS: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        configured = 160 * 1024;
+    }
+    dim3 grid((N / (64 * WN)) * mblocks);
+    hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, A, W, zeros, scales8,
+                       reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
+                       reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K,
+                       mblocks, ns);
+    return qs_launch_status("w4a8 gemm (ring)");
+}
+
+}  // namespace
+
+// Entry used by the dispatcher in gemm_w4a8.hip.  mt = m-tiles per workgroup (1, 2, 4), wn = units per workgroup
+// (1, 2); preconditions (checked there): N % (64*wn) == 0, (K/64) % (2 * 8/wn) == 0, mblocks == 1 or (N/(64 wn)) % 8 == 0,
+// M*K and N*K/2 below 4 GiB.
+int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, const uint8_t* W, const int8_t* zeros,
+                        const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
+                        const void* assums, void* out, int M, int N, int K, int mblocks, hipStream_t stream) {
+#define QS_R(MTV, WNV, MODEV, OUTV)                                                                              \
+    return launch_ring<MTV, WNV, MODEV, OUTV>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, \
+                                              mblocks, stream)
+#define QS_RM(MODEV, OUTV)                              \
+    do {                                                \
+        if (wn == 2) {                                  \
+            if (mt == 4) QS_R(4, 2, MODEV, OUTV);       \
+            if (mt == 2) QS_R(2, 2, MODEV, OUTV);       \
+        } else {                                        \
+            if (mt == 4) QS_R(4, 1, MODEV, OUTV);       \
+            if (mt == 2) QS_R(2, 1, MODEV, OUTV);       \
+            if (mt == 1) QS_R(1, 1, MODEV, OUTV);       \
+        }                                               \
+    } while (0)
+    if (mode == 0 && outk == 0) QS_RM(0, 0);
+    if (mode == 0 && outk == 1) QS_RM(0, 1);
+    if (mode == 1 && outk == 0) QS_RM(1, 0);
+    if (mode == 1 && outk == 1) QS_RM(1, 1);
+#undef QS_RM
+#undef QS_R
+    qs_set_error("w4a8 gemm (ring): unsupported geometry mt=%d wn=%d", mt, wn);
+    return QS_ENOSUP;
+}

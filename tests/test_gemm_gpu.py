@@ -105,6 +105,46 @@ def test_tiled_kernel_equals_decode_kernel(gpu):
     assert np.array_equal(outs[0].view(np.uint16), outs[2].view(np.uint16))
 
 
+# decode ring kernel: (variant = 4100 + 10*m_tiles + units, M, N, K); K/64 divisible by 16/units, ragged M, M split
+RING = [(4111, 16, 64, 1024), (4111, 40, 512, 2048), (4121, 23, 64, 1024), (4121, 64, 512, 1024),
+        (4141, 50, 64, 2048), (4141, 100, 512, 1024), (4122, 32, 128, 512), (4122, 20, 256, 1024),
+        (4142, 64, 128, 512), (4142, 37, 384, 1536)]
+
+
+@pytest.mark.parametrize("variant,M,N,K", RING)
+@pytest.mark.parametrize("mode", ["per_channel", "per_group", "per_group_any_bytes"])
+def test_ring_kernel_vs_oracle(gpu, variant, M, N, K, mode):
+    from qserve_amd import _lib
+    _lib.lib.qs_set_gemm_variant(variant)
+    try:
+        if mode == "per_channel":
+            import qserve_backend.qgemm_w4a8_per_chn as op
+            pr = synth.per_channel_problem(M, N, K, seed=M + N + K)
+            acc_ref, out_ref = w4a8.gemm_per_chn(pr["A"], pr["qweight"], pr["wscales"], pr["ascales"], pr["w_szs"],
+                                                 pr["a_ssums"])
+            A, W = dev(pr["A"]), dev(pr["qweight"])
+            acc = torch.full((M + 2, N), -7, dtype=torch.int32, device=gpu)
+            op.gemm_forward_acc(A, W, acc[:M])
+            out = torch.full((M + 2, N), float("nan"), dtype=torch.float16, device=gpu)
+            op.gemm_forward_cuda(A, W, dev(pr["wscales"]), dev(pr["ascales"]), dev(pr["w_szs"]), dev(pr["a_ssums"]),
+                                 out[:M])
+        else:
+            import qserve_backend.qgemm_w4a8_per_group as op
+            pr = synth.per_group_problem(M, N, K, seed=M * 3 + N + K, valid=mode == "per_group")
+            acc_ref, out_ref = w4a8.gemm_per_group(pr["A"], pr["qweight"], pr["s2_zeros"], pr["s2_scales"],
+                                                   pr["wscales"], pr["ascales"])
+            A, W, Z, S = dev(pr["A"]), dev(pr["qweight"]), dev(pr["s2_zeros"]), dev(pr["s2_scales"])
+            acc = torch.full((M + 2, N), -7, dtype=torch.int32, device=gpu)
+            op.gemm_forward_acc(A, W, Z, S, acc[:M])
+            out = torch.full((M + 2, N), float("nan"), dtype=torch.float16, device=gpu)
+            op.gemm_forward_cuda(A, W, Z, S, dev(pr["wscales"]), dev(pr["ascales"]), out[:M])
+    finally:
+        _lib.lib.qs_set_gemm_variant(-1)
+    assert np.array_equal(acc[:M].cpu().numpy(), acc_ref), "int32 accumulators"
+    assert torch.all(acc[M:] == -7) and torch.all(torch.isnan(out[M:])), "rows beyond M were written"
+    assert ulp_diff_f16(out[:M].cpu().numpy(), out_ref).max() == 0
+
+
 def test_rows_beyond_M_untouched_and_empty_batch(gpu):
     import qserve_backend.qgemm_w4a8_per_chn as op
     pr = synth.per_channel_problem(5, 64, 128, seed=9)
