@@ -436,13 +436,17 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         return qs_launch_gemm_ring(MODE, OUTK, mt, wn, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N,
                                    K, mb, stream);
     }
-    if (M <= 64 && M > 16 && g_variant != 4000 && (g_variant < 1000 || g_variant >= 4000) &&
+    // measured crossovers (scripts/bench_gemm.py, Llama-3-8B shapes, M = 16 / 32 / 64 / 128)
+    if (M <= 128 && g_variant != 4000 && (g_variant < 1000 || g_variant >= 4000) &&
         (size_t)M * K < (1ull << 32) && (size_t)N * K / 2 < (1ull << 32)) {
         const int mt_all = (M + 15) / 16;
-        if (units >= 256 && N % 128 == 0 && (K / 64) % 8 == 0)          // many channels: 2 units x 4 K-groups
-            return qs_launch_gemm_ring(MODE, OUTK, mt_all <= 2 ? 2 : 4, 2, A, Wu, zeros, scales8, wscales, ascales,
-                                       wszs, assums, out, M, N, K, 1, stream);
-        if (units < 256 && units % 8 == 0 && (K / 64) % 16 == 0) {      // few channels: 1 unit x 8 K-groups, M split
+        if (units >= 256 && M > 16 && N % 128 == 0 && (K / 64) % 8 == 0) {   // many channels: 2 units x 4 K-groups
+            const int mt = mt_all <= 2 ? 2 : 4, mb = (mt_all + mt - 1) / mt;
+            if (mb == 1 || (N / 128) % 8 == 0)
+                return qs_launch_gemm_ring(MODE, OUTK, mt, 2, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out,
+                                           M, N, K, mb, stream);
+        }
+        if (units < 256 && units % 8 == 0 && (K / 64) % 16 == 0) {           // few channels: 1 unit x 8 K-groups, M split
             int mt = 1;
             for (int cand = 4; cand >= 1; cand >>= 1) {
                 if (cand > mt_all && cand > 1) continue;
@@ -453,8 +457,10 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
                 }
             }
             const int mb = (mt_all + mt - 1) / mt;
-            return qs_launch_gemm_ring(MODE, OUTK, mt, 1, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out,
-                                       M, N, K, mb, stream);
+            // beyond 64 tokens only while 64-token tiles fill the chip (smaller tiles re-read the weights too often)
+            if (M <= 64 || mt == 4)
+                return qs_launch_gemm_ring(MODE, OUTK, mt, 1, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out,
+                                           M, N, K, mb, stream);
         }
     }
     // many channels: LDS-shared activation tiles + LDS-DMA rings (gemm_w4a8_lds.hip); variant 2000 forces the
