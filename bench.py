@@ -235,12 +235,14 @@ def main():
         # passes (scripts/gpu_pmc.sh), so the committed measurement of the same kernel + shape is quoted here
         traffic, traffic_src = None, None
         try:
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                              "r01_pmc_traffic.json")))
-            ent = pmc["kernels"].get(dom["kernel"])
+            import glob
+            pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            newest = sorted(glob.glob(os.path.join(pdir, "r*_pmc_traffic.json")))[-1]   # named per round
+            ent = json.load(open(newest))["kernels"].get(dom["kernel"])
             if ent:
-                traffic, traffic_src = ent["hbm_bytes"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, offline pass)"
-        except (OSError, ValueError, KeyError):
+                traffic = ent["hbm_bytes"]
+                traffic_src = f"profiles/{os.path.basename(newest)} ({ent['kernel_symbol']}, rocprofv3 --pmc, offline pass)"
+        except (OSError, ValueError, KeyError, IndexError):
             pass
         roof = dict(bound="hbm", kernel=dom["kernel"], achieved=round(dom["gbs"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(dom["gbs"] / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
