@@ -503,8 +503,14 @@ int launch_decode(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Fl
 // KV4 fast path on the matrix cores (attention_mfma.hip)
 int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
                           const int64_t* kvp, const int* len, _Float16* out, int H, int Hkv, int64_t qs, int64_t kvs,
-                          int mb, int timestep, float base, int max_pos);
-static int g_attn_variant = 0;   // 0 = MFMA kernel for KV4 (default), 1 = VALU kernel everywhere (A/B tests)
+                          int mb, int timestep, float base, int max_pos, int force_split);
+// KV8 twin (attention_mfma8.hip)
+int qs_launch_decode_mfma8(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
+                           const int64_t* kvp, const int* len, _Float16* out, int H, int Hkv, int64_t qs, int64_t kvs,
+                           int mb, int timestep, float base, int max_pos, int force_split);
+// 0 = MFMA kernel for KV4 with the split-KV heuristic (default), 1 = VALU kernel everywhere, 100 + n = MFMA kernel with
+// exactly n KV splits (A/B tests)
+static int g_attn_variant = 0;
 extern "C" void qs_set_attention_variant(int variant) { g_attn_variant = variant; }
 
 extern "C" int qs_single_query_attention(const void* q, const void* k, const void* v, const int64_t* kv_pointers,
@@ -527,17 +533,22 @@ extern "C" int qs_single_query_attention(const void* q, const void* k, const voi
     QS_REQUIRE(size_per_token == num_kv_heads * dhb, "single_query_attention: size_per_token=%d, expected %d",
                size_per_token, num_kv_heads * dhb);
     QS_REQUIRE(max_blocks > 0 && memory_max_seqlen > 0, "single_query_attention: bad max_blocks / memory_max_seqlen");
-    (void)timestep;
     if (batch == 0) return QS_OK;
     dim3 grid(num_kv_heads, batch);
     const int G = num_heads / num_kv_heads;
     hipStream_t st = (hipStream_t)stream;
     // the matrix-core kernel caches a sequence's page addresses in LDS (192 pages = 12288 tokens per sequence); longer
     // page tables take the VALU kernel
-    if (int4_kv_cache && g_attn_variant == 0 && max_blocks <= 192)
+    if (int4_kv_cache && g_attn_variant != 1 && max_blocks <= 192)
         return qs_launch_decode_mfma(G, grid, st, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
                                      kv_pointers, length_per_sample, (_Float16*)out, num_heads, num_kv_heads,
-                                     q_stride0, kv_stride0, max_blocks, timestep, rotary_base, memory_max_seqlen);
+                                     q_stride0, kv_stride0, max_blocks, timestep, rotary_base, memory_max_seqlen,
+                                     g_attn_variant >= 100 ? g_attn_variant - 100 : 0);
+    if (!int4_kv_cache && g_attn_variant != 1 && max_blocks <= 192)
+        return qs_launch_decode_mfma8(G, grid, st, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
+                                      kv_pointers, length_per_sample, (_Float16*)out, num_heads, num_kv_heads,
+                                      q_stride0, kv_stride0, max_blocks, timestep, rotary_base, memory_max_seqlen,
+                                      g_attn_variant >= 100 ? g_attn_variant - 100 : 0);
     if (int4_kv_cache)
         return launch_decode<true>(G, grid, st, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
                                    kv_pointers, length_per_sample, (_Float16*)out, num_heads, num_kv_heads, q_stride0,

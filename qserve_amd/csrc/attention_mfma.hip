@@ -94,7 +94,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
     const int64_t* __restrict__ kv_pointers, const int* __restrict__ lengths, _Float16* __restrict__ out,
     int num_heads, int num_kv_heads, int64_t q_stride0, int64_t kv_stride0, int max_blocks, int timestep,
-    float rope_base, const float2* __restrict__ rope_tab, int rope_tab_len) {
+    float rope_base, const float2* __restrict__ rope_tab, int rope_tab_len, int nsplit, float* __restrict__ ws) {
     __shared__ __attribute__((aligned(16))) uint8_t s_kv[2 * NW * PAGE_TOK * DHB];   // [K | V][wave][4 KiB]
     __shared__ __attribute__((aligned(16))) _Float16 s_meta[NW][4][PAGE_TOK];   // k scale, k zero, v scale, v zero
     __shared__ __attribute__((aligned(16))) _Float16 s_q[G][DH];                // rotated q of the G heads
@@ -118,6 +118,11 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
 
     // ---- page fetch by LDS-DMA ------------------------------------------------------------------------------------
     const int npages = (tl + PAGE_TOK - 1) >> 6;
+    // split-KV (flash-decoding across workgroups, gridDim.z = nsplit > 1 when batch x kv-heads cannot fill the chip):
+    // this workgroup handles pages [p_begin, p_end); split 0 also owns the new token (cache write + its own term)
+    const int z = blockIdx.z;
+    const int pps = (npages + nsplit - 1) / nsplit;
+    const int p_begin = z * pps, p_end = min(npages, p_begin + pps);
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     // Page addresses inside the loop come from the LDS copy (s_ptab, filled in phase A): a global load there would sit
@@ -145,9 +150,9 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
                                           ((lane >> 5) * num_kv_heads + hkv) * PAGE_TOK * 2 + (lane & 31) * 4);
         __builtin_amdgcn_global_load_lds((gptr_t)mb, (lptr_t)(&s_meta[wave][2][0]), 4, 0, 0);
     };
-    if (wave < npages) {
-        dma_k(ktab[wave]);
-        dma_v(vtab[wave]);
+    if (p_begin + wave < p_end) {
+        dma_k(ktab[p_begin + wave]);
+        dma_v(vtab[p_begin + wave]);
     }
     for (int i = tid; i < 2 * MAXP; i += NW * 64) {
         const int pi = i >> 1;
@@ -182,12 +187,12 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     __syncthreads();
     {
         const int blk = tl >> 6, slot = tl & 63;
-        if (wave == 0) {
+        if (wave == 0 && z == 0) {
             uint8_t* pg = reinterpret_cast<uint8_t*>(ktab[blk]);
             __half* sc = reinterpret_cast<__half*>(pg + (size_t)num_kv_heads * PAGE_TOK * DHB);
             wave_quant_store4(s_knew[2 * lane], s_knew[2 * lane + 1], pg + ((size_t)hkv * PAGE_TOK + slot) * DHB,
                               sc + hkv * PAGE_TOK + slot, sc + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
-        } else if (wave == 1) {
+        } else if (wave == 1 && z == 0) {
             uint8_t* pg = reinterpret_cast<uint8_t*>(vtab[blk]);
             __half* sc = reinterpret_cast<__half*>(pg + (size_t)num_kv_heads * PAGE_TOK * DHB);
             wave_quant_store4(vb[2 * lane], vb[2 * lane + 1], pg + ((size_t)hkv * PAGE_TOK + slot) * DHB,
@@ -242,10 +247,10 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     for (int e = 0; e < 8; ++e) acc[e] = (v4f){0.f, 0.f, 0.f, 0.f};
     float m_run = -3.0e38f, l_part = 0.f, corr = 0.f;
 
-    for (int p = wave; p < npages; p += NW) {
+    for (int p = p_begin + wave; p < p_end; p += NW) {
         // K(p) landed?  Outstanding younger VMEM ops at this point: the 5 of V(p).
         asm volatile("s_waitcnt vmcnt(5) ; QS_LOOP_BEGIN" ::: "memory");
-        const bool more = p + NW < npages;
+        const bool more = p + NW < p_end;
         const int valid = min(PAGE_TOK, tl - p * PAGE_TOK);
         const bool full = valid == PAGE_TOK;   // wave-uniform: only the last page needs masking
 
@@ -392,19 +397,46 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     __syncthreads();
     for (int o = tid; o < G * DH; o += NW * 64) {
         const int h = o / DH, d = o % DH;
-        float M = s_cur[h];
+        float M = z == 0 ? s_cur[h] : -3.0e38f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) M = fmaxf(M, s_m[w][h]);
-        const float pc = __expf(s_cur[h] - M);
-        float num = pc * (float)vb[d], den = pc + 1.e-6f;          // Template.hpp:1819 (sum + 1e-6)
+        const float pc = z == 0 ? __expf(s_cur[h] - M) : 0.f;      // the new token's own term (split 0 only)
+        float num = pc * (float)vb[d], den = pc;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             const float f = __expf(s_m[w][h] - M);
             num += f * s_o[w][h][d];
             den += f * s_l[w][h];
         }
-        out[((size_t)b * num_heads + (size_t)hkv * G + h) * DH + d] = (_Float16)(num / den);
+        if (nsplit == 1) {
+            out[((size_t)b * num_heads + (size_t)hkv * G + h) * DH + d] = (_Float16)(num / (den + 1.e-6f));   // Template.hpp:1819
+        } else {                                                    // un-normalised partial: [O(128) | M | L]
+            float* pw = ws + ((((size_t)b * num_kv_heads + hkv) * nsplit + z) * G + h) * (DH + 2);
+            pw[d] = num;
+            if (d == 0) {
+                pw[DH] = M;
+                pw[DH + 1] = den;
+            }
+        }
     }
+}
+
+// second phase of split-KV: one workgroup per (sequence, query head) combines the nsplit partials
+__global__ __launch_bounds__(DH) void decode_attention_merge_kernel(const float* __restrict__ ws, _Float16* __restrict__ out,
+                                                                    int num_heads, int num_kv_heads, int G, int nsplit) {
+    const int b = blockIdx.y, hq = blockIdx.x, d = threadIdx.x;
+    const int hkv = hq / G, h = hq % G;
+    const float* base = ws + (((size_t)b * num_kv_heads + hkv) * nsplit * G + h) * (DH + 2);
+    const size_t zs = (size_t)G * (DH + 2);
+    float M = -3.0e38f;
+    for (int zz = 0; zz < nsplit; ++zz) M = fmaxf(M, base[zz * zs + DH]);
+    float num = 0.f, den = 0.f;
+    for (int zz = 0; zz < nsplit; ++zz) {
+        const float f = __expf(base[zz * zs + DH] - M);
+        num += f * base[zz * zs + d];
+        den += f * base[zz * zs + DH + 1];
+    }
+    out[((size_t)b * num_heads + hq) * DH + d] = (_Float16)(num / (den + 1.e-6f));
 }
 
 // cos/sin table [max_pos][64] (float2), every entry double-evaluated and rounded once to float32: bit-identical to the
@@ -461,15 +493,72 @@ const float2* qs_rope_table(float base, int max_pos, hipStream_t st, int* len_ou
     return r.tab;
 }
 
-// called from attention.hip's dispatcher for KV4
+// Library-managed split-KV workspace (per device, grow-only).  nullptr while a capture is running and the buffer is
+// too small (callers then run un-split).
+namespace {
+struct SplitWs {
+    float* p = nullptr;
+    size_t bytes = 0;
+};
+SplitWs g_ws[16];
+}  // namespace
+// second phase of split-KV, shared with the KV8 kernel (attention_mfma8.hip)
+void qs_launch_attention_merge(const float* ws, _Float16* out, int H, int Hkv, int G, int nsplit, int batch,
+                               hipStream_t st) {
+    hipLaunchKernelGGL(decode_attention_merge_kernel, dim3(H, batch), dim3(DH), 0, st, ws, out, H, Hkv, G, nsplit);
+}
+float* qs_split_workspace(size_t bytes, hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SplitWs& w = g_ws[dev];
+    if (w.p && w.bytes >= bytes) return w.p;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (w.p) {
+        (void)hipStreamSynchronize(st);       // a previous launch on this stream may still read the old buffer
+        (void)hipFree(w.p);
+        w.p = nullptr;
+        w.bytes = 0;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    w.p = reinterpret_cast<float*>(p);
+    w.bytes = bytes;
+    return w.p;
+}
+
+// called from attention.hip's dispatcher for KV4.  force_split: 0 = heuristic, n > 0 = exactly n splits (tests)
 int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
                           const int64_t* kvp, const int* len, _Float16* out, int H, int Hkv, int64_t qs, int64_t kvs,
-                          int mb, int timestep, float base, int max_pos) {
+                          int mb, int timestep, float base, int max_pos, int force_split) {
     int tab_len = 0;
     const float2* tab = qs_rope_table(base, max_pos, st, &tab_len);
+    // split-KV when (sequences x kv heads) cannot fill 256 CUs twice: aim at >= 512 workgroups, keep >= NW pages each
+    const int blocks = (int)(grid.x * grid.y);
+    const int pages_max = (timestep + PAGE_TOK - 1) / PAGE_TOK;
+    int nsplit = 1;
+    if (force_split > 0) nsplit = force_split;
+    else if (blocks < 384) {
+        nsplit = (512 + blocks - 1) / blocks;
+        const int cap = pages_max / (2 * NW) > 1 ? pages_max / (2 * NW) : 1;   // >= 2 pages per wave and split
+        if (nsplit > cap) nsplit = cap;
+        if (nsplit > 32) nsplit = 32;
+    }
+    float* ws = nullptr;
+    if (nsplit > 1) {
+        ws = qs_split_workspace((size_t)blocks * nsplit * G * (DH + 2) * sizeof(float), st);
+        if (!ws) nsplit = 1;
+    }
+    grid.z = nsplit;
 #define QS_LAUNCH_G(GG)                                                                                             \
     hipLaunchKernelGGL((decode_attention_mfma_kernel<GG>), grid, dim3(NW * 64), 0, st, q, k, v, kvp, len, out, H, Hkv, \
-                       qs, kvs, mb, timestep, base, tab, tab_len)
+                       qs, kvs, mb, timestep, base, tab, tab_len, nsplit, ws)
     switch (G) {
         case 1: QS_LAUNCH_G(1); break;
         case 2: QS_LAUNCH_G(2); break;
@@ -480,5 +569,7 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
             return QS_ENOSUP;
     }
 #undef QS_LAUNCH_G
+    if (nsplit > 1)
+        hipLaunchKernelGGL(decode_attention_merge_kernel, dim3(H, grid.y), dim3(DH), 0, st, ws, out, H, Hkv, G, nsplit);
     return qs_launch_status("single_query_attention");
 }

@@ -1,15 +1,41 @@
 #!/usr/bin/env python3
-"""A/B micro-benchmark of decode attention (graph-timed): variant 0 = MFMA kernel, 1 = VALU kernel."""
+"""A/B micro-benchmark of decode attention (graph-timed).  env: B, LS (comma list), VARS (attention variants),
+SAMEPAGE; --kv8 for the INT8 cache."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 import qserve_backend.fused_attention as fa
 from qserve_amd._lib import lib
-from bench_gemm import timeit
+
+
+def timeit(fn, reps=32, replays=6):
+    """GPU-side time per launch: the launches are captured in a hipGraph (no host overhead between them)."""
+    for i in range(2):
+        fn(i)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph, stream=s):
+            for i in range(reps):
+                fn(i)
+    torch.cuda.synchronize()
+    gph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(replays):
+        gph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (reps * replays)
+
 
 dev = torch.device("cuda:0")
-B, H, Hkv = 64, 32, 8
+B, H, Hkv = int(os.environ.get("B", "64")), 32, 8
+VARS = [int(x) for x in os.environ.get("VARS", "0,1").split(",")]   # 0 auto, 1 VALU, 100+n = n KV splits
 int4 = "--kv8" not in sys.argv
 NL = 8
 LS = [int(x) for x in os.environ.get("LS", "1024,1280,1535,4096").split(",")]
@@ -37,7 +63,7 @@ for L in LS:
     lens = torch.full((B,), L, dtype=torch.int32, device=dev)
     bytes_ = B * (L - 1) * Hkv * (2 * dhb + 8)
     row = []
-    for var in ((0, 1) if int4 else (1,)):
+    for var in VARS:
         lib.qs_set_attention_variant(var)
         us = timeit(lambda i: fa.single_query_attention(q, k, v, tables[i % NL], lens, None, 8192, 64, Hkv * dhb, L, 128, 5e5, True, int4, True), reps=16)
         row.append(f"variant {var}: {us:7.2f} us {bytes_ / us / 1e3:7.0f} GB/s")

@@ -176,3 +176,29 @@ def test_rejects_what_reference_rejects(gpu):
     with pytest.raises(RuntimeError):   # k.stride(1) must equal head_dim (:179)
         fa.single_query_attention(q, k.transpose(0, 1).contiguous().transpose(0, 1), k, ptrs, None, None, 8192, 64,
                                   512, 1, 128, ROPE, True, True, True)
+
+
+@pytest.mark.parametrize("int4", [True, False])
+@pytest.mark.parametrize("nsplit", [1, 2, 3, 7])
+def test_decode_split_kv_forced(gpu, nsplit, int4):
+    """Flash-decoding across workgroups (KV4 and KV8 matrix-core kernels): forced split counts incl. splits that get
+    no page and 1-token sequences; same tolerance as the un-split kernel, cache bytes identical."""
+    from qserve_amd import _lib
+    _lib.lib.qs_set_attention_variant(100 + nsplit)
+    try:
+        run_case(gpu, 5, 8, 2, [1, 63, 130, 700, 1536], int4, seed=40 + nsplit)
+        run_case(gpu, 2, 32, 8, [2048, 1999], int4, seed=50 + nsplit)
+    finally:
+        _lib.lib.qs_set_attention_variant(0)
+
+
+@pytest.mark.parametrize("int4", [True, False])
+def test_decode_valu_kernel_still_correct(gpu, int4):
+    """The VALU kernels stay in the library (page tables longer than 192 entries, A/B tests): keep them covered."""
+    from qserve_amd import _lib
+    _lib.lib.qs_set_attention_variant(1)
+    try:
+        run_case(gpu, 4, 8, 2, [1, 65, 300, 1100], int4, seed=60)
+    finally:
+        _lib.lib.qs_set_attention_variant(0)
+
