@@ -145,6 +145,21 @@ int qs_add_residual_rms_norm_general(int8_t* out, void* hidden_io, const void* d
 int qs_silu_and_mul_quant(int8_t* out, const void* input, void* input_sum, void* scale, int num_tokens, int d,
                           qs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Prefill attention: provider for the call the reference makes into the un-vendored flash-attn wheel,
+ *   flash_attn.flash_attn_interface.flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q,
+ *   max_seqlen_k, dropout_p=0, softmax_scale=None, causal=True)      (llama_w4a8_unpad.py:30,232-242).
+ *   q   half [total_q, H, 128]   token stride q_stride0 elements (views into the packed qkv buffer are fine)
+ *   k,v half [total_k, Hkv, 128] token strides k_stride0 / v_stride0
+ *   out half [total_q, H, 128]   token stride o_stride0
+ *   cu_seqlens_q / cu_seqlens_k int32 [batch+1] (device).  causal: bottom-right aligned when lengths differ (v2.1+).
+ * head_dim must be 128; dropout, ALiBi, sliding windows and returning probabilities are not provided.
+ * ---------------------------------------------------------------------------------------------------------- */
+int qs_flash_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, const int32_t* cu_seqlens_q,
+                             const int32_t* cu_seqlens_k, int batch, int num_heads, int num_kv_heads, int head_dim,
+                             int64_t q_stride0, int64_t k_stride0, int64_t v_stride0, int64_t o_stride0,
+                             int max_seqlen_q, int max_seqlen_k, float softmax_scale, int causal, qs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

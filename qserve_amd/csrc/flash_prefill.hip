@@ -1,0 +1,253 @@
+// flash_prefill.hip -- prefill attention (causal / full, variable-length, GQA, fp16, head_dim 128) for MI355X (gfx950).
+//
+// Provider for the call the reference makes into the un-vendored flash-attn package
+//   flash_attn.flash_attn_interface.flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q,
+//   max_seqlen_k, causal=True)            (qserve/modeling/models/llama_w4a8_unpad.py:30,232-242)
+// flash-attn v2 semantics: softmax(scale * Q K^T) V per sequence and head, fp32 softmax, causal mask aligned to the
+// bottom-right corner when the query and key lengths differ.  The algorithm is the published FlashAttention-2 forward
+// (online softmax over key tiles, no S x S matrix); the mapping below is written for CDNA4:
+//   * workgroup = 4 wave64 = 128 query rows of one (sequence, head); wave w owns 32 rows and keeps their Q fragments
+//     (8 x 16 dims) in registers for the whole key loop;
+//   * key/value tiles of 64 keys are staged through LDS once per workgroup (shared by the 4 waves; the G query heads
+//     of a GQA group are separate workgroups that re-read the tiles from L2): K row-major with a 16-byte XOR swizzle,
+//     V TRANSPOSED to [dim][key] with padded rows, both double-buffered, one barrier per tile;
+//   * "swapped" products on v_mfma_f32_32x32x16_f16:  S^T = K Q^T  (A = K rows, B = Q rows, both plain 16-byte reads)
+//     leaves every lane holding 16 of the 32 scores of ITS OWN query row, so the softmax is register-only (one
+//     cross-lane max with lane ^ 32) and the probabilities already sit in B-operand order for
+//     O^T = V^T P^T  (A = V^T rows from LDS, 2 x 8 bytes; k-slot <-> key mapping chosen to match the S^T layout);
+//   * exp2 with the scale folded into one fp32 multiply; rescaling of O only through the running max.
+#include "common.h"
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef u32 v2u __attribute__((ext_vector_type(2)));
+
+constexpr int DH = 128;
+constexpr int BM = 128;           // query rows per workgroup
+constexpr int BN = 64;            // keys per tile
+constexpr int VT_STRIDE = 136;    // bytes per V^T row: 64 keys * 2 B + 8 (conflict-free 8-byte reads over 32 rows)
+constexpr int KS_BYTES = BN * DH * 2;             // 16 KiB
+constexpr int VT_BYTES = DH * VT_STRIDE;          // 17 KiB
+
+__device__ __forceinline__ u32 pack_h2(float a, float b) {
+    const h2 v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(u32, v);
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
+                                                          const _Float16* __restrict__ v, _Float16* __restrict__ out,
+                                                          const int* __restrict__ cu_q, const int* __restrict__ cu_k,
+                                                          int num_heads, int num_kv_heads, int64_t q_stride0,
+                                                          int64_t k_stride0, int64_t v_stride0, int64_t o_stride0,
+                                                          float scale_log2) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t (*s_k)[KS_BYTES] = reinterpret_cast<uint8_t (*)[KS_BYTES]>(smem);                    // [2][16 KiB]
+    uint8_t (*s_vt)[VT_BYTES] = reinterpret_cast<uint8_t (*)[VT_BYTES]>(smem + 2 * KS_BYTES);    // [2][17 KiB]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
+    const int q_start = cu_q[b], len_q = cu_q[b + 1] - q_start;
+    const int k_start = cu_k[b], len_k = cu_k[b + 1] - k_start;
+    if (qt * BM >= len_q) return;
+    const int hkv = h / (num_heads / num_kv_heads);
+    const int shift = len_k - len_q;                   // causal diagonal: key <= row + shift
+    const int li = lane & 31, hi = lane >> 5;
+    const int row = qt * BM + wave * 32 + li;          // this lane's query row (both lane halves share it)
+    const int row_ld = row < len_q ? row : len_q - 1;
+
+    // ---- Q fragments: B operand of S^T = K Q^T, lane (row, hi) holds dims 16s + 8hi .. +8 ----------------------------
+    h8 qf[8];
+    {
+        const _Float16* qp = q + (size_t)(q_start + row_ld) * q_stride0 + (size_t)h * DH + 8 * hi;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const h8*>(qp + 16 * s);
+    }
+
+    // ---- key range ----------------------------------------------------------------------------------------------------
+    int kv_end = len_k;
+    if (CAUSAL) {
+        const int last = qt * BM + BM - 1 + shift;     // largest key any row of this workgroup may see
+        kv_end = last + 1 < len_k ? last + 1 : len_k;
+    }
+    const int ntiles = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
+
+    // ---- tile staging: thread t moves pieces t, t+256, t+512, t+768 (piece = key * 16 + 16-byte chunk) ----------------
+    const _Float16* kg = k + (size_t)k_start * k_stride0 + (size_t)hkv * DH;
+    const _Float16* vg = v + (size_t)k_start * v_stride0 + (size_t)hkv * DH;
+    v4u kreg[4], vreg[4];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i, key = idx >> 4, ch = idx & 15;
+            const int kk = t * BN + key;
+            if (kk < len_k) {
+                kreg[i] = *reinterpret_cast<const v4u*>(kg + (size_t)kk * k_stride0 + ch * 8);
+                vreg[i] = *reinterpret_cast<const v4u*>(vg + (size_t)kk * v_stride0 + ch * 8);
+            } else {
+                kreg[i] = (v4u){0, 0, 0, 0};
+                vreg[i] = (v4u){0, 0, 0, 0};
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i, key = idx >> 4, ch = idx & 15;
+            *reinterpret_cast<v4u*>(&s_k[buf][key * 256 + ((ch ^ (key & 15)) * 16)]) = kreg[i];
+            const h8 vv = __builtin_bit_cast(h8, vreg[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                *reinterpret_cast<_Float16*>(&s_vt[buf][(ch * 8 + e) * VT_STRIDE + key * 2]) = vv[e];
+        }
+    };
+
+    v16f oacc[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    if (ntiles > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) load_tile(t + 1);          // global loads in flight during the MFMAs below
+
+        // ---------------- S^T = K Q^T : two blocks of 32 keys ----------------
+        v16f sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+            const int key = 32 * kb + li;
+            const uint8_t* krow = &s_k[buf][key * 256];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const h8 ka = *reinterpret_cast<const h8*>(krow + (((2 * s + hi) ^ (key & 15)) * 16));
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qf[s], sacc[kb], 0, 0, 0);
+            }
+        }
+        // sacc[kb][r] = score of (this lane's row, key t*64 + 32kb + (r&3) + 8(r>>2) + 4hi)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * BN + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const bool ok = key < len_k && (!CAUSAL || key <= row + shift);
+                const float sv = ok ? sacc[kb][r] * scale_log2 : -INFINITY;
+                sacc[kb][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;     // fully masked so far: keep exp2 arguments finite
+        const float alpha = exp2f(m_run - m_use);                  // m_run = -inf -> 0
+        m_run = m_new;
+        float psum = 0.f;
+        u32 pb[2][2][4];                                           // [kb][m]: 8 probabilities in B-operand order
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float p0 = exp2f(sacc[kb][8 * m + 2 * j] - m_use);
+                    const float p1 = exp2f(sacc[kb][8 * m + 2 * j + 1] - m_use);
+                    psum += p0 + p1;
+                    pb[kb][m][j] = pack_h2(p0, p1);
+                }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+
+        // ---------------- O^T += V^T P^T ----------------
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint8_t* vrow = &s_vt[buf][(32 * d + li) * VT_STRIDE + 8 * hi];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int kofs = (32 * kb + 16 * m) * 2;
+                    const v2u lo = *reinterpret_cast<const v2u*>(vrow + kofs);          // keys 16m + 4hi + 0..3
+                    const v2u hi2 = *reinterpret_cast<const v2u*>(vrow + kofs + 16);    // keys 16m + 8 + 4hi + 0..3
+                    const h8 va = __builtin_bit_cast(h8, (v4u){lo.x, lo.y, hi2.x, hi2.y});
+                    const h8 pbv = __builtin_bit_cast(h8, (v4u){pb[kb][m][0], pb[kb][m][1], pb[kb][m][2], pb[kb][m][3]});
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pbv, oacc[d], 0, 0, 0);
+                }
+        }
+        if (t + 1 < ntiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: normalise, fp16, 8-byte stores (4 consecutive dims per accumulator quad) ---------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (row < len_q) {
+        _Float16* op = out + (size_t)(q_start + row) * o_stride0 + (size_t)h * DH;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                h4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (_Float16)(oacc[d][4 * rq + j] * inv);
+                *reinterpret_cast<h4*>(op + 32 * d + 8 * rq + 4 * hi) = o;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int qs_flash_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out,
+                                        const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int batch,
+                                        int num_heads, int num_kv_heads, int head_dim, int64_t q_stride0,
+                                        int64_t k_stride0, int64_t v_stride0, int64_t o_stride0, int max_seqlen_q,
+                                        int max_seqlen_k, float softmax_scale, int causal, qs_stream_t stream) {
+    QS_REQUIRE(q && k && v && out && cu_seqlens_q && cu_seqlens_k, "flash_attn_varlen: null pointer");
+    QS_REQUIRE(batch >= 0 && num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
+               "flash_attn_varlen: bad head counts H=%d Hkv=%d", num_heads, num_kv_heads);
+    if (head_dim != DH) {
+        qs_set_error("flash_attn_varlen: head_dim=%d, only 128 is supported (the reference's models)", head_dim);
+        return QS_ENOSUP;
+    }
+    QS_REQUIRE(q_stride0 % 8 == 0 && k_stride0 % 8 == 0 && v_stride0 % 8 == 0 && o_stride0 % 4 == 0,
+               "flash_attn_varlen: token strides must keep 16-byte alignment");
+    QS_REQUIRE(max_seqlen_q >= 0 && max_seqlen_k >= 0, "flash_attn_varlen: negative max_seqlen");
+    if (batch == 0 || max_seqlen_q == 0) return QS_OK;
+    const float scale_log2 = softmax_scale * 1.4426950408889634f;
+    dim3 grid((max_seqlen_q + BM - 1) / BM, num_heads, batch);
+    constexpr int SMEM = 2 * KS_BYTES + 2 * VT_BYTES;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_fwd_kernel<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_fwd_kernel<false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            qs_set_error("flash_attn_varlen: cannot reserve %d bytes of LDS", SMEM);
+            return (int)(e1 != hipSuccess ? e1 : e2);
+        }
+        configured = true;
+    }
+    if (causal)
+        hipLaunchKernelGGL(flash_fwd_kernel<true>, grid, dim3(256), SMEM, (hipStream_t)stream, (const _Float16*)q,
+                           (const _Float16*)k, (const _Float16*)v, (_Float16*)out, cu_seqlens_q, cu_seqlens_k, num_heads,
+                           num_kv_heads, q_stride0, k_stride0, v_stride0, o_stride0, scale_log2);
+    else
+        hipLaunchKernelGGL(flash_fwd_kernel<false>, grid, dim3(256), SMEM, (hipStream_t)stream, (const _Float16*)q,
+                           (const _Float16*)k, (const _Float16*)v, (_Float16*)out, cu_seqlens_q, cu_seqlens_k, num_heads,
+                           num_kv_heads, q_stride0, k_stride0, v_stride0, o_stride0, scale_log2);
+    return qs_launch_status("flash_attn_varlen");
+}
