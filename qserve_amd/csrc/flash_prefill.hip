@@ -10,11 +10,12 @@
 //     (8 x 16 dims) in registers for the whole key loop;
 //   * key/value tiles of 64 keys are staged through LDS once per workgroup (shared by the 4 waves; the G query heads
 //     of a GQA group are separate workgroups that re-read the tiles from L2): K row-major with a 16-byte XOR swizzle,
-//     V TRANSPOSED to [dim][key] with padded rows, both double-buffered, one barrier per tile;
+//     V row-major too (16-byte swizzle by key & 3) and TRANSPOSED ON READ by ds_read_b64_tr_b16, both tiles
+//     double-buffered, one barrier per tile;
 //   * "swapped" products on v_mfma_f32_32x32x16_f16:  S^T = K Q^T  (A = K rows, B = Q rows, both plain 16-byte reads)
 //     leaves every lane holding 16 of the 32 scores of ITS OWN query row, so the softmax is register-only (one
 //     cross-lane max with lane ^ 32) and the probabilities already sit in B-operand order for
-//     O^T = V^T P^T  (A = V^T rows from LDS, 2 x 8 bytes; k-slot <-> key mapping chosen to match the S^T layout);
+//     O^T = V^T P^T  (A = V^T fragments, two transpose reads each; k-slot <-> key mapping chosen to match the S^T layout);
 //   * exp2 with the scale folded into one fp32 multiply; rescaling of O only through the running max.
 #include "common.h"
 
@@ -26,9 +27,8 @@ typedef u32 v2u __attribute__((ext_vector_type(2)));
 constexpr int DH = 128;
 constexpr int BM = 128;           // query rows per workgroup
 constexpr int BN = 64;            // keys per tile
-constexpr int VT_STRIDE = 136;    // bytes per V^T row: 64 keys * 2 B + 8 (conflict-free 8-byte reads over 32 rows)
 constexpr int KS_BYTES = BN * DH * 2;             // 16 KiB
-constexpr int VT_BYTES = DH * VT_STRIDE;          // 17 KiB
+constexpr int VT_BYTES = BN * DH * 2;             // 16 KiB (row-major like K; transposed on read)
 
 __device__ __forceinline__ u32 pack_h2(float a, float b) {
     const h2 v = {(_Float16)a, (_Float16)b};
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const _Float16* __res
                                                           float scale_log2) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t (*s_k)[KS_BYTES] = reinterpret_cast<uint8_t (*)[KS_BYTES]>(smem);                    // [2][16 KiB]
-    uint8_t (*s_vt)[VT_BYTES] = reinterpret_cast<uint8_t (*)[VT_BYTES]>(smem + 2 * KS_BYTES);    // [2][17 KiB]
+    uint8_t (*s_vt)[VT_BYTES] = reinterpret_cast<uint8_t (*)[VT_BYTES]>(smem + 2 * KS_BYTES);    // [2][16 KiB]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,10 +97,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const _Float16* __res
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 256 * i, key = idx >> 4, ch = idx & 15;
             *reinterpret_cast<v4u*>(&s_k[buf][key * 256 + ((ch ^ (key & 15)) * 16)]) = kreg[i];
-            const h8 vv = __builtin_bit_cast(h8, vreg[i]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                *reinterpret_cast<_Float16*>(&s_vt[buf][(ch * 8 + e) * VT_STRIDE + key * 2]) = vv[e];
+            *reinterpret_cast<v4u*>(&s_vt[buf][key * 256 + ((ch ^ ((key & 3) << 1)) * 16)]) = vreg[i];
         }
     };
 
@@ -136,21 +133,32 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const _Float16* __res
             }
         }
         // sacc[kb][r] = score of (this lane's row, key t*64 + 32kb + (r&3) + 8(r>>2) + 4hi)
+        // masking only where the tile touches the diagonal or the end of the keys (wave-uniform test); raw scores
+        // stay unscaled, the scale is folded into the exponent's fma
+        const int tile_last = t * BN + BN - 1;
+        const bool need_mask = tile_last >= len_k || (CAUSAL && tile_last > qt * BM + wave * 32 + shift);
         float mx = -INFINITY;
+        if (need_mask) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = t * BN + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const bool ok = key < len_k && (!CAUSAL || key <= row + shift);
-                const float sv = ok ? sacc[kb][r] * scale_log2 : -INFINITY;
-                sacc[kb][r] = sv;
-                mx = fmaxf(mx, sv);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * BN + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool ok = key < len_k && (!CAUSAL || key <= row + shift);
+                    const float sv = ok ? sacc[kb][r] : -INFINITY;
+                    sacc[kb][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2;      // scale > 0: max commutes with it
         const float m_new = fmaxf(m_run, mx);
         const float m_use = m_new == -INFINITY ? 0.f : m_new;     // fully masked so far: keep exp2 arguments finite
-        const float alpha = exp2f(m_run - m_use);                  // m_run = -inf -> 0
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);                  // m_run = -inf -> 0
         m_run = m_new;
         float psum = 0.f;
         u32 pb[2][2][4];                                           // [kb][m]: 8 probabilities in B-operand order
@@ -160,28 +168,39 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const _Float16* __res
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float p0 = exp2f(sacc[kb][8 * m + 2 * j] - m_use);
-                    const float p1 = exp2f(sacc[kb][8 * m + 2 * j + 1] - m_use);
+                    const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][8 * m + 2 * j], scale_log2, -m_use));      // -inf stays -inf
+                    const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[kb][8 * m + 2 * j + 1], scale_log2, -m_use));
                     psum += p0 + p1;
                     pb[kb][m][j] = pack_h2(p0, p1);
                 }
         l_run = l_run * alpha + psum;
+        if (__any(alpha != 1.0f)) {                                // the running max moved for some row of this wave
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+            for (int d = 0; d < 4; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+        }
 
         // ---------------- O^T += V^T P^T ----------------
+        // A = V^T fragments by the LDS transpose read: a 16-lane group (16 consecutive dims, one lane half) reads the
+        // [4 keys][16 dims] block of the row-major tile - lane a supplies the 8-byte piece (key a>>2, dims 4(a&3)..+3) - and
+        // lane c receives column c = (dim c, keys 0..3), i.e. exactly its four k-slots of the PV MFMA.
+        const int ta = lane & 15, g1 = (lane >> 4) & 1;
+        const int tkey = 4 * hi + (ta >> 2);                       // key within a 16-key block; tkey & 3 == ta >> 2
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const uint8_t* vrow = &s_vt[buf][(32 * d + li) * VT_STRIDE + 8 * hi];
+            const int chunk = (4 * d + 2 * g1 + ((ta & 3) >> 1)) ^ ((ta >> 2) << 1);
+            const uint8_t* vrow = &s_vt[buf][tkey * 256 + chunk * 16 + (ta & 1) * 8];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const int kofs = (32 * kb + 16 * m) * 2;
-                    const v2u lo = *reinterpret_cast<const v2u*>(vrow + kofs);          // keys 16m + 4hi + 0..3
-                    const v2u hi2 = *reinterpret_cast<const v2u*>(vrow + kofs + 16);    // keys 16m + 8 + 4hi + 0..3
+                    const int kofs = (32 * kb + 16 * m) * 256;
+                    typedef short s4 __attribute__((ext_vector_type(4)));
+                    typedef __attribute__((address_space(3))) s4* lds_s4;
+                    const s4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(vrow + kofs));             // keys +0..3
+                    const s4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(vrow + kofs + 8 * 256));   // keys +8..11
+                    const v2u lo = __builtin_bit_cast(v2u, t0), hi2 = __builtin_bit_cast(v2u, t1);
                     const h8 va = __builtin_bit_cast(h8, (v4u){lo.x, lo.y, hi2.x, hi2.y});
                     const h8 pbv = __builtin_bit_cast(h8, (v4u){pb[kb][m][0], pb[kb][m][1], pb[kb][m][2], pb[kb][m][3]});
                     oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pbv, oacc[d], 0, 0, 0);
@@ -225,6 +244,7 @@ extern "C" int qs_flash_attn_varlen_fwd(const void* q, const void* k, const void
     QS_REQUIRE(q_stride0 % 8 == 0 && k_stride0 % 8 == 0 && v_stride0 % 8 == 0 && o_stride0 % 4 == 0,
                "flash_attn_varlen: token strides must keep 16-byte alignment");
     QS_REQUIRE(max_seqlen_q >= 0 && max_seqlen_k >= 0, "flash_attn_varlen: negative max_seqlen");
+    QS_REQUIRE(softmax_scale > 0.f, "flash_attn_varlen: softmax_scale must be positive");
     if (batch == 0 || max_seqlen_q == 0) return QS_OK;
     const float scale_log2 = softmax_scale * 1.4426950408889634f;
     dim3 grid((max_seqlen_q + BM - 1) / BM, num_heads, batch);
