@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-bench", action="store_true")
+    ap.add_argument("--no-prefill", action="store_true", help="skip the prompt-phase measurement")
     ap.add_argument("--op-by-op", action="store_true",
                     help="issue the reference's ops one by one (no fused pairs) in the timed step")
     return ap.parse_args()
@@ -222,6 +223,23 @@ def main():
         ms_op = (time.perf_counter() - t0) / steps2 * 1e3
         eng.fuse_pairs = True
 
+    # the prompt phase through the same library (W4A8 GEMMs at M = batch*prompt_len, prefill KV writer, causal flash
+    # attention): prompt tokens/s, and the reference's end-to-end protocol (qserve_benchmark.py:48-67,108: generated
+    # tokens / (prefill + decode wall time)) composed from the two measured phases
+    prefill_ms = None
+    if not args.no_prefill and world == 1:
+        saved_len = eng.lengths.clone()
+        try:
+            eng.prefill(args.prompt_len)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.prefill(args.prompt_len)
+            torch.cuda.synchronize()
+            prefill_ms = (time.perf_counter() - t0) * 1e3
+            eng.lengths.copy_(saved_len)               # the per-kernel timing below uses the step's context length
+        except RuntimeError as e:                      # e.g. out of memory for the [tokens, 2*inter] buffer
+            print(f"[bench] prefill phase skipped: {e}", file=sys.stderr)
+
     roof, kernels = None, None
     if not args.no_kernel_bench:
         kernels = kernel_bench(eng, torch)
@@ -279,7 +297,15 @@ def main():
                        "op_sequence": "reference ops one by one" if args.op_by_op else
                        "reference ops; (residual add, layer norm) and (silu_and_mul, quant) issued as bit-identical "
                        "fused pairs (qserve_amd/fused.py)",
-                       "op_by_op_tokens_per_s": round(args.batch / (ms_op / 1e3), 1) if ms_op else None},
+                       "op_by_op_tokens_per_s": round(args.batch / (ms_op / 1e3), 1) if ms_op else None,
+                       "prefill_tokens_per_s": round(args.batch * args.prompt_len / (prefill_ms / 1e3), 1)
+                       if prefill_ms else None,
+                       "prefill_ms": round(prefill_ms, 2) if prefill_ms else None,
+                       "e2e_tokens_per_s": round(args.batch * args.max_new / ((prefill_ms + args.max_new * ms) / 1e3), 1)
+                       if prefill_ms else None,
+                       "e2e_note": "reference protocol (qserve_benchmark.py: generated tokens / (prefill + decode) wall "
+                                   f"time) for {args.max_new} generated tokens per sequence, composed from the measured "
+                                   "prefill time and the measured decode step time"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernels": kernels,

@@ -149,6 +149,90 @@ class DecodeEngine:
         self.lengths.fill_(prompt_len + 1)
         torch.cuda.synchronize()
 
+    # ---- real prefill: the reference's is_prompt=True path (llama_w4a8_unpad.py:199-243, 330-361) -------------
+    def prefill(self, prompt_len, tokens=None):
+        """Run the prompt through the model: per layer  norm+quant -> qkv GEMM -> apply_bias_rope_update_kv_cache
+        (RoPE in place + quantised cache write) -> flash_attn_varlen_func (causal) -> quant -> o_proj -> residual+norm
+        -> gate_up -> silu_and_mul+quant -> down -> residual.  All sequences have `prompt_len` tokens.  Leaves the
+        cache filled, `hidden` = last-token states, `tokens` = first sampled token, lengths = prompt_len + 1."""
+        from .flash import flash_attn_varlen_func
+        cfg, B, dev = self.cfg, self.B, self.dev
+        assert self.with_lm_head and prompt_len + 1 <= self.max_len
+        T = B * prompt_len
+        f16, i8 = torch.float16, torch.int8
+        fuse_sum, fuse = self.group_size == -1, self.fuse_pairs
+        if tokens is None:
+            tokens = torch.randint(0, cfg["vocab"], (T,), device=dev,
+                                   generator=torch.Generator(device=dev).manual_seed(7))
+        h = torch.index_select(self.embed, 0, tokens)
+        qa = torch.empty((T, self.hid), dtype=i8, device=dev)
+        qo = torch.empty((T, self.H * 128), dtype=i8, device=dev)
+        q_mlp = torch.empty((T, self.inter), dtype=i8, device=dev)
+        q_scale = torch.empty((T,), dtype=f16, device=dev)
+        q_sum = torch.empty((T,), dtype=f16, device=dev)
+        qkv = torch.empty((T, self.qkv_n), dtype=f16, device=dev)
+        proj = torch.empty((T, self.hid), dtype=f16, device=dev)
+        gate_up = torch.empty((T, 2 * self.inter), dtype=f16, device=dev)
+        mlp_act = None if fuse else torch.empty((T, self.inter), dtype=f16, device=dev)
+        seq = torch.full((B,), prompt_len, dtype=torch.int32, device=dev)
+        cu = torch.arange(0, B + 1, device=dev, dtype=torch.int32) * prompt_len
+        pad = fused_attention.compute_padding_offsets(cu, prompt_len, T)
+        sums = q_sum if fuse_sum else None
+
+        def norm_quant(x, w):
+            if fuse_sum:
+                layernorm_ops.rms_norm_general_fuse_sum(qa, x, w, q_sum, q_scale, cfg["eps"], True)
+            else:
+                layernorm_ops.rms_norm_general(qa, x, w, q_scale, cfg["eps"], True)
+
+        def add_norm_quant(x, delta, w):
+            if fuse:
+                fusedmod.add_residual_rms_norm_general(qa, x, delta, w, q_scale, cfg["eps"], sums)
+            else:
+                residual_add_(x, delta)
+                norm_quant(x, w)
+
+        nl = len(self.layers)
+        for li, L in enumerate(self.layers):
+            if li == 0:
+                norm_quant(h, L["ln1"])
+            L["qkv"](qa, q_scale, q_sum, qkv)
+            fused_attention.apply_bias_rope_update_kv_cache(
+                qkv, seq, pad, self.tables[li], self.H, self.Hkv, prompt_len, 64, self.size_per_token, 128,
+                cfg["rope_theta"], 8192, True, self.int4, True)
+            q, k, v = qkv.split([self.H * 128, self.Hkv * 128, self.Hkv * 128], dim=-1)
+            attn = flash_attn_varlen_func(q.reshape(T, self.H, 128), k.reshape(T, self.Hkv, 128),
+                                          v.reshape(T, self.Hkv, 128), cu, cu, prompt_len, prompt_len, dropout_p=0.0,
+                                          causal=True).reshape(T, -1)
+            if fuse_sum:
+                fused_kernels.invoke_quant_fuse_sum(qo, attn, q_sum, q_scale)
+            else:
+                fused_kernels.invoke_quant(qo, attn, q_scale)
+            L["o"](qo, q_scale, q_sum, proj)
+            tpmod.all_reduce_sum_(proj)
+            add_norm_quant(h, proj, L["ln2"])
+            L["gate_up"](qa, q_scale, q_sum, gate_up)
+            if fuse:
+                fusedmod.silu_and_mul_quant(q_mlp, gate_up, q_scale, sums)
+            else:
+                activation_ops.silu_and_mul(mlp_act, gate_up)
+                if fuse_sum:
+                    fused_kernels.invoke_quant_fuse_sum(q_mlp, mlp_act, q_sum, q_scale)
+                else:
+                    fused_kernels.invoke_quant(q_mlp, mlp_act, q_scale)
+            L["down"](q_mlp, q_scale, q_sum, proj)
+            tpmod.all_reduce_sum_(proj)
+            if li + 1 < nl:
+                add_norm_quant(h, proj, self.layers[li + 1]["ln1"])
+            else:
+                residual_add_(h, proj)
+        last = (cu[1:] - 1).to(torch.int64)
+        torch.index_select(h, 0, last, out=self.hidden)
+        layernorm_ops.rms_norm(self.final, self.hidden, self.norm_w, cfg["eps"])
+        logits = torch.matmul(self.final, self.lm_head.t())
+        torch.argmax(logits, dim=-1, out=self.tokens)
+        self.lengths.fill_(prompt_len + 1)
+
     # ---- one decode step (llama_w4a8_unpad.py:330-361 per layer) --------------------------------------------
     def step(self):
         cfg, B = self.cfg, self.B
