@@ -27,6 +27,39 @@ __device__ __forceinline__ float block_reduce(float v, float* sm, int op) {
     for (int w = 1; w < NT / 64; ++w) r = op == 0 ? r + sm[w] : fmaxf(r, sm[w]);
     return r;
 }
+// One-barrier variants: every reduction round of a kernel gets its OWN LDS slots (`sm`, `sm2` never reused), so the
+// leading "protect reuse" barrier is unnecessary, and a max and a sum that are needed at the same point travel together.
+// Same shuffle trees and the same left-to-right combination over waves as block_reduce: bit-identical results.
+template <int NT = TPB>
+__device__ __forceinline__ float block_reduce_once(float v, float* sm, int op) {
+    v = op == 0 ? wave_sum(v) : wave_max(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    float r = sm[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) r = op == 0 ? r + sm[w] : fmaxf(r, sm[w]);
+    return r;
+}
+template <int NT = TPB>
+__device__ __forceinline__ void block_reduce_max_sum(float& mx, float& sum, float* sm, float* sm2, bool want_sum) {
+    mx = wave_max(mx);
+    if (want_sum) sum = wave_sum(sum);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        sm[wave] = mx;
+        if (want_sum) sm2[wave] = sum;
+    }
+    __syncthreads();
+    float r = sm[0], s = want_sum ? sm2[0] : 0.f;
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) {
+        r = fmaxf(r, sm[w]);
+        if (want_sum) s = s + sm2[w];
+    }
+    mx = r;
+    sum = s;
+}
 // rows wider than this are handled by 1024-thread workgroups (same rule in invoke_quant and silu_and_mul_quant, so the
 // two associate their fp32 statistics identically)
 constexpr int WIDE_ROW = 4096;
@@ -51,7 +84,7 @@ template <int NC, int NT>
 __global__ __launch_bounds__(NT) void quant_kernel(int8_t* __restrict__ out, const _Float16* __restrict__ in,
                                                     __half* __restrict__ sum_out, __half* __restrict__ scale_out,
                                                     int hidden) {
-    __shared__ float sm[NT / 64];
+    __shared__ float sm[2][NT / 64];
     const size_t base = (size_t)blockIdx.x * hidden;
     h8 v[NC];
     float amax = 0.f, sum = 0.f;
@@ -68,8 +101,8 @@ __global__ __launch_bounds__(NT) void quant_kernel(int8_t* __restrict__ out, con
             }
         }
     }
-    amax = block_reduce<NT>(amax, sm, 1);
-    if (sum_out) sum = block_reduce<NT>(sum, sm, 0);
+    block_reduce_max_sum<NT>(amax, sum, sm[0], sm[1], sum_out != nullptr);
+    
     if (threadIdx.x == 0) {
         scale_out[blockIdx.x] = __float2half_rn(amax / 127.0f);          // fused_kernels.cu:72
         if (sum_out) sum_out[blockIdx.x] = __float2half_rn(sum);         // :121
@@ -100,7 +133,7 @@ __global__ __launch_bounds__(TPB) void general_norm_quant_kernel(int8_t* __restr
                                                                  __half* __restrict__ sum_out,
                                                                  __half* __restrict__ scale_out, float eps,
                                                                  int hidden) {
-    __shared__ float sm[TPB / 64];
+    __shared__ float sm[4][TPB / 64];
     const size_t base = (size_t)blockIdx.x * hidden;
     h8 v[NC], g[NC];
     float s = 0.f;
@@ -114,7 +147,7 @@ __global__ __launch_bounds__(TPB) void general_norm_quant_kernel(int8_t* __restr
             for (int j = 0; j < 8; ++j) s += (float)v[c][j];
         }
     }
-    const float mean = block_reduce(s, sm, 0) / hidden;                  // :248
+    const float mean = block_reduce_once(s, sm[0], 0) / hidden;                  // :248
     float vs = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -125,7 +158,7 @@ __global__ __launch_bounds__(TPB) void general_norm_quant_kernel(int8_t* __restr
                 vs += d * d;
             }
         }
-    const float rstd_e = 1.0f / sqrtf(block_reduce(vs, sm, 0) / hidden + eps);   // :271 (rsqrtf there)
+    const float rstd_e = 1.0f / sqrtf(block_reduce_once(vs, sm[1], 0) / hidden + eps);   // :271 (rsqrtf there)
     float amax = (float)(_Float16)1e-6f, sum = 0.f;                      // :285-286 (amax, sum start values)
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -137,8 +170,8 @@ __global__ __launch_bounds__(TPB) void general_norm_quant_kernel(int8_t* __restr
                 sum += (float)hv;
             }
         }
-    amax = block_reduce(amax, sm, 1);
-    if (sum_out) sum = block_reduce(sum, sm, 0);
+    block_reduce_max_sum(amax, sum, sm[2], sm[3], sum_out != nullptr);
+    
     const float mul = 127.f / amax;                                      // :308
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -167,7 +200,7 @@ __global__ __launch_bounds__(TPB) void rms_norm_kernel(_Float16* __restrict__ ou
 #pragma unroll
         for (int j = 0; j < 8; ++j) vs += (float)v[j] * (float)v[j];
     }
-    const float rstd = 1.0f / sqrtf(block_reduce(vs, sm, 0) / hidden + eps);   // :347
+    const float rstd = 1.0f / sqrtf(block_reduce_once(vs, sm, 0) / hidden + eps);   // :347
     for (int i = threadIdx.x * 8; i < hidden; i += TPB * 8) {
         h8 v = load8(in + base + i);
         h8 g = load8(w + i);
@@ -222,7 +255,7 @@ __global__ __launch_bounds__(TPB) void add_residual_norm_quant_kernel(int8_t* __
                                                                       __half* __restrict__ sum_out,
                                                                       __half* __restrict__ scale_out, float eps,
                                                                       int hidden) {
-    __shared__ float sm[TPB / 64];
+    __shared__ float sm[4][TPB / 64];
     const size_t base = (size_t)blockIdx.x * hidden;
     h8 v[NC], g[NC];
     float s = 0.f;
@@ -237,7 +270,7 @@ __global__ __launch_bounds__(TPB) void add_residual_norm_quant_kernel(int8_t* __
             for (int j = 0; j < 8; ++j) s += (float)v[c][j];
         }
     }
-    const float mean = block_reduce(s, sm, 0) / hidden;
+    const float mean = block_reduce_once(s, sm[0], 0) / hidden;
     float vs = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -248,7 +281,7 @@ __global__ __launch_bounds__(TPB) void add_residual_norm_quant_kernel(int8_t* __
                 vs += d * d;
             }
         }
-    const float rstd_e = 1.0f / sqrtf(block_reduce(vs, sm, 0) / hidden + eps);
+    const float rstd_e = 1.0f / sqrtf(block_reduce_once(vs, sm[1], 0) / hidden + eps);
     float amax = (float)(_Float16)1e-6f, sum = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -260,8 +293,8 @@ __global__ __launch_bounds__(TPB) void add_residual_norm_quant_kernel(int8_t* __
                 sum += (float)hv;
             }
         }
-    amax = block_reduce(amax, sm, 1);
-    if (sum_out) sum = block_reduce(sum, sm, 0);
+    block_reduce_max_sum(amax, sum, sm[2], sm[3], sum_out != nullptr);
+    
     const float mul = 127.f / amax;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -285,7 +318,7 @@ template <int NC, int NT>
 __global__ __launch_bounds__(NT) void silu_mul_quant_kernel(int8_t* __restrict__ out, const _Float16* __restrict__ in,
                                                              __half* __restrict__ sum_out,
                                                              __half* __restrict__ scale_out, int d) {
-    __shared__ float sm[NT / 64];
+    __shared__ float sm[2][NT / 64];
     const size_t ib = (size_t)blockIdx.x * 2 * d, ob = (size_t)blockIdx.x * d;
     h8 x[NC], y[NC], o[NC];
 #pragma unroll
@@ -312,8 +345,8 @@ __global__ __launch_bounds__(NT) void silu_mul_quant_kernel(int8_t* __restrict__
             }
         }
     }
-    amax = block_reduce<NT>(amax, sm, 1);
-    if (sum_out) sum = block_reduce<NT>(sum, sm, 0);
+    block_reduce_max_sum<NT>(amax, sum, sm[0], sm[1], sum_out != nullptr);
+    
     if (threadIdx.x == 0) {
         scale_out[blockIdx.x] = __float2half_rn(amax / 127.0f);
         if (sum_out) sum_out[blockIdx.x] = __float2half_rn(sum);
