@@ -73,7 +73,12 @@ int qs_w4a8_per_group_gemm_acc(const int8_t* in_feats, const int8_t* kernel, con
 int qs_w8a8_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscales, const void* ascales,
                  void* out_feats, int M, int N, int K, qs_stream_t stream);
 
-/* Kernel-variant selection for benchmarking / A-B tests (process-wide; default -1 = heuristic). */
+/* Kernel-variant selection for benchmarking / A-B tests (process-wide; default -1 = the measured heuristic).  Every
+ * variant except the 31xx timing experiments computes the same results:
+ *   9xx / 1000 + 100*mtile + 10*S + NW ... split-K decode kernel geometries;  2000 / 2001 ... LDS-pair kernel off / forced;
+ *   3000 ... tiled (prefill) kernel off, 3001 / 3002 ... forced with the 256- / 128-token tile;
+ *   4000 ... ring (decode) kernel off, 4100 + 10*m_tiles + units ... forced ring geometry;
+ *   3100 + bits ... TIMING EXPERIMENTS ONLY (kernel parts switched off, results are wrong by design). */
 void qs_set_gemm_variant(int variant);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -98,7 +103,8 @@ int qs_single_query_attention(const void* q, const void* k, const void* v, const
                               int timestep, int rotary_embedding_dim, float rotary_base, int neox_rotary_style,
                               int int4_kv_cache, int kv_cache_with_zeros, qs_stream_t stream);
 
-/* Kernel selection for A/B tests: 0 = matrix-core (MFMA) kernel for KV4 [default], 1 = VALU kernel. */
+/* Kernel selection for A/B tests: 0 = matrix-core kernels (KV4 and KV8) with the split-KV heuristic [default],
+ * 1 = VALU kernels, 100 + n = matrix-core kernels with exactly n KV splits. */
 void qs_set_attention_variant(int variant);
 
 /* Prefill KV writer.  Replaces qserve_backend.fused_attention.apply_bias_rope_update_kv_cache
