@@ -14,8 +14,9 @@
  *     GEMMs use: gemm_cuda.cu:53);
  *   - return value: 0 on success, a negative QS_E* code on rejected arguments (nothing was launched),
  *     a positive hipError_t if the launch failed.  qs_last_error() returns a thread-local message;
- *   - nothing here allocates device memory; callers own every buffer (ownership rules of the reference,
- *     SURVEY.md 8(b) "Conventions").
+ *   - callers own every tensor buffer (ownership rules of the reference, SURVEY.md 8(b) "Conventions"); the library
+ *     keeps three small device scratch areas of its own (RoPE cos/sin table, split-KV partials, split-K slabs),
+ *     allocated lazily on a first eager call and never while the stream is being captured into a graph.
  */
 #ifndef QSERVE_AMD_H
 #define QSERVE_AMD_H
