@@ -1,0 +1,70 @@
+"""Host-side logic of the mirror / provider modules, exercised without a GPU: every op validates dtype, device, layout
+and unsupported options BEFORE it touches the library, with the error types the reference raises (RuntimeError for
+TORCH_CHECK / data_ptr<T>() mismatches, NotImplementedError for variants outside the W4A8KV4 path)."""
+import pytest
+import torch
+
+
+def test_gemm_mirror_rejects_cpu_and_wrong_dtype_tensors(built_lib):
+    import qserve_backend.qgemm_w4a8_per_chn as op
+    a = torch.zeros((4, 128), dtype=torch.int8)
+    w = torch.zeros((64, 64), dtype=torch.int8)
+    h = torch.zeros((64,), dtype=torch.float16)
+    m = torch.zeros((4,), dtype=torch.float16)
+    out = torch.zeros((4, 64), dtype=torch.float16)
+    with pytest.raises(RuntimeError):                      # CPU tensors: the reference's kernels would fault; we raise
+        op.gemm_forward_cuda(a, w, h, m, h, m, out)
+    with pytest.raises(RuntimeError):                      # dtype: data_ptr<int8_t>() throws in the reference
+        op.gemm_forward_cuda(a.float(), w, h, m, h, m, out)
+
+
+def test_flash_shim_signature_and_option_checks(built_lib):
+    import inspect
+
+    from flash_attn.flash_attn_interface import flash_attn_varlen_func
+    params = list(inspect.signature(flash_attn_varlen_func).parameters)
+    assert params[:7] == ["q", "k", "v", "cu_seqlens_q", "cu_seqlens_k", "max_seqlen_q", "max_seqlen_k"]
+    for kw in ("dropout_p", "softmax_scale", "causal"):    # keywords the reference passes (llama_w4a8_unpad.py:232-242)
+        assert kw in params
+    q = torch.zeros((4, 2, 128), dtype=torch.float16)
+    cu = torch.tensor([0, 4], dtype=torch.int32)
+    with pytest.raises(NotImplementedError):
+        flash_attn_varlen_func(q, q, q, cu, cu, 4, 4, dropout_p=0.5)
+    with pytest.raises(NotImplementedError):
+        flash_attn_varlen_func(q, q, q, cu, cu, 4, 4, window_size=(128, 0))
+    with pytest.raises(RuntimeError):                      # CPU tensors
+        flash_attn_varlen_func(q, q, q, cu, cu, 4, 4, causal=True)
+
+
+def test_xformers_shim_exports_the_type_the_reference_imports():
+    from xformers.ops import AttentionBias
+    assert isinstance(AttentionBias, type)
+
+
+def test_w8a8_only_ops_say_so(built_lib):
+    import qserve_backend.activation_ops as act
+    import qserve_backend.layernorm_ops as ln
+    with pytest.raises(NotImplementedError):
+        ln.invoke_dequant_add_residual_rms_norm_quant()
+    with pytest.raises(NotImplementedError):
+        ln.rms_norm(None, None, None, 1e-5, use_quant=True)
+    assert hasattr(act, "silu_and_mul")
+
+
+def test_fused_pair_wrappers_validate_shapes(built_lib):
+    from qserve_amd import fused
+    x = torch.zeros((2, 64), dtype=torch.float16)
+    with pytest.raises(RuntimeError):                      # CPU tensors / dtype checks come first
+        fused.add_residual_rms_norm_general(torch.zeros((2, 64), dtype=torch.int8), x, x, x[0], x[:, 0], 1e-5)
+    with pytest.raises(RuntimeError):
+        fused.silu_and_mul_quant(torch.zeros((2, 32), dtype=torch.int8), x, x[:, 0])
+
+
+def test_decode_engine_config_shapes():
+    """TP shard arithmetic of the bench driver (no device work): heads, kv heads and the intermediate size split."""
+    from qserve_amd.decode import LLAMA3_8B, QWEN15_72B
+    for cfg, tp in ((LLAMA3_8B, 8), (QWEN15_72B, 8), (LLAMA3_8B, 2)):
+        H, Hkv, inter = cfg["heads"], cfg["kv_heads"], cfg["inter"]
+        assert H % tp == 0 and Hkv % tp == 0 and inter % (tp * 128) == 0
+        qkv_n = (H // tp + 2 * (Hkv // tp)) * 128
+        assert qkv_n % 64 == 0 and (inter // tp) % 128 == 0
