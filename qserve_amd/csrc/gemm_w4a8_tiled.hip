@@ -95,7 +95,8 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 15, g = lane >> 4;
     const int tsel = li >> 3, c = li & 7;
-    // tile coordinates: consecutive workgroups walk M first inside a band of channels (weights of the band stay in L2)
+    // tile coordinates: consecutive workgroups walk M first inside a band of channels (weights of the band stay in L2).
+    // (an XCD-aware variant - every XCD owning a contiguous 4 x 2 super-tile of the grid - measured no better.)
     const int bm = blockIdx.x % nbm, bn = blockIdx.x / nbm;
     const int m0 = bm * BM, n0 = bn * BN;
     const int KT = K >> 5;
@@ -230,7 +231,9 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
             for (int cl = 0; cl < 4; ++cl)
                 if (!(DBG & 1)) acc[mt][cl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ac[cl], b_use, acc[mt][cl], 0, 0, 0);
                 else acc[mt][cl][0] += ac[cl][0] ^ b_use[cl];
-            QS_PIN();
+            // measured: pinning the read / DMA / unpack order between the MFMA groups gains 4-8 % per-channel, but with
+            // the VALU-heavy per-group dequant the compiler's own interleaving is 5-6 % faster
+            if (MODE == 0) QS_PIN();
         }
     };
     // barrier(u): stage u+1 has landed (this wave's pieces by the counted wait; the barrier extends that to every
