@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-prefill", action="store_true", help="skip the prompt-phase measurement")
     ap.add_argument("--op-by-op", action="store_true",
                     help="issue the reference's ops one by one (no fused pairs) in the timed step")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1 (tensor parallel): weak = --batch sequences PER GPU (global batch = batch x N, so every "
+                         "rank keeps N=1's GEMM MACs and KV bytes); strong = --batch is the global batch")
     return ap.parse_args()
 
 
@@ -160,6 +163,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    per_gpu_batch = args.batch
+    if world > 1 and args.scaling == "weak":
+        args.batch *= world          # global batch; the TP shards (heads / N / K splits) divide the work back
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -247,7 +253,13 @@ def main():
 
     roof, kernels = None, None
     if not args.no_kernel_bench:
-        kernels = kernel_bench(eng, torch)
+        try:
+            kernels = kernel_bench(eng, torch)      # every rank times its own shard's kernels; rank 0 reports
+        except Exception as e:
+            if world == 1:
+                raise
+            print(f"[bench] rank {rank}: per-kernel timing skipped ({type(e).__name__}: {e})", file=sys.stderr)
+    if kernels is not None:
         tot = {}
         for r in kernels:
             key = "w4a8_gemm" if r["kernel"].startswith("w4a8") else "decode_attention"
@@ -281,7 +293,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "decode tokens/sec/GPU Llama-3-8B W4A8KV4 bs=64" if args.model == "llama3-8b" and args.batch == 64
+            "metric": "decode tokens/sec/GPU Llama-3-8B W4A8KV4 bs=64" if args.model == "llama3-8b" and per_gpu_batch == 64
             else f"decode tokens/sec {cfg['name']} bs={args.batch}",
             "value": round(args.batch / (ms / 1e3), 1),
             "unit": "tokens/s",
@@ -290,12 +302,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms, 4),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "int8xint4->int32 (MFMA) + fp16",
             "data": "synthetic random-quantised weights/activations, KV cache written by the prefill writer",
             "config": {"workload": f"{cfg['name']} W4A8{'g128' if args.group_size == 128 else ' per-channel'} "
-                                   f"KV{'8' if args.kv8 else '4'} decode step, bs={args.batch}, context "
+                                   f"KV{'8' if args.kv8 else '4'} decode step, bs={args.batch}"
+                                   f"{f' ({per_gpu_batch} per GPU x tp{world})' if world > 1 else ''}, context "
                                    f"{args.prompt_len}->+{args.max_new} (BASELINE.json configs[1])",
                        "global_batch": args.batch, "context_start": args.prompt_len + 1 + args.warmup,
                        "parallelism": f"tp{world}", "hipgraph": graphed, "layers": cfg["layers"],

@@ -419,7 +419,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
             const long nb = N / 256;
             // measured crossovers (scripts/bench_gemm_big.py, N=4096..28672): the tiles must (nearly) fill 256 CUs
             if (((M + 255) / 256) * nb >= 192) tmt = 8;
-            else if (M >= 512 && ((M + 127) / 128) * nb >= (MODE == 0 ? 96 : 192)) tmt = 4;
+            else if (M >= 256 && ((M + 127) / 128) * nb >= (MODE == 0 ? 96 : 192)) tmt = 4;
         }
         if (tmt)
             return qs_launch_gemm_tiled(MODE, OUTK, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,
@@ -431,41 +431,36 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         const int mt = (g_variant - 4100) / 10, wn = (g_variant - 4100) % 10;
         const int mb = ((M + 15) / 16 + mt - 1) / mt;
         QS_REQUIRE((mt == 1 || mt == 2 || mt == 4) && (wn == 1 || wn == 2) && !(mt == 1 && wn == 2) &&
-                       N % (64 * wn) == 0 && (K / 64) % (16 / wn) == 0 && (mb == 1 || (N / (64 * wn)) % 8 == 0),
+                       N % (64 * wn) == 0 && (K / 64) % (16 / wn) == 0,
                    "w4a8 gemm: forced ring geometry mt=%d wn=%d does not fit M=%d N=%d K=%d", mt, wn, M, N, K);
         return qs_launch_gemm_ring(MODE, OUTK, mt, wn, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N,
                                    K, mb, stream);
     }
-    // measured crossovers (scripts/bench_gemm.py, Llama-3-8B shapes, M = 16 / 32 / 64 / 128)
-    if (M <= 128 && g_variant != 4000 && (g_variant < 1000 || g_variant >= 4000) &&
+    // Geometry choice (measured: scripts/bench_gemm.py for the Llama-3-8B shapes, scripts/bench_gemm_shard.py for the
+    // tensor-parallel shard shapes): a workgroup of (16 mt tokens) x (64 wn channels) streams K (16 mt + 32 wn) bytes
+    // through its CU, one workgroup per CU at a time, and the per-CU fill rate (~47 GB/s) is what bounds these shapes -
+    // so take the geometry with the fewest bytes per CU over all its rounds; ties go to the two-unit workgroups (the
+    // activation tile is shared by two waves).  Short K (< 1024) at M <= 64 stays on the split-K kernel (fixed costs).
+    if (M <= 1024 && !(K < 1024 && M <= 64) && g_variant != 4000 && (g_variant < 1000 || g_variant >= 4000) &&
         (size_t)M * K < (1ull << 32) && (size_t)N * K / 2 < (1ull << 32)) {
         const int mt_all = (M + 15) / 16;
-        if (units >= 256 && M > 16 && N % 128 == 0 && (K / 64) % 8 == 0) {   // many channels: 2 units x 4 K-groups
-            const int mt = mt_all <= 2 ? 2 : 4, mb = (mt_all + mt - 1) / mt;
-            if (mb == 1 || (N / 128) % 8 == 0)
-                return qs_launch_gemm_ring(MODE, OUTK, mt, 2, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out,
-                                           M, N, K, mb, stream);
+        static const int geo[5][2] = {{4, 2}, {2, 2}, {4, 1}, {2, 1}, {1, 1}};
+        long best = -1;
+        int bmt = 0, bwn = 0;
+        for (int i = 0; i < 5; ++i) {
+            const int mt = geo[i][0], wn = geo[i][1];
+            if (N % (64 * wn) != 0 || (K / 64) % (16 / wn) != 0) continue;
+            const long blocks = (long)((mt_all + mt - 1) / mt) * (N / (64 * wn));
+            const long cost = ((blocks + 255) / 256) * (16 * mt + 32 * wn);
+            if (best < 0 || cost < best) best = cost, bmt = mt, bwn = wn;
         }
-        if (units < 256 && units % 8 == 0 && (K / 64) % 16 == 0) {           // few channels: 1 unit x 8 K-groups, M split
-            int mt = 1;
-            for (int cand = 4; cand >= 1; cand >>= 1) {
-                if (cand > mt_all && cand > 1) continue;
-                const int mb = (mt_all + cand - 1) / cand;
-                if (units * mb >= 192 || cand == 1) {
-                    mt = cand;
-                    break;
-                }
-            }
-            const int mb = (mt_all + mt - 1) / mt;
-            // beyond 64 tokens only while 64-token tiles fill the chip (smaller tiles re-read the weights too often)
-            if (M <= 64 || mt == 4)
-                return qs_launch_gemm_ring(MODE, OUTK, mt, 1, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out,
-                                           M, N, K, mb, stream);
-        }
+        if (best >= 0)
+            return qs_launch_gemm_ring(MODE, OUTK, bmt, bwn, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M,
+                                       N, K, (mt_all + bmt - 1) / bmt, stream);
     }
     // many channels: LDS-shared activation tiles + LDS-DMA rings (gemm_w4a8_lds.hip); variant 2000 forces the
     // split-K kernel, 2001 forces the LDS kernel (A/B tests)
-    if (((units >= 256 && M > 16 && g_variant != 2000) || g_variant == 2001) && N % 128 == 0 && K >= 256)
+    if ((((units >= 256 && M > 16) || M >= 384) && g_variant != 2000 || g_variant == 2001) && N % 128 == 0 && K >= 256)
         return qs_launch_gemm_pair(MODE, OUTK, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,
                                    stream);
     int mtile = M <= 16 ? 1 : M <= 32 ? 2 : M <= 48 ? 3 : 4;

@@ -91,9 +91,16 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
     // weights are fetched from HBM once and re-served by that XCD's L2
     int nblk = blockIdx.x, mblk = 0;
     if (mblocks > 1) {
-        const int b = blockIdx.x, slot = b >> 3;
-        mblk = slot % mblocks;
-        nblk = (slot / mblocks) * 8 + (b & 7);
+        const int b = blockIdx.x, n8 = (N / (64 * WN)) & ~7;   // channel blocks covered by whole groups of 8 (one per XCD)
+        if (b < n8 * mblocks) {
+            const int slot = b >> 3;
+            mblk = slot % mblocks;
+            nblk = (slot / mblocks) * 8 + (b & 7);
+        } else {                                               // remainder (< 8 channel blocks): plain order
+            const int r = b - n8 * mblocks;
+            mblk = r % mblocks;
+            nblk = n8 + r / mblocks;
+        }
     }
     const int unit0 = nblk * WN;                      // first 64-channel unit of the workgroup
     const int m0 = mblk * (16 * MT);
@@ -379,7 +386,7 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
 }  // namespace
 
 // Entry used by the dispatcher in gemm_w4a8.hip.  mt = m-tiles per workgroup (1, 2, 4), wn = units per workgroup
-// (1, 2); preconditions (checked there): N % (64*wn) == 0, (K/64) % (2 * 8/wn) == 0, mblocks == 1 or (N/(64 wn)) % 8 == 0,
+// (1, 2); preconditions (checked there): N % (64*wn) == 0, (K/64) % (2 * 8/wn) == 0,
 // M*K and N*K/2 below 4 GiB.
 int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, const uint8_t* W, const int8_t* zeros,
                         const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,

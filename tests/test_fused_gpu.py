@@ -168,3 +168,24 @@ def test_prefill_batched_equals_per_sequence(gpu):
         for _ in range(3):
             big.step()
         assert torch.isfinite(big.hidden.float()).all()
+
+
+@pytest.mark.parametrize("tp_world", [2, 4, 8])
+def test_decode_engine_tp_rank_shapes_run(gpu, tp_world):
+    """One rank's shard of the tensor-parallel Llama-3-8B step (2 layers; all-reduce is a no-op without a process
+    group): every per-rank kernel shape the N>1 bench issues -- H/tp query heads over Hkv/tp KV heads, K-split o/down
+    -- runs eagerly and under hipGraph capture, fused pairs == op-by-op, real prefill included."""
+    from qserve_amd.decode import LLAMA3_8B, DecodeEngine
+    cfg = dict(LLAMA3_8B, layers=2)
+    outs = []
+    for fuse in (False, True):
+        eng = DecodeEngine(cfg, batch=8, prompt_len=96, max_new=8, device="cuda:0", seed=11, tp_rank=tp_world - 1,
+                           tp_world=tp_world, fuse_pairs=fuse)
+        eng.prefill(96)
+        eng.step()
+        eng.capture()
+        eng.run()
+        torch.cuda.synchronize()
+        assert torch.isfinite(eng.hidden.float()).all()
+        outs.append((eng.hidden.clone(), eng.tokens.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -190,6 +190,38 @@ def test_full_size_llama_shapes_exact_on_device(gpu, M, N, K):
     assert torch.equal(acc.to(torch.int64).sum(0), col)
 
 
+# per-rank shard shapes of the tensor-parallel path (qserve_amd/tp.py): Llama-3-8B at TP=2/4/8 and configs[3]
+# (Qwen1.5-72B TP=8): column-parallel qkv / gate_up (N split), row-parallel o / down (K split)
+TP_SHARDS = [(3072, 4096), (4096, 2048), (14336, 4096), (4096, 7168),        # llama3-8b tp2
+             (1536, 4096), (4096, 1024), (7168, 4096), (4096, 3584),         # tp4
+             (768, 4096), (4096, 512), (3584, 4096), (4096, 1792),           # tp8
+             (3072, 8192), (8192, 1024), (6144, 8192), (8192, 3072)]         # qwen1.5-72b tp8
+
+
+@pytest.mark.parametrize("N,K", TP_SHARDS)
+@pytest.mark.parametrize("M", [64, 37, 512])
+def test_tp_shard_shapes_exact(gpu, M, N, K):
+    """Every per-rank GEMM shape the N>1 bench issues: INT32 accumulator exact vs a device integer matmul, fp16 output
+    bit-exact vs the oracle epilogue applied to that (verified) accumulator."""
+    import qserve_backend.qgemm_w4a8_per_chn as op
+    g = torch.Generator(device=gpu).manual_seed(N * 3 + K + M)
+    W = torch.randint(-128, 128, (N, K // 2), dtype=torch.int8, device=gpu, generator=g)
+    A = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=gpu, generator=g)
+    acc = torch.empty((M, N), dtype=torch.int32, device=gpu)
+    op.gemm_forward_acc(A, W, acc)
+    ref = int_matmul_torch(A, unpack_qweight_torch(W))
+    assert torch.equal(acc.to(torch.int64), ref)
+    r = np.random.default_rng(N + K)
+    ws = r.uniform(0.001, 0.01, N).astype(np.float16)
+    wz = r.uniform(-0.05, 0.05, N).astype(np.float16)
+    sa = r.uniform(0.005, 0.05, M).astype(np.float16)
+    ss = r.uniform(-20, 20, M).astype(np.float16)
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+    op.gemm_forward_cuda(A, W, dev(ws), dev(sa), dev(wz), dev(ss), out)
+    out_ref = w4a8.epilogue_per_chn(acc.cpu().numpy(), ws, sa, wz, ss)
+    assert ulp_diff_f16(out.cpu().numpy(), out_ref).max() == 0
+
+
 def test_config1_4096_cubed_per_channel(gpu):
     """configs[0] of BASELINE.json (the reference's CPU-runnable case) on the GPU, exact."""
     import qserve_backend.qgemm_w4a8_per_chn as op
