@@ -12,6 +12,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench  # noqa: E402
 import qserve_backend.qgemm_w4a8_per_chn as op  # noqa: E402
+import qserve_backend.qgemm_w4a8_per_group as opg  # noqa: E402
 from qserve_amd import _lib  # noqa: E402
 
 VARIANTS = [-1, 4141, 4142, 4121, 4122, 4111, 3002, 3001, 2001, 4000]
@@ -38,12 +39,22 @@ def main():
         sa = torch.rand(M, device="cuda").half() * 0.01
         ss = torch.rand(M, device="cuda").half()
         out = torch.empty((M, N), dtype=torch.float16, device="cuda")
+        group = os.environ.get("MODE", "chn") == "group"       # MODE=group: per-group (g128) kernels
+        if group:
+            Z = torch.randint(0, 16, (K // 128, N), dtype=torch.int8, device="cuda", generator=g)
+            S = torch.randint(1, 8, (K // 128, N), dtype=torch.int8, device="cuda", generator=g)
+            Z = (-Z * S).to(torch.int8)
+
+        def run(i):
+            if group:
+                opg.gemm_forward_cuda(A, Ws[i % nl], Z, S, ws, sa, out)
+            else:
+                op.gemm_forward_cuda(A, Ws[i % nl], ws, sa, wz, ss, out)
         res = {}
         for v in VARIANTS:
             _lib.lib.qs_set_gemm_variant(v)
             try:
-                res[v] = bench.time_kernel(lambda i: op.gemm_forward_cuda(A, Ws[i % nl], ws, sa, wz, ss, out), 2 * nl,
-                                           torch)
+                res[v] = bench.time_kernel(run, 2 * nl, torch)
             except RuntimeError:
                 res[v] = None
                 torch.cuda.synchronize()
