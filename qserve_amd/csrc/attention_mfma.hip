@@ -107,11 +107,21 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hkv = blockIdx.x, b = blockIdx.y;
-    const int tl = (lengths ? lengths[b] : timestep) - 1;
-    if (tl < 0) return;
     const int64_t* ktab = kv_pointers + (size_t)b * 2 * max_blocks;
     const int64_t* vtab = ktab + max_blocks;
+    // first-round page addresses are requested together with the length (they do not depend on it when this workgroup
+    // starts at page 0): one memory round trip less on the launch -> first bytes chain
+    const bool spec = (nsplit == 1 || blockIdx.z == 0) && wave < max_blocks;
+    int64_t kpage0 = 0, vpage0 = 0;
+    if (spec) {
+        kpage0 = ktab[wave];
+        vpage0 = vtab[wave];
+    }
+    const int tl = (lengths ? lengths[b] : timestep) - 1;
+    if (tl < 0) return;
     const float inv_sqrt = 0.08838834764831845f;
+    const float qk_scale = inv_sqrt * 1.4426950408889634f;   // scores live in the log2 domain: exp2 everywhere
+    constexpr bool COMPACT = (G <= 4);                         // softmax on compacted lanes (see the page loop)
     const int li = lane & 15, tg = lane >> 4;
     uint8_t* const s_kw = s_kv + wave * (PAGE_TOK * DHB);                // this wave's K page buffer
     uint8_t* const s_vw = s_kv + (NW + wave) * (PAGE_TOK * DHB);         // this wave's V page buffer
@@ -151,8 +161,8 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         __builtin_amdgcn_global_load_lds((gptr_t)mb, (lptr_t)(&s_meta[wave][2][0]), 4, 0, 0);
     };
     if (p_begin + wave < p_end) {
-        dma_k(ktab[p_begin + wave]);
-        dma_v(vtab[p_begin + wave]);
+        dma_k(spec ? kpage0 : ktab[p_begin + wave]);
+        dma_v(spec ? vpage0 : vtab[p_begin + wave]);
     }
     for (int i = tid; i < 2 * MAXP; i += NW * 64) {
         const int pi = i >> 1;
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             for (int h = wave - 3; h < G; h += NW - 3) {
                 float d = (float)s_q[h][lane] * (float)s_knew[lane] + (float)s_q[h][64 + lane] * (float)s_knew[64 + lane];
                 d = wave_sum(d);
-                if (lane == 0) s_cur[h] = d * inv_sqrt;
+                if (lane == 0) s_cur[h] = d * qk_scale;
             }
         }
     }
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         float se = 0.f, so = 0.f;   // sums over lo-form / hi-form operand positions of this lane's 32 dims
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const h8 x = *reinterpret_cast<const h8*>(&s_qp[li][32 * tg + 8 * w]);
+            const h8 x = *reinterpret_cast<const h8*>(&s_qp[COMPACT ? (li & (G - 1)) : li][32 * tg + 8 * w]);
             se += (float)x[0] + (float)x[1] + (float)x[4] + (float)x[5];
             so += (float)x[2] + (float)x[3] + (float)x[6] + (float)x[7];
         }
@@ -245,7 +255,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     v4f acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = (v4f){0.f, 0.f, 0.f, 0.f};
-    float m_run = -3.0e38f, l_part = 0.f, corr = 0.f;
+    float m_run = -3.0e38f, l_part = 0.f, corr = 0.f, psum = 0.f;   // psum = sum of P' (removes the V operand offsets)
 
     for (int p = p_begin + wave; p < p_end; p += NW) {
         // K(p) landed?  Outstanding younger VMEM ops at this point: the 5 of V(p).
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         const lds_u8 ml = (lds_u8)(&s_meta[wave][0][0]) + 8 * tg_;
         const lds_u8 ql = (lds_u8)(&s_qp[0][0]) + (li_ * (DH * 2) + 64 * tg_);
         // ---------------- Q.K^T : 4 tiles of 16 tokens ----------------
-        v4f sc[4];
+        v4f craw[4];   // craw[t][r] = raw dot (offsets already cancelled) of token 16t + 4tg + r with head li
         h8 qB[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) qB[w] = *(const __attribute__((address_space(3))) h8*)(ql + 16 * w);
@@ -282,93 +292,201 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
                                 and_or(xs, c_hi, c_magic)};
                 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a4), qB[w], c, 0, 0, 0);
             }
-            // c[r] = raw dot (+ offsets) of token 16t + 4tg + r with head li; undo offsets, apply scale / zero point
-            const h4 ks = *(const __attribute__((address_space(3))) h4*)(ml + 2 * (16 * t));
-            const h4 kz = *(const __attribute__((address_space(3))) h4*)(ml + 2 * (PAGE_TOK + 16 * t));
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                sc[t][r] = ((float)ks[r] * inv_sqrt) * (c[r] - (float)kz[r] * qsum);
+            craw[t] = c;
         }
-        if (!full) {
+        u32 pbv[2][4];   // P'^T operands (B of P.V) of the two half pages
+        float m_new;
+        float scc[4];    // COMPACT: this lane's 4 scores
+        v4f scf[4];      // otherwise: 16 scores of head li
+        if constexpr (COMPACT) {
+            // Only the columns li < G of the 16x16 results are real heads.  Instead of running the softmax on 16
+            // values per lane with 3/4 of the lanes idle, tile t' moves to the lanes li = G t' + h (DPP row_shr inside
+            // the 16-lane row): every lane li < 4G then owns 4 scores of head h = li % G, tokens 16t' + 4tg + r.
+            const int tq_raw = li_ / G;                   // tile owned by this lane; lanes li >= 4G stay idle (G < 4)
+            const bool lane_ok = G == 4 || tq_raw < 4;
+            const int tq = G == 4 ? tq_raw : min(tq_raw, 3);
+            float (&sc)[4] = scc;
+            const h4 ks = *(const __attribute__((address_space(3))) h4*)(ml + 32 * tq);
+            const h4 kz = *(const __attribute__((address_space(3))) h4*)(ml + 2 * PAGE_TOK + 32 * tq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // (scalar copies first: __builtin_bit_cast of a vector-element lvalue reads element 0)
+                const float c0 = craw[0][r], c1 = craw[1][r], c2 = craw[2][r], c3 = craw[3][r];
+                int x = __builtin_bit_cast(int, c0);
+                if constexpr (G == 4) {   // whole 4-lane banks move: bank-masked DPP writes
+                    x = __builtin_amdgcn_update_dpp(x, __builtin_bit_cast(int, c1), 0x114, 0xF, 0x2, false);
+                    x = __builtin_amdgcn_update_dpp(x, __builtin_bit_cast(int, c2), 0x118, 0xF, 0x4, false);
+                    x = __builtin_amdgcn_update_dpp(x, __builtin_bit_cast(int, c3), 0x11C, 0xF, 0x8, false);
+                } else {
+                    const int s1 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c1), 0x110 + G, 0xF, 0xF, true);
+                    const int s2 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c2), 0x110 + 2 * G, 0xF, 0xF, true);
+                    const int s3 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c3), 0x110 + 3 * G, 0xF, 0xF, true);
+                    x = tq_raw == 1 ? s1 : x;
+                    x = tq_raw == 2 ? s2 : x;
+                    x = tq_raw == 3 ? s3 : x;
+                }
+                sc[r] = ((float)ks[r] * qk_scale) * (__builtin_bit_cast(float, x) - (float)kz[r] * qsum);
+                if (!lane_ok) sc[r] = -3.0e38f;
+            }
+            if (!full) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * tq + 4 * tg_ + r >= valid) sc[r] = -3.0e38f;   // also discards NaN from garbage scales
+            }
+            // K buffer consumed -> request K(p+NW)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (more) dma_k(page_addr(0, p + NW));
+            float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+            if constexpr (G == 4) {
+                mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx),
+                                                                                     0x124, 0xF, 0xF, true)));   // row_ror:4
+                mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx),
+                                                                                     0x128, 0xF, 0xF, true)));   // row_ror:8
+            } else {
+                mx = fmaxf(mx, __shfl_xor(mx, G, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 2 * G, 64));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            if (__any(alpha != 1.0f)) {
+                l_part *= alpha;
+                corr *= alpha;
+                psum *= alpha;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] *= alpha;
+            }
+        } else {
+            v4f (&sc)[4] = scf;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                // undo offsets, apply scale / zero point
+                const h4 ks = *(const __attribute__((address_space(3))) h4*)(ml + 2 * (16 * t));
+                const h4 kz = *(const __attribute__((address_space(3))) h4*)(ml + 2 * (PAGE_TOK + 16 * t));
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sc[t][r] = ((float)ks[r] * qk_scale) * (craw[t][r] - (float)kz[r] * qsum);
+            }
+            if (!full) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * t + 4 * tg_ + r >= valid) sc[t][r] = -3.0e38f;   // also discards NaN from garbage scales
+            }
+            // K buffer consumed -> request K(p+NW)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (more) dma_k(page_addr(0, p + NW));
+            // online softmax (per head = per li; the 4 tg lanes of a head hold 16 tokens each)
+            float mx = sc[0][0];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (16 * t + 4 * tg_ + r >= valid) sc[t][r] = -3.0e38f;   // also discards NaN from garbage scales
-        }
-        // K buffer consumed -> request K(p+NW)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (more) dma_k(page_addr(0, p + NW));
-        // ---------------- online softmax (per head = per li; the 4 tg lanes of a head hold 16 tokens each) ---------
-        float mx = sc[0][0];
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            if (__any(alpha != 1.0f)) {
+                l_part *= alpha;
+                corr *= alpha;
+                psum *= alpha;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
-        m_run = m_new;
-        if (__any(alpha != 1.0f)) {
-            l_part *= alpha;
-            corr *= alpha;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] *= alpha;
+                for (int e = 0; e < 8; ++e) acc[e] *= alpha;
+            }
         }
         if (more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // V(p) landed (K(p+NW) may still be in flight)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // ---------------- P.V : two half pages of 32 tokens ----------------
+        if constexpr (COMPACT) {
+            const int tq_raw = li_ / G;
+            const bool lane_ok = G == 4 || tq_raw < 4;
+            const int tq = G == 4 ? tq_raw : min(tq_raw, 3);
+            float (&sc)[4] = scc;
+            const h4 vs = *(const __attribute__((address_space(3))) h4*)(ml + 4 * PAGE_TOK + 32 * tq);
+            const h4 vz = *(const __attribute__((address_space(3))) h4*)(ml + 6 * PAGE_TOK + 32 * tq);
+            float pp[4];
 #pragma unroll
-        for (int hp = 0; hp < 2; ++hp) {
-            u32 pb[4];
+            for (int r = 0; r < 4; ++r) {
+                const float pe = __builtin_amdgcn_exp2f(sc[r] - m_new);   // 0 for masked tokens
+                l_part += pe;
+                // P' = p * v-scale rounded to fp16 for the MFMA; the zero-point term uses the SAME rounded value
+                float ps = (float)(_Float16)(pe * (float)vs[r]);
+                float pz = ps * (float)vz[r];
+                if ((!full && 16 * tq + 4 * tg_ + r >= valid) || !lane_ok) {   // garbage (possibly NaN) scales of unused slots
+                    ps = 0.f;
+                    pz = 0.f;
+                }
+                corr += pz;
+                psum += ps;
+                pp[r] = ps;
+            }
+            const int pk0 = (int)pack_h2(pp[0], pp[1]), pk1 = (int)pack_h2(pp[2], pp[3]);
+            // B operand of P.V for lane (head li < G, kg = tg): tokens 16t + 4tg + r of tiles t = 2hp, 2hp + 1 - they sit
+            // in the lanes li + G t of the same row (row_shl; lanes >= 4 receive other heads' values or zeros: their
+            // output columns are never read)
+            pbv[0][0] = (u32)pk0;
+            pbv[0][1] = (u32)pk1;
+            pbv[0][2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + G, 0xF, 0xF, true);
+            pbv[0][3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + G, 0xF, 0xF, true);
+            pbv[1][0] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + 2 * G, 0xF, 0xF, true);
+            pbv[1][1] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 2 * G, 0xF, 0xF, true);
+            pbv[1][2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + 3 * G, 0xF, 0xF, true);
+            pbv[1][3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 3 * G, 0xF, 0xF, true);
+        } else {
+            v4f (&sc)[4] = scf;
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int t = 2 * hp + tt;
+            for (int t = 0; t < 4; ++t) {
                 const h4 vs = *(const __attribute__((address_space(3))) h4*)(ml + 2 * (2 * PAGE_TOK + 16 * t));
                 const h4 vz = *(const __attribute__((address_space(3))) h4*)(ml + 2 * (3 * PAGE_TOK + 16 * t));
                 float pp[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pe = __expf(sc[t][r] - m_new);          // 0 for masked tokens
+                    const float pe = __builtin_amdgcn_exp2f(sc[t][r] - m_new);   // 0 for masked tokens
                     l_part += pe;
-                    // P' = p * v-scale rounded to fp16 for the MFMA; the zero-point term uses the SAME rounded value
                     float ps = (float)(_Float16)(pe * (float)vs[r]);
                     float pz = ps * (float)vz[r];
-                    if (!full && 16 * t + 4 * tg_ + r >= valid) {        // garbage (possibly NaN) scales of unused slots
+                    if (!full && 16 * t + 4 * tg_ + r >= valid) {
                         ps = 0.f;
                         pz = 0.f;
                     }
                     corr += pz;
+                    psum += ps;
                     pp[r] = ps;
                 }
-                pb[2 * tt] = pack_h2(pp[0], pp[1]);
-                pb[2 * tt + 1] = pack_h2(pp[2], pp[3]);
+                pbv[t >> 1][2 * (t & 1)] = pack_h2(pp[0], pp[1]);
+                pbv[t >> 1][2 * (t & 1) + 1] = pack_h2(pp[2], pp[3]);
             }
-            const h8 pB = __builtin_bit_cast(h8, (v4u){pb[0], pb[1], pb[2], pb[3]});
+        }
+        // ---------------- P.V : two half pages of 32 tokens ----------------
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+            const h8 pB = __builtin_bit_cast(h8, (v4u){pbv[hp][0], pbv[hp][1], pbv[hp][2], pbv[hp][3]});
             u32 raw[8];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
                 raw[jj] = *(const __attribute__((address_space(3))) u32*)(vl + (16 * (2 * hp + (jj >> 2)) + (jj & 3)) * DHB);
             }
 
-            const h2 k1024 = {(_Float16)1024.f, (_Float16)1024.f};
-            const h2 k16 = {(_Float16)0.0625f, (_Float16)0.0625f};
-            const h2 km64 = {(_Float16)-64.f, (_Float16)-64.f};
+            // V operands stay in offset form (1024 + n for low nibbles, 1024 + 16 n for high ones, fed with P'/16): the
+            // offsets add 1024 * sum(P') resp. 64 * sum(P') to the accumulators, removed once at the end (psum)
+            const _Float16 s16 = (_Float16)0.0625f;
+            const h8 pB16 = pB * (h8){s16, s16, s16, s16, s16, s16, s16, s16};
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) {
                 u32 lo[4], hi[4];
 #pragma unroll
                 for (int pq = 0; pq < 4; ++pq) {
                     const u32 W = __builtin_amdgcn_perm(raw[2 * pq + 1], raw[2 * pq], 0x0c000c00u | bb | ((4u + bb) << 16));
-                    lo[pq] = __builtin_bit_cast(u32, __builtin_bit_cast(h2, and_or(W, c_lo, c_magic)) - k1024);
-                    hi[pq] = __builtin_bit_cast(
-                        u32, __builtin_elementwise_fma(__builtin_bit_cast(h2, and_or(W, c_hi, c_magic)), k16, km64));
+                    lo[pq] = and_or(W, c_lo, c_magic);
+                    hi[pq] = and_or(W, c_hi, c_magic);
                 }
                 const h8 a_lo = __builtin_bit_cast(h8, (v4u){lo[0], lo[1], lo[2], lo[3]});
                 const h8 a_hi = __builtin_bit_cast(h8, (v4u){hi[0], hi[1], hi[2], hi[3]});
                 acc[2 * bb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, pB, acc[2 * bb], 0, 0, 0);
-                acc[2 * bb + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, pB, acc[2 * bb + 1], 0, 0, 0);
+                acc[2 * bb + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, pB16, acc[2 * bb + 1], 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0) ; QS_LOOP_END" ::: "memory");
@@ -376,10 +494,20 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     }
 
     // ---- per-wave partials -> LDS.  Lane (head li, tg) holds out dims 8*(4tg + r) + e in acc[e][r] ---------------
+    if constexpr (COMPACT) {   // the head's tokens were spread over the lanes li = 4t' + h as well
+        l_part += __shfl_xor(l_part, G, 64);
+        l_part += __shfl_xor(l_part, 2 * G, 64);
+        corr += __shfl_xor(corr, G, 64);
+        corr += __shfl_xor(corr, 2 * G, 64);
+        psum += __shfl_xor(psum, G, 64);
+        psum += __shfl_xor(psum, 2 * G, 64);
+    }
     l_part += __shfl_xor(l_part, 16, 64);
     l_part += __shfl_xor(l_part, 32, 64);
     corr += __shfl_xor(corr, 16, 64);
     corr += __shfl_xor(corr, 32, 64);
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
     __syncthreads();   // every wave is done with its page buffers: reuse s_k as the [NW][G][DH+4] fp32 merge area
     constexpr int OS = DH + 4;
     float (*s_o)[G][OS] = reinterpret_cast<float (*)[G][OS]>(&s_kv[0]);
@@ -388,7 +516,8 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s_o[wave][li][8 * (4 * tg + r) + e] = acc[e][r] - corr;
+            for (int r = 0; r < 4; ++r)
+                s_o[wave][li][8 * (4 * tg + r) + e] = acc[e][r] - (corr + ((e & 1) ? 64.f : 1024.f) * psum);
         if (tg == 0) {
             s_m[wave][li] = m_run;
             s_l[wave][li] = l_part;
@@ -400,11 +529,11 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         float M = z == 0 ? s_cur[h] : -3.0e38f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) M = fmaxf(M, s_m[w][h]);
-        const float pc = z == 0 ? __expf(s_cur[h] - M) : 0.f;      // the new token's own term (split 0 only)
+        const float pc = z == 0 ? __builtin_amdgcn_exp2f(s_cur[h] - M) : 0.f;      // the new token's own term (split 0 only)
         float num = pc * (float)vb[d], den = pc;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            const float f = __expf(s_m[w][h] - M);
+            const float f = __builtin_amdgcn_exp2f(s_m[w][h] - M);
             num += f * s_o[w][h][d];
             den += f * s_l[w][h];
         }
@@ -414,7 +543,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             float* pw = ws + ((((size_t)b * num_kv_heads + hkv) * nsplit + z) * G + h) * (DH + 2);
             pw[d] = num;
             if (d == 0) {
-                pw[DH] = M;
+                pw[DH] = M * 0.6931471805599453f;   // the merge kernel works in natural-log units
                 pw[DH + 1] = den;
             }
         }

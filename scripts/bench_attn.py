@@ -37,7 +37,7 @@ dev = torch.device("cuda:0")
 B, H, Hkv = int(os.environ.get("B", "64")), 32, 8
 VARS = [int(x) for x in os.environ.get("VARS", "0,1").split(",")]   # 0 auto, 1 VALU, 100+n = n KV splits
 int4 = "--kv8" not in sys.argv
-NL = 8
+NL = int(os.environ.get("NL", "8"))   # KV pools rotated per launch (1 = Infinity-Cache-resident)
 LS = [int(x) for x in os.environ.get("LS", "1024,1280,1535,4096").split(",")]
 for L in LS:
     mb = (L + 63) // 64 + 1
