@@ -87,6 +87,17 @@ __device__ __forceinline__ u32 and_or(u32 x, u32 m, u32 c) {
     return (x & m) | c;
 }
 
+// butterfly exchange with an explicitly supplied lane id: __shfl_xor derives its own (loop-invariant) lane id, which the
+// register allocator then keeps alive - or spills - across the page loop
+__device__ __forceinline__ float xor_lane(float x, u32 lid, int mask) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)((lid ^ (u32)mask) << 2), __builtin_bit_cast(int, x)));
+}
+__device__ __forceinline__ u32 fresh_lane_id() {   // opaque to CSE: not shared with earlier derivations
+    u32 lid;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
+    return lid;
+}
+
 typedef __attribute__((address_space(3))) const uint8_t* lds_u8;   // 32-bit LDS address (keeps ds_read, not flat_load)
 
 template <int G>
@@ -343,11 +354,11 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
                 mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx),
                                                                                      0x128, 0xF, 0xF, true)));   // row_ror:8
             } else {
-                mx = fmaxf(mx, __shfl_xor(mx, G, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 2 * G, 64));
+                mx = fmaxf(mx, xor_lane(mx, lid, G));
+                mx = fmaxf(mx, xor_lane(mx, lid, 2 * G));
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = fmaxf(mx, xor_lane(mx, lid, 16));
+            mx = fmaxf(mx, xor_lane(mx, lid, 32));
             m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
@@ -385,8 +396,8 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = fmaxf(mx, xor_lane(mx, lid, 16));
+            mx = fmaxf(mx, xor_lane(mx, lid, 32));
             m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
@@ -494,37 +505,40 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     }
 
     // ---- per-wave partials -> LDS.  Lane (head li, tg) holds out dims 8*(4tg + r) + e in acc[e][r] ---------------
-    if constexpr (COMPACT) {   // the head's tokens were spread over the lanes li = 4t' + h as well
-        l_part += __shfl_xor(l_part, G, 64);
-        l_part += __shfl_xor(l_part, 2 * G, 64);
-        corr += __shfl_xor(corr, G, 64);
-        corr += __shfl_xor(corr, 2 * G, 64);
-        psum += __shfl_xor(psum, G, 64);
-        psum += __shfl_xor(psum, 2 * G, 64);
+    // (lane-derived values are re-derived here so that none of them has to survive the page loop in a register)
+    const u32 lid2 = fresh_lane_id();
+    const int li2 = lid2 & 15, tg2 = lid2 >> 4, tid2 = wave * 64 + (int)lid2;
+    if constexpr (COMPACT) {   // the head's tokens were spread over the lanes li = G t' + h as well
+        l_part += xor_lane(l_part, lid2, G);
+        l_part += xor_lane(l_part, lid2, 2 * G);
+        corr += xor_lane(corr, lid2, G);
+        corr += xor_lane(corr, lid2, 2 * G);
+        psum += xor_lane(psum, lid2, G);
+        psum += xor_lane(psum, lid2, 2 * G);
     }
-    l_part += __shfl_xor(l_part, 16, 64);
-    l_part += __shfl_xor(l_part, 32, 64);
-    corr += __shfl_xor(corr, 16, 64);
-    corr += __shfl_xor(corr, 32, 64);
-    psum += __shfl_xor(psum, 16, 64);
-    psum += __shfl_xor(psum, 32, 64);
+    l_part += xor_lane(l_part, lid2, 16);
+    l_part += xor_lane(l_part, lid2, 32);
+    corr += xor_lane(corr, lid2, 16);
+    corr += xor_lane(corr, lid2, 32);
+    psum += xor_lane(psum, lid2, 16);
+    psum += xor_lane(psum, lid2, 32);
     __syncthreads();   // every wave is done with its page buffers: reuse s_k as the [NW][G][DH+4] fp32 merge area
     constexpr int OS = DH + 4;
     float (*s_o)[G][OS] = reinterpret_cast<float (*)[G][OS]>(&s_kv[0]);
     static_assert(sizeof(float) * NW * G * OS <= sizeof(s_kv), "merge area must fit the page buffers");
-    if (li < G) {
+    if (li2 < G) {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                s_o[wave][li][8 * (4 * tg + r) + e] = acc[e][r] - (corr + ((e & 1) ? 64.f : 1024.f) * psum);
-        if (tg == 0) {
-            s_m[wave][li] = m_run;
-            s_l[wave][li] = l_part;
+                s_o[wave][li2][8 * (4 * tg2 + r) + e] = acc[e][r] - (corr + ((e & 1) ? 64.f : 1024.f) * psum);
+        if (tg2 == 0) {
+            s_m[wave][li2] = m_run;
+            s_l[wave][li2] = l_part;
         }
     }
     __syncthreads();
-    for (int o = tid; o < G * DH; o += NW * 64) {
+    for (int o = tid2; o < G * DH; o += NW * 64) {
         const int h = o / DH, d = o % DH;
         float M = z == 0 ? s_cur[h] : -3.0e38f;
 #pragma unroll
