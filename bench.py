@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-prefill", action="store_true", help="skip the prompt-phase measurement")
     ap.add_argument("--op-by-op", action="store_true",
                     help="issue the reference's ops one by one (no fused pairs) in the timed step")
+    ap.add_argument("--tp-full-graph", action="store_true",
+                    help="N>1: capture the all-reduces into the step's hipGraph as well (default: one graph per segment "
+                         "between the collectives, collectives issued eagerly - independent of capture support in RCCL)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1 (tensor parallel): weak = --batch sequences PER GPU (global batch = batch x N, so every "
                          "rank keeps N=1's GEMM MACs and KV bytes); strong = --batch is the global batch")
@@ -166,14 +169,18 @@ def main():
     per_gpu_batch = args.batch
     if world > 1 and args.scaling == "weak":
         args.batch *= world          # global batch; the TP shards (heads / N / K splits) divide the work back
+    # functional runs of the N > 1 flow on a single-GPU box (tests/test_bench_tp_gpu.py): QS_DIST_BACKEND=gloo (gloo
+    # all-reduces CUDA tensors through the host) and QS_DIST_DEVICE=0 (every rank on cuda:0).  Never set by the driver.
+    backend = os.environ.get("QS_DIST_BACKEND", "nccl")
+    dev_index = int(os.environ["QS_DIST_DEVICE"]) if "QS_DIST_DEVICE" in os.environ else (local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device(f"cuda:{local_rank}"))
-    else:
-        torch.cuda.set_device(0)
-    dev = f"cuda:{local_rank if world > 1 else 0}"
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{dev_index}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    dev = f"cuda:{dev_index}"
 
     from qserve_amd import build
     if rank == 0:
@@ -189,13 +196,24 @@ def main():
     graphed = False
     if not args.no_graph:
         try:
-            eng.capture()
+            eng.capture(piecewise=False if args.tp_full_graph else None)
             graphed = True
-        except Exception as e:   # e.g. RCCL refusing capture: fall back to eager launches
+        except Exception as e:   # e.g. a collective refusing capture: fall back to eager launches
             if rank == 0:
-                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {str(e).splitlines()[0]}); running eagerly",
+                      file=sys.stderr)
             eng.graph = None
-            eng.lengths.fill_(args.prompt_len + 1)
+            eng.pieces = None
+            # the invalidated capture leaves a stale HIP error behind that the next checked call would re-raise:
+            # drain it (measured with the gloo functional run, tests/test_bench_tp_gpu.py) before touching the engine
+            for _ in range(4):
+                try:
+                    torch.cuda.synchronize()
+                    eng.lengths.fill_(args.prompt_len + 1)
+                    torch.cuda.synchronize()
+                    break
+                except Exception:
+                    continue
     steps2 = 0 if args.op_by_op else min(args.steps, 32)      # secondary timing of the op-by-op sequence
     assert args.warmup + args.steps + steps2 + 8 <= args.max_new, "steps exceed the page budget (prompt_len + max_new)"
 
@@ -311,7 +329,9 @@ def main():
                                    f"{f' ({per_gpu_batch} per GPU x tp{world})' if world > 1 else ''}, context "
                                    f"{args.prompt_len}->+{args.max_new} (BASELINE.json configs[1])",
                        "global_batch": args.batch, "context_start": args.prompt_len + 1 + args.warmup,
-                       "parallelism": f"tp{world}", "hipgraph": graphed, "layers": cfg["layers"],
+                       "parallelism": f"tp{world}",
+                       "hipgraph": ("piecewise (collectives issued eagerly between the pieces)"
+                                    if graphed and world > 1 and not args.tp_full_graph else graphed), "layers": cfg["layers"],
                        "op_sequence": "reference ops one by one" if args.op_by_op else
                        "reference ops; (residual add, layer norm) and (silu_and_mul, quant) issued as bit-identical "
                        "fused pairs (qserve_amd/fused.py)",

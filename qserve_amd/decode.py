@@ -132,6 +132,7 @@ class DecodeEngine:
         self.lengths = torch.full((B,), prompt_len, dtype=torch.int32, device=self.dev)   # context incl. new token
         self.tokens = torch.randint(0, cfg["vocab"], (B,), device=self.dev, generator=gen)
         self.graph = None
+        self.pieces = None
 
     # ---- fill the cache for positions [0, prompt_len) through the prefill writer (random K/V source) ----------
     def prefill_cache(self, prompt_len, chunk=8):
@@ -234,7 +235,10 @@ class DecodeEngine:
         self.lengths.fill_(prompt_len + 1)
 
     # ---- one decode step (llama_w4a8_unpad.py:330-361 per layer) --------------------------------------------
-    def step(self):
+    def _segments(self):
+        """The step as a generator: yields the row-parallel partial output wherever tensor parallelism needs its sum
+        all-reduce (2 per layer), so that the caller decides how the collective is issued (eagerly between hipGraph
+        pieces, inside one graph, or not at all at world size 1)."""
         cfg, B = self.cfg, self.B
         fuse_sum = self.group_size == -1
         if self.with_lm_head:
@@ -273,7 +277,8 @@ class DecodeEngine:
             else:
                 fused_kernels.invoke_quant(qo, attn, self.q_scale)
             L["o"](qo, self.q_scale, self.q_sum, self.proj_out)
-            tpmod.all_reduce_sum_(self.proj_out)
+            if self.tp_world > 1:
+                yield self.proj_out
             add_norm_quant(h, self.proj_out, L["ln2"])
             L["gate_up"](qa, self.q_scale, self.q_sum, self.gate_up_buf)
             if fuse:
@@ -285,7 +290,8 @@ class DecodeEngine:
                 else:
                     fused_kernels.invoke_quant(self.q_mlp, self.mlp_act, self.q_scale)
             L["down"](self.q_mlp, self.q_scale, self.q_sum, self.proj_out)
-            tpmod.all_reduce_sum_(self.proj_out)
+            if self.tp_world > 1:
+                yield self.proj_out
             if li + 1 < nl:
                 add_norm_quant(h, self.proj_out, self.layers[li + 1]["ln1"])   # next layer's input norm
             else:
@@ -296,22 +302,58 @@ class DecodeEngine:
             torch.argmax(logits, dim=-1, out=self.tokens)            # greedy sampler
         self.lengths.add_(1)
 
-    def capture(self):
-        """Capture one step in a hipGraph (removes ~400 launches of host overhead per step)."""
+
+    def step(self):
+        for partial in self._segments():
+            tpmod.all_reduce_sum_(partial)
+
+    def capture(self, piecewise=None):
+        """Capture one step in hipGraph(s) (removes ~400 launches of host overhead per step).
+
+        World size 1: one graph.  Tensor parallel (default `piecewise`): one graph per segment between the all-reduces,
+        the collectives themselves are issued eagerly between the replays - nothing depends on the communication
+        library supporting stream capture, and the host only issues ~2 calls per layer and rank.
+        `piecewise=False` captures the collectives too (needs a capturable backend)."""
+        if piecewise is None:
+            piecewise = self.tp_world > 1
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             self.step()                       # warm-up outside capture (allocator, lazy init)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.step()
-        self.graph = g
-        return g
+        self.pieces = None
+        if not piecewise:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.step()
+            self.graph = g
+            return g
+        pool = torch.cuda.graph_pool_handle()
+        pieces, gen = [], self._segments()
+        while True:
+            g = torch.cuda.CUDAGraph()
+            partial = None
+            with torch.cuda.graph(g, pool=pool):
+                try:
+                    partial = next(gen)
+                except StopIteration:
+                    pass
+            pieces.append((g, partial))
+            if partial is None:
+                break
+            tpmod.all_reduce_sum_(partial)    # keeps the data flow of the capture pass identical to a real step
+        self.pieces = pieces
+        self.graph = None
+        return pieces
 
     def run(self):
-        if self.graph is not None:
+        if getattr(self, "pieces", None):
+            for g, partial in self.pieces:
+                g.replay()
+                if partial is not None:
+                    tpmod.all_reduce_sum_(partial)
+        elif self.graph is not None:
             self.graph.replay()
         else:
             self.step()

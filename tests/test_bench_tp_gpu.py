@@ -1,0 +1,38 @@
+"""The N > 1 flow of bench.py (process group, tensor-parallel engine, all-reduces, max-over-ranks timing, one JSON line)
+executed for real on a single-GPU box: two ranks share cuda:0 and talk gloo (QS_DIST_BACKEND / QS_DIST_DEVICE, see
+bench.py).  Functional only - the numbers mean nothing."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, port):
+    env = dict(os.environ, QS_DIST_BACKEND="gloo", QS_DIST_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--model", "tiny",
+           "--batch", "4", "--prompt-len", "96", "--max-new", "48", "--steps", "4", "--warmup", "2", "--no-prefill"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0]), r.stderr
+
+
+def test_bench_two_ranks_eager(gpu):
+    out, _ = _run(["--no-graph"], 29541)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 8
+    assert out["config"]["parallelism"] == "tp2" and out["value"] > 0 and out["config"]["hipgraph"] is False
+
+
+def test_bench_two_ranks_piecewise_graphs(gpu):
+    """Default N > 1 mode: one hipGraph per segment between the all-reduces, the collectives issued eagerly - works with
+    any backend (here gloo, which could never be captured)."""
+    out, err = _run([], 29542)
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert str(out["config"]["hipgraph"]).startswith("piecewise"), err[-2000:]
