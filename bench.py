@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-prefill", action="store_true", help="skip the prompt-phase measurement")
     ap.add_argument("--op-by-op", action="store_true",
                     help="issue the reference's ops one by one (no fused pairs) in the timed step")
+    ap.add_argument("--gemm-variant", type=int, default=-1, help="A/B: qs_set_gemm_variant code (include/qserve_amd.h)")
     ap.add_argument("--tp-full-graph", action="store_true",
                     help="N>1: capture the all-reduces into the step's hipGraph as well (default: one graph per segment "
                          "between the collectives, collectives issued eagerly - independent of capture support in RCCL)")
@@ -188,6 +189,9 @@ def main():
     if world > 1:
         dist.barrier()
     from qserve_amd import decode as D
+    if args.gemm_variant != -1:
+        from qserve_amd import _lib
+        _lib.lib.qs_set_gemm_variant(args.gemm_variant)
     cfg = {"llama3-8b": D.LLAMA3_8B, "qwen1.5-72b": D.QWEN15_72B, "tiny": D.TINY}[args.model]
     eng = D.DecodeEngine(cfg, args.batch, args.prompt_len, args.max_new, group_size=args.group_size,
                          int4_kv=not args.kv8, device=dev, tp_rank=rank, tp_world=world,

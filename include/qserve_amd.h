@@ -16,7 +16,9 @@
  *     a positive hipError_t if the launch failed.  qs_last_error() returns a thread-local message;
  *   - callers own every tensor buffer (ownership rules of the reference, SURVEY.md 8(b) "Conventions"); the library
  *     keeps three small device scratch areas of its own (RoPE cos/sin table, split-KV partials, split-K slabs),
- *     allocated lazily on a first eager call and never while the stream is being captured into a graph.
+ *     allocated lazily on a first eager call and never while the stream is being captured into a graph.  The scratch
+ *     areas are per device: launches that use them (split-KV attention, K-sliced GEMMs) must not run concurrently on
+ *     different streams of one device (the reference's engine is single-stream).
  */
 #ifndef QSERVE_AMD_H
 #define QSERVE_AMD_H
@@ -78,7 +80,8 @@ int qs_w8a8_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscal
  * variant except the 31xx timing experiments computes the same results:
  *   9xx / 1000 + 100*mtile + 10*S + NW ... split-K decode kernel geometries;  2000 / 2001 ... LDS-pair kernel off / forced;
  *   3000 ... tiled (prefill) kernel off, 3001 / 3002 ... forced with the 256- / 128-token tile;
- *   4000 ... ring (decode) kernel off, 4100 + 10*m_tiles + units ... forced ring geometry;
+ *   4000 ... ring (decode) kernel off, 4001 ... ring kernel without K slices,
+ *   4100 + 100*(k_slices-1) + 10*m_tiles + units ... forced ring geometry;
  *   3100 + bits ... TIMING EXPERIMENTS ONLY (kernel parts switched off, results are wrong by design). */
 void qs_set_gemm_variant(int variant);
 

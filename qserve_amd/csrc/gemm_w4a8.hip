@@ -308,11 +308,16 @@ struct Workspace {
 };
 Workspace g_ws[16];
 
-Workspace* get_workspace() {
+Workspace* get_workspace(hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     Workspace& w = g_ws[dev];
     if (!w.tried) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return nullptr;                       // first use inside a capture: run un-split, allocate on a later eager call
+        }
         w.tried = true;
         const size_t slab_bytes = 48u << 20;
         const int ncnt = 1 << 16;
@@ -356,7 +361,7 @@ int launch_splitk(const int8_t* A, const uint8_t* W, const int8_t* zeros, const 
     int* slabs = nullptr;
     unsigned* counters = nullptr;
     if (S > 1) {
-        Workspace* ws = get_workspace();
+        Workspace* ws = get_workspace(stream);
         const size_t tiles = (size_t)grid.x * grid.y;
         const size_t need = tiles * S * (size_t)(MT * 4 * 64) * 16;
         if (ws && need <= ws->slab_bytes && tiles <= (size_t)ws->ncounters) {
@@ -380,7 +385,8 @@ int qs_launch_gemm_pair(int mode, int outk, const int8_t* A, const uint8_t* W, c
 // decode ring kernel (gemm_w4a8_ring.hip)
 int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, const uint8_t* W, const int8_t* zeros,
                         const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
-                        const void* assums, void* out, int M, int N, int K, int mblocks, hipStream_t stream);
+                        const void* assums, void* out, int M, int N, int K, int mblocks, int ksplit, int* slabs,
+                        unsigned* counters, hipStream_t stream);
 // compute-bound tiled kernel (gemm_w4a8_tiled.hip)
 int qs_launch_gemm_tiled(int mode, int outk, const int8_t* A, const uint8_t* W, const int8_t* zeros,
                          const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
@@ -427,14 +433,30 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
     }
     // decode shapes: LDS-DMA ring kernel with operands read one stage ahead (gemm_w4a8_ring.hip); variant 4000
     // disables it (A/B tests against the two older decode kernels below)
-    if (g_variant >= 4100 && g_variant < 4200) {       // tests: force geometry 4100 + 10*mt + wn (mt tiles, wn units)
-        const int mt = (g_variant - 4100) / 10, wn = (g_variant - 4100) % 10;
+    // K slices need the slab / counter workspace: tiles * ksplit * (mt KiB * 4) bytes, one counter per tile
+    auto ring_ws = [&](int mt, int mb, int ks, int** slabs, unsigned** counters) -> bool {
+        *slabs = nullptr;
+        *counters = nullptr;
+        if (ks <= 1) return true;
+        Workspace* ws = get_workspace(stream);
+        const size_t tiles = (size_t)units * mb;
+        if (!ws || tiles > (size_t)ws->ncounters || tiles * ks * mt * 4096 > ws->slab_bytes) return false;
+        *slabs = ws->slabs;
+        *counters = ws->counters;
+        return true;
+    };
+    if (g_variant >= 4100 && g_variant < 4500) {       // tests: force geometry 4100 + 100*(ksplit-1) + 10*mt + wn
+        const int v = g_variant - 4100, ks = v / 100 + 1, mt = (v % 100) / 10, wn = v % 10;
         const int mb = ((M + 15) / 16 + mt - 1) / mt;
         QS_REQUIRE((mt == 1 || mt == 2 || mt == 4) && (wn == 1 || wn == 2) && !(mt == 1 && wn == 2) &&
-                       N % (64 * wn) == 0 && (K / 64) % (16 / wn) == 0,
-                   "w4a8 gemm: forced ring geometry mt=%d wn=%d does not fit M=%d N=%d K=%d", mt, wn, M, N, K);
+                       N % (64 * wn) == 0 && (K / 64) % ks == 0 && (K / 64 / ks) % (16 / wn) == 0,
+                   "w4a8 gemm: forced ring geometry mt=%d wn=%d ksplit=%d does not fit M=%d N=%d K=%d", mt, wn, ks, M, N,
+                   K);
+        int* slabs = nullptr;
+        unsigned* counters = nullptr;
+        QS_REQUIRE(ring_ws(mt, mb, ks, &slabs, &counters), "w4a8 gemm: no split-K workspace for the forced geometry");
         return qs_launch_gemm_ring(MODE, OUTK, mt, wn, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N,
-                                   K, mb, stream);
+                                   K, mb, ks, slabs, counters, stream);
     }
     // Geometry choice (measured: scripts/bench_gemm.py for the Llama-3-8B shapes, scripts/bench_gemm_shard.py for the
     // tensor-parallel shard shapes): a workgroup of (16 mt tokens) x (64 wn channels) streams K (16 mt + 32 wn) bytes
@@ -445,18 +467,47 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         (size_t)M * K < (1ull << 32) && (size_t)N * K / 2 < (1ull << 32)) {
         const int mt_all = (M + 15) / 16;
         static const int geo[5][2] = {{4, 2}, {2, 2}, {4, 1}, {2, 1}, {1, 1}};
+        // K slices (ksplit 2 / 4, int32 partial tiles meeting in a workspace, last arriver finishes): fewer bytes per
+        // CU when neither tokens nor channels can be cut further, against the seam's cost; variant 4001
+        // keeps ksplit = 1 (A/B)
+        // seam cost in bytes of streaming, calibrated on scripts/bench_gemm_shard.py (VARIANTS=4001,-1): slab stores ->
+        // ticket -> slab loads (one batch for mt <= 2, one per slice for mt = 4); K-sliced streams are charged 10 % extra
+        auto seam = [](int ks, int mt) -> long {   // measured 3-7 us: three dependent system-scope round trips
+            if (ks <= 1) return 0;
+            return ((ks == 2 ? 150L : 250L) + (mt > 2 ? 74L * (ks - 2) : 0)) * 1024;
+        };
         long best = -1;
-        int bmt = 0, bwn = 0;
-        for (int i = 0; i < 5; ++i) {
-            const int mt = geo[i][0], wn = geo[i][1];
-            if (N % (64 * wn) != 0 || (K / 64) % (16 / wn) != 0) continue;
-            const long blocks = (long)((mt_all + mt - 1) / mt) * (N / (64 * wn));
-            const long cost = ((blocks + 255) / 256) * (16 * mt + 32 * wn);
-            if (best < 0 || cost < best) best = cost, bmt = mt, bwn = wn;
+        int bmt = 0, bwn = 0, bks = 1;
+        for (int ks = 1; ks <= (g_variant == 4001 ? 1 : 4); ks *= 2)
+            for (int i = 0; i < 5; ++i) {
+                const int mt = geo[i][0], wn = geo[i][1];
+                if (N % (64 * wn) != 0 || (K / 64) % ks != 0 || (K / 64 / ks) % (16 / wn) != 0) continue;
+                const int mb = (mt_all + mt - 1) / mt;
+                const long blocks = (long)mb * (N / (64 * wn)) * ks;
+                const long cost = ((blocks + 255) / 256) * (16 * mt + 32 * wn) * (long)(K / ks) * (ks > 1 ? 11 : 10) / 10 +
+                                  seam(ks, mt);
+                if (best < 0 || cost < best) best = cost, bmt = mt, bwn = wn, bks = ks;
+            }
+        if (best >= 0) {
+            int mb = (mt_all + bmt - 1) / bmt;
+            int* slabs = nullptr;
+            unsigned* counters = nullptr;
+            if (!ring_ws(bmt, mb, bks, &slabs, &counters)) {   // no workspace (e.g. first call inside a capture): best un-split
+                best = -1;
+                bks = 1;
+                for (int i = 0; i < 5; ++i) {
+                    const int mt = geo[i][0], wn = geo[i][1];
+                    if (N % (64 * wn) != 0 || (K / 64) % (16 / wn) != 0) continue;
+                    const long blocks = (long)((mt_all + mt - 1) / mt) * (N / (64 * wn));
+                    const long cost = ((blocks + 255) / 256) * (16 * mt + 32 * wn);
+                    if (best < 0 || cost < best) best = cost, bmt = mt, bwn = wn;
+                }
+                mb = (mt_all + bmt - 1) / bmt;
+            }
+            if (best >= 0)
+                return qs_launch_gemm_ring(MODE, OUTK, bmt, bwn, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out,
+                                           M, N, K, mb, bks, slabs, counters, stream);
         }
-        if (best >= 0)
-            return qs_launch_gemm_ring(MODE, OUTK, bmt, bwn, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M,
-                                       N, K, (mt_all + bmt - 1) / bmt, stream);
     }
     // many channels: LDS-shared activation tiles + LDS-DMA rings (gemm_w4a8_lds.hip); variant 2000 forces the
     // split-K kernel, 2001 forces the LDS kernel (A/B tests)

@@ -63,7 +63,8 @@ __device__ __forceinline__ void raw_barrier() {
 }
 
 // MT m-tiles (16 tokens each) per wave = tokens per workgroup / 16; WN units per workgroup; KG = 8 / WN K-groups.
-template <int MT, int WN, int MODE, int OUTK>
+// KSPLIT = false folds every K-slice path away (the un-split launches keep exactly their earlier code).
+template <int MT, int WN, int MODE, int OUTK, bool KSPLIT>
 __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restrict__ A, const uint8_t* __restrict__ W,
                                                          const int8_t* __restrict__ zeros,
                                                          const int8_t* __restrict__ scales8,
@@ -71,7 +72,9 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
                                                          const __half* __restrict__ ascales,
                                                          const __half* __restrict__ wszs,
                                                          const __half* __restrict__ assums, void* __restrict__ out,
-                                                         int M, int N, int K, int mblocks, int ns) {
+                                                         int M, int N, int K, int mblocks, int ns, int ksplit_arg,
+                                                         int* __restrict__ slabs, unsigned* __restrict__ counters) {
+    const int ksplit = KSPLIT ? ksplit_arg : 1;
     constexpr int KG = 8 / WN;
     constexpr int ASTAGE = 16 * MT * 64;              // activation bytes per stage (64 k)
     constexpr int WSTAGE = WN * 2048;                 // packed weight bytes per stage
@@ -89,23 +92,31 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
     const int tsel = li >> 3, c = li & 7;
     // workgroup -> (channel block, token block); token blocks of one channel block sit on ONE XCD (b % 8) so that the
     // weights are fetched from HBM once and re-served by that XCD's L2
-    int nblk = blockIdx.x, mblk = 0;
-    if (mblocks > 1) {
+    // K split (ksplit > 1): the K range is cut into ksplit slices handled by different workgroups (same XCD as well);
+    // the int32 partial tiles meet in a workspace, the last arriver finishes (see the seam below).
+    int nblk = blockIdx.x, mblk = 0, kq = 0;
+    const int per = mblocks * ksplit;                 // workgroups per channel block
+    if (per > 1) {
         const int b = blockIdx.x, n8 = (N / (64 * WN)) & ~7;   // channel blocks covered by whole groups of 8 (one per XCD)
-        if (b < n8 * mblocks) {
+        int sub;
+        if (b < n8 * per) {
             const int slot = b >> 3;
-            mblk = slot % mblocks;
-            nblk = (slot / mblocks) * 8 + (b & 7);
+            sub = slot % per;
+            nblk = (slot / per) * 8 + (b & 7);
         } else {                                               // remainder (< 8 channel blocks): plain order
-            const int r = b - n8 * mblocks;
-            mblk = r % mblocks;
-            nblk = n8 + r / mblocks;
+            const int r = b - n8 * per;
+            sub = r % per;
+            nblk = n8 + r / per;
         }
+        mblk = sub % mblocks;
+        kq = sub / mblocks;
     }
     const int unit0 = nblk * WN;                      // first 64-channel unit of the workgroup
     const int m0 = mblk * (16 * MT);
     const int KT = K >> 5;
-    const int nloc = (K >> 6) / KG;                   // stages per group (dispatcher: (K/64) % KG == 0)
+    const int nst = (K >> 6) / ksplit;                // 64-k stages of this workgroup's K slice
+    const int u0 = kq * nst;                          // first global stage
+    const int nloc = nst / KG;                        // stages per group (dispatcher: (K/64/ksplit) % (2 KG) == 0)
 
     uint8_t* const ring = smem + kg * ns * GSTAGE;    // this group's ring: slot s = [A | W | meta]
     const u32 ring_lds = (u32)(size_t)(lptr_t)ring;
@@ -141,7 +152,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
                      : "memory");
     };
     auto issue = [&](int i, int slot) {               // group-local stage i -> global stage u = i*KG + kg
-        const int u = i * KG + kg;
+        const int u = u0 + i * KG + kg;
         const u32 dst = ring_lds + slot * GSTAGE;
 #pragma unroll
         for (int j = 0; j < NPIECE / WN; ++j) {
@@ -308,6 +319,62 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     acc[mt][cl][r] += red[(((k2 * WN + wn) * NP + mt * 4 + cl) * 4 + r) * 64 + lane];
+    // ---- K-split seam (per wave = per 64-channel unit): partial tile -> slab, arrival ticket, the last arriver sums
+    // the other slices' slabs and goes on to the epilogue.  No fences: an agent-scope release / acquire writes back and
+    // invalidates the XCD's whole L2 under every other workgroup's feet (measured: +10 us); instead the slab traffic
+    // itself bypasses the caches (sc0 sc1 = system-scope write-through stores / cache-missing loads), the stores are
+    // acknowledged (vmcnt 0) before the ticket, and the ticket is a device-scope atomic.  The counter is reset by the
+    // last arriver (no host work between launches).
+    if (KSPLIT && ksplit > 1) {
+        const size_t tile = (size_t)(unit0 + wn) * mblocks + mblk;
+        v4i* const slab = reinterpret_cast<v4i*>(slabs) + tile * ksplit * (size_t)(NP * 64);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl) {
+                v4i* const dst = slab + ((size_t)kq * NP + mt * 4 + cl) * 64 + lane;
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(acc[mt][cl]) : "memory");
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket != (unsigned)(ksplit - 1)) return;
+        if (lane == 0) __hip_atomic_store(counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the other slices' slabs: all requested before ONE wait while they fit the register budget (mt <= 2, up to 3
+        // slices = 96 VGPRs), slice by slice otherwise - each wait is a full memory round trip
+        constexpr int ZB = MT <= 2 ? 3 : 1;            // slices per batch
+        for (int j0 = 0; j0 < ksplit - 1; j0 += ZB) {
+            v4i t[ZB][MT][4];
+#pragma unroll
+            for (int jb = 0; jb < ZB; ++jb) {
+                const int j = j0 + jb;
+                if (j < ksplit - 1) {
+                    int z = kq + 1 + j;
+                    z = z >= ksplit ? z - ksplit : z;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int cl = 0; cl < 4; ++cl) {
+                            const v4i* const src = slab + ((size_t)z * NP + mt * 4 + cl) * 64 + lane;
+                            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(t[jb][mt][cl]) : "v"(src) : "memory");
+                        }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int jb = 0; jb < ZB; ++jb)
+                if (j0 + jb < ksplit - 1) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int cl = 0; cl < 4; ++cl) {
+                            asm volatile("" : "+v"(t[jb][mt][cl]));   // the values exist only after the wait above
+                            acc[mt][cl] += t[jb][mt][cl];
+                        }
+                }
+        }
+    }
     if (OUTK == 1) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -349,17 +416,17 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
     }
 }
 
-template <int MT, int WN, int MODE, int OUTK>
+template <int MT, int WN, int MODE, int OUTK, bool KSPLIT>
 int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
                 const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K,
-                int mblocks, hipStream_t stream) {
-    auto kern = w4a8_gemm_ring<MT, WN, MODE, OUTK>;
+                int mblocks, int ksplit, int* slabs, unsigned* counters, hipStream_t stream) {
+    auto kern = w4a8_gemm_ring<MT, WN, MODE, OUTK, KSPLIT>;
     constexpr int KG = 8 / WN;
     constexpr int GSTAGE = 16 * MT * 64 + WN * 2048 + (MODE == 1 ? 256 : 0);
     // ring depth: as deep as 144 KiB of LDS allows (<= 6), never deeper than a group's stage count + 1
     int ns = (144 * 1024) / (KG * GSTAGE);
     if (ns > 6) ns = 6;
-    const int nloc = (K / 64) / KG;
+    const int nloc = (K / 64) / ksplit / KG;
     if (ns > nloc + 1) ns = nloc + 1;
     if (ns < 3) ns = 3;                                // the slot read ahead and the slot refilled must differ
     size_t smem = (size_t)KG * ns * GSTAGE;
@@ -375,25 +442,29 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
         }
         configured = 160 * 1024;
     }
-    dim3 grid((N / (64 * WN)) * mblocks);
+    dim3 grid((N / (64 * WN)) * mblocks * ksplit);
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, A, W, zeros, scales8,
                        reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
                        reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K,
-                       mblocks, ns);
+                       mblocks, ns, ksplit, slabs, counters);
     return qs_launch_status("w4a8 gemm (ring)");
 }
 
 }  // namespace
 
 // Entry used by the dispatcher in gemm_w4a8.hip.  mt = m-tiles per workgroup (1, 2, 4), wn = units per workgroup
-// (1, 2); preconditions (checked there): N % (64*wn) == 0, (K/64) % (2 * 8/wn) == 0,
+// (1, 2); ksplit = K slices (1 = none; > 1 needs the slab / counter workspace: (N/64) * mblocks * ksplit * mt KiB * 4 and
+// (N/64) * mblocks counters); preconditions (checked there): N % (64*wn) == 0, (K/64/ksplit) % (2 * 8/wn) == 0,
 // M*K and N*K/2 below 4 GiB.
 int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, const uint8_t* W, const int8_t* zeros,
                         const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
-                        const void* assums, void* out, int M, int N, int K, int mblocks, hipStream_t stream) {
-#define QS_R(MTV, WNV, MODEV, OUTV)                                                                              \
-    return launch_ring<MTV, WNV, MODEV, OUTV>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, \
-                                              mblocks, stream)
+                        const void* assums, void* out, int M, int N, int K, int mblocks, int ksplit, int* slabs,
+                        unsigned* counters, hipStream_t stream) {
+#define QS_R(MTV, WNV, MODEV, OUTV)                                                                                   \
+    return ksplit > 1 ? launch_ring<MTV, WNV, MODEV, OUTV, true>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, \
+                                                                 M, N, K, mblocks, ksplit, slabs, counters, stream)      \
+                      : launch_ring<MTV, WNV, MODEV, OUTV, false>(A, W, zeros, scales8, wscales, ascales, wszs, assums,  \
+                                                                  out, M, N, K, mblocks, 1, nullptr, nullptr, stream)
 #define QS_RM(MODEV, OUTV)                              \
     do {                                                \
         if (wn == 2) {                                  \

@@ -16,6 +16,8 @@ import qserve_backend.qgemm_w4a8_per_group as opg  # noqa: E402
 from qserve_amd import _lib  # noqa: E402
 
 VARIANTS = [-1, 4141, 4142, 4121, 4122, 4111, 3002, 3001, 2001, 4000]
+if os.environ.get("VARIANTS"):       # e.g. VARIANTS=-1,4001,4422 (4100 + 100*(ksplit-1) + 10*mt + wn; 4001 = no K slices)
+    VARIANTS = [int(x) for x in os.environ["VARIANTS"].split(",")]
 
 
 def shard_shapes():
