@@ -87,17 +87,6 @@ __device__ __forceinline__ u32 and_or(u32 x, u32 m, u32 c) {
     return (x & m) | c;
 }
 
-// butterfly exchange with an explicitly supplied lane id: __shfl_xor derives its own (loop-invariant) lane id, which the
-// register allocator then keeps alive - or spills - across the page loop
-__device__ __forceinline__ float xor_lane(float x, u32 lid, int mask) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)((lid ^ (u32)mask) << 2), __builtin_bit_cast(int, x)));
-}
-__device__ __forceinline__ u32 fresh_lane_id() {   // opaque to CSE: not shared with earlier derivations
-    u32 lid;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
-    return lid;
-}
-
 typedef __attribute__((address_space(3))) const uint8_t* lds_u8;   // 32-bit LDS address (keeps ds_read, not flat_load)
 
 template <int G>

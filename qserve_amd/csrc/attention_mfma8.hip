@@ -92,6 +92,8 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
     const int64_t* ktab = kv_pointers + (size_t)b * 2 * max_blocks;
     const int64_t* vtab = ktab + max_blocks;
     const float inv_sqrt = 0.08838834764831845f;
+    const float qk_scale = inv_sqrt * 1.4426950408889634f;   // scores live in the log2 domain: exp2 everywhere
+    constexpr bool COMPACT = (G <= 4);                         // softmax on compacted lanes (see the page loop)
     const int li = lane & 15, tg = lane >> 4;
     uint8_t* const s_kw = s_kv + wave * (PAGE_TOK * DHB);                // this wave's K page buffer
     uint8_t* const s_vw = s_kv + (NW + wave) * (PAGE_TOK * DHB);         // this wave's V page buffer
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
             for (int h = wave - 2; h < G; h += NW - 2) {
                 float d = (float)s_qp[h][lane] * (float)s_knew[lane] + (float)s_qp[h][64 + lane] * (float)s_knew[64 + lane];
                 d = wave_sum(d);
-                if (lane == 0) s_cur[h] = d * inv_sqrt;
+                if (lane == 0) s_cur[h] = d * qk_scale;
             }
         }
     }
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const h8 x = *reinterpret_cast<const h8*>(&s_qp[li][32 * tg + 8 * w]);
+            const h8 x = *reinterpret_cast<const h8*>(&s_qp[COMPACT ? (li & (G - 1)) : li][32 * tg + 8 * w]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += (float)x[j];
         }
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
         const lds_u8 ql = (lds_u8)(&s_qp[0][0]) + (li_ * (DH * 2) + 64 * tg_);
         const bool odd = tg_ & 1;
         // ---------------- Q.K^T : 4 tiles of 16 tokens ----------------
-        v4f sc[4];
+        v4f craw[4];   // craw[t][r] = raw dot (offsets already cancelled) of token 16t + 4tg + r with head li
         h8 qB[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) qB[w] = LDS_AT(h8, ql + 16 * w);
@@ -249,31 +251,85 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
                                 __builtin_amdgcn_perm(xb, c_magic, 0x00050004u), __builtin_amdgcn_perm(xb, c_magic, 0x00070006u)};
                 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a4), qB[w], c, 0, 0, 0);
             }
-            const h4 ks = LDS_AT(h4, ml + 2 * (16 * t));
-            const h4 kz = LDS_AT(h4, ml + 2 * (PAGE_TOK + 16 * t));
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sc[t][r] = ((float)ks[r] * inv_sqrt) * (c[r] - (float)kz[r] * qsum);
+            craw[t] = c;
         }
-        if (!full) {
+        // softmax on compacted lanes for G <= 4 (tile t' -> lanes li = G t' + h, see attention_mfma.hip), scores in the
+        // log2 domain
+        u32 pbv[2][4];
+        float m_new;
+        float scc[4];
+        v4f scf[4];
+        const int tq_raw = li_ / G;
+        const bool lane_ok = G == 4 || !COMPACT || tq_raw < 4;
+        const int tq = G == 4 ? tq_raw : min(tq_raw, 3);
+        if constexpr (COMPACT) {
+            float (&sc)[4] = scc;
+            const h4 ks = LDS_AT(h4, ml + 32 * tq);
+            const h4 kz = LDS_AT(h4, ml + 2 * PAGE_TOK + 32 * tq);
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int r = 0; r < 4; ++r) {
+                // (scalar copies first: __builtin_bit_cast of a vector-element lvalue reads element 0)
+                const float c0 = craw[0][r], c1 = craw[1][r], c2 = craw[2][r], c3 = craw[3][r];
+                int x = __builtin_bit_cast(int, c0);
+                if constexpr (G == 4) {
+                    x = __builtin_amdgcn_update_dpp(x, __builtin_bit_cast(int, c1), 0x114, 0xF, 0x2, false);
+                    x = __builtin_amdgcn_update_dpp(x, __builtin_bit_cast(int, c2), 0x118, 0xF, 0x4, false);
+                    x = __builtin_amdgcn_update_dpp(x, __builtin_bit_cast(int, c3), 0x11C, 0xF, 0x8, false);
+                } else {
+                    const int s1 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c1), 0x110 + G, 0xF, 0xF, true);
+                    const int s2 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c2), 0x110 + 2 * G, 0xF, 0xF, true);
+                    const int s3 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c3), 0x110 + 3 * G, 0xF, 0xF, true);
+                    x = tq_raw == 1 ? s1 : x;
+                    x = tq_raw == 2 ? s2 : x;
+                    x = tq_raw == 3 ? s3 : x;
+                }
+                sc[r] = ((float)ks[r] * qk_scale) * (__builtin_bit_cast(float, x) - (float)kz[r] * qsum);
+                if (!lane_ok) sc[r] = -3.0e38f;
+            }
+            if (!full) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (16 * t + 4 * tg_ + r >= valid) sc[t][r] = -3.0e38f;   // also discards NaN from garbage scales
+                    if (16 * tq + 4 * tg_ + r >= valid) sc[r] = -3.0e38f;   // also discards NaN from garbage scales
+            }
+        } else {
+            v4f (&sc)[4] = scf;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const h4 ks = LDS_AT(h4, ml + 2 * (16 * t));
+                const h4 kz = LDS_AT(h4, ml + 2 * (PAGE_TOK + 16 * t));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[t][r] = ((float)ks[r] * qk_scale) * (craw[t][r] - (float)kz[r] * qsum);
+            }
+            if (!full) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * t + 4 * tg_ + r >= valid) sc[t][r] = -3.0e38f;   // also discards NaN from garbage scales
+            }
         }
         // K buffer consumed -> request K(p+NW)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (more) dma_k(s_ptab[0][p + NW]);
-        // ---------------- online softmax (per head = per li; the 4 tg lanes of a head hold 16 tokens each) ---------
-        float mx = sc[0][0];
+        // ---------------- online softmax ----------------
+        {
+            float mx;
+            if constexpr (COMPACT) {
+                mx = fmaxf(fmaxf(scc[0], scc[1]), fmaxf(scc[2], scc[3]));
+                mx = fmaxf(mx, xor_lane(mx, lid, G));
+                mx = fmaxf(mx, xor_lane(mx, lid, 2 * G));
+            } else {
+                mx = scf[0][0];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, scf[t][r]);
+            }
+            mx = fmaxf(mx, xor_lane(mx, lid, 16));
+            mx = fmaxf(mx, xor_lane(mx, lid, 32));
+            m_new = fmaxf(m_run, mx);
+        }
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         if (__any(alpha != 1.0f)) {
             l_part *= alpha;
@@ -284,23 +340,48 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
         }
         if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NVM) : "memory");   // V(p) landed (K(p+NW) may be in flight)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // ---------------- P.V : two half pages of 32 tokens ----------------
+        // P' = fp16(p * v-scale); V rows sit in slot tok ^ ((tok >> 2) & 1): lanes of odd tg see each token pair swapped
+        if constexpr (COMPACT) {
+            const h4 vs = LDS_AT(h4, ml + 4 * PAGE_TOK + 32 * tq);
+            const h4 vz = LDS_AT(h4, ml + 6 * PAGE_TOK + 32 * tq);
+            float pp[4];
 #pragma unroll
-        for (int hp = 0; hp < 2; ++hp) {
-            u32 pb[4];
+            for (int r = 0; r < 4; ++r) {
+                const float pe = __builtin_amdgcn_exp2f(scc[r] - m_new);   // 0 for masked tokens
+                l_part += pe;
+                float ps = (float)(_Float16)(pe * (float)vs[r]);           // P' rounded to fp16 (what the MFMA sees)
+                float pz = ps * (float)vz[r];
+                if ((!full && 16 * tq + 4 * tg_ + r >= valid) || !lane_ok) {   // garbage (possibly NaN) scales of unused slots
+                    ps = 0.f;
+                    pz = 0.f;
+                }
+                corr += pz;
+                psum += ps;
+                pp[r] = ps;
+            }
+            const int pk0 = (int)(odd ? pack_h2(pp[1], pp[0]) : pack_h2(pp[0], pp[1]));
+            const int pk1 = (int)(odd ? pack_h2(pp[3], pp[2]) : pack_h2(pp[2], pp[3]));
+            pbv[0][0] = (u32)pk0;
+            pbv[0][1] = (u32)pk1;
+            pbv[0][2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + G, 0xF, 0xF, true);
+            pbv[0][3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + G, 0xF, 0xF, true);
+            pbv[1][0] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + 2 * G, 0xF, 0xF, true);
+            pbv[1][1] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 2 * G, 0xF, 0xF, true);
+            pbv[1][2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + 3 * G, 0xF, 0xF, true);
+            pbv[1][3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 3 * G, 0xF, 0xF, true);
+        } else {
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int t = 2 * hp + tt;
+            for (int t = 0; t < 4; ++t) {
                 const h4 vs = LDS_AT(h4, ml + 2 * (2 * PAGE_TOK + 16 * t));
                 const h4 vz = LDS_AT(h4, ml + 2 * (3 * PAGE_TOK + 16 * t));
                 float pp[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pe = __expf(sc[t][r] - m_new);          // 0 for masked tokens
+                    const float pe = __builtin_amdgcn_exp2f(scf[t][r] - m_new);   // 0 for masked tokens
                     l_part += pe;
-                    float ps = (float)(_Float16)(pe * (float)vs[r]);    // P' rounded to fp16 (what the MFMA sees)
+                    float ps = (float)(_Float16)(pe * (float)vs[r]);
                     float pz = ps * (float)vz[r];
-                    if (!full && 16 * t + 4 * tg_ + r >= valid) {       // garbage (possibly NaN) scales of unused slots
+                    if (!full && 16 * t + 4 * tg_ + r >= valid) {
                         ps = 0.f;
                         pz = 0.f;
                     }
@@ -308,11 +389,14 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
                     psum += ps;
                     pp[r] = ps;
                 }
-                // V rows sit in slot tok ^ ((tok >> 2) & 1): lanes of odd tg see each token pair swapped
-                pb[2 * tt] = odd ? pack_h2(pp[1], pp[0]) : pack_h2(pp[0], pp[1]);
-                pb[2 * tt + 1] = odd ? pack_h2(pp[3], pp[2]) : pack_h2(pp[2], pp[3]);
+                pbv[t >> 1][2 * (t & 1)] = odd ? pack_h2(pp[1], pp[0]) : pack_h2(pp[0], pp[1]);
+                pbv[t >> 1][2 * (t & 1) + 1] = odd ? pack_h2(pp[3], pp[2]) : pack_h2(pp[2], pp[3]);
             }
-            const h8 pB = __builtin_bit_cast(h8, (v4u){pb[0], pb[1], pb[2], pb[3]});
+        }
+        // ---------------- P.V : two half pages of 32 tokens ----------------
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+            const h8 pB = __builtin_bit_cast(h8, (v4u){pbv[hp][0], pbv[hp][1], pbv[hp][2], pbv[hp][3]});
             v2u raw[8];                                                  // 8 dims (bytes) of each of the lane's 8 slots
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) raw[jj] = LDS_AT(v2u, vl + (16 * (2 * hp + (jj >> 2)) + (jj & 3)) * DHB);
@@ -333,38 +417,48 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
     }
 
     // ---- per-wave partials -> LDS.  Lane (head li, tg) holds out dims 8*(4tg + r) + e in acc[e][r] ---------------
-    l_part += __shfl_xor(l_part, 16, 64);
-    l_part += __shfl_xor(l_part, 32, 64);
-    corr += __shfl_xor(corr, 16, 64);
-    corr += __shfl_xor(corr, 32, 64);
-    psum += __shfl_xor(psum, 16, 64);
-    psum += __shfl_xor(psum, 32, 64);
+    const u32 lid2 = fresh_lane_id();   // nothing lane-derived lives across the page loop
+    if constexpr (COMPACT) {
+        l_part += xor_lane(l_part, lid2, G);
+        l_part += xor_lane(l_part, lid2, 2 * G);
+        corr += xor_lane(corr, lid2, G);
+        corr += xor_lane(corr, lid2, 2 * G);
+        psum += xor_lane(psum, lid2, G);
+        psum += xor_lane(psum, lid2, 2 * G);
+    }
+    l_part += xor_lane(l_part, lid2, 16);
+    l_part += xor_lane(l_part, lid2, 32);
+    corr += xor_lane(corr, lid2, 16);
+    corr += xor_lane(corr, lid2, 32);
+    psum += xor_lane(psum, lid2, 16);
+    psum += xor_lane(psum, lid2, 32);
     corr += 1024.f * psum;                              // zero-point term + the 1024 offsets of the V operand
     __syncthreads();   // every wave is done with its page buffers: reuse them as the [NW][G][DH+4] fp32 merge area
     constexpr int OS = DH + 4;
     float (*s_o)[G][OS] = reinterpret_cast<float (*)[G][OS]>(&s_kv[0]);
     static_assert(sizeof(float) * NW * G * OS <= sizeof(s_kv), "merge area must fit the page buffers");
-    if (li < G) {
+    const int li2 = lid2 & 15, tg2 = lid2 >> 4, tid2 = wave * 64 + (int)lid2;
+    if (li2 < G) {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s_o[wave][li][8 * (4 * tg + r) + e] = acc[e][r] - corr;
-        if (tg == 0) {
-            s_m[wave][li] = m_run;
-            s_l[wave][li] = l_part;
+            for (int r = 0; r < 4; ++r) s_o[wave][li2][8 * (4 * tg2 + r) + e] = acc[e][r] - corr;
+        if (tg2 == 0) {
+            s_m[wave][li2] = m_run;
+            s_l[wave][li2] = l_part;
         }
     }
     __syncthreads();
-    for (int o = tid; o < G * DH; o += NW * 64) {
+    for (int o = tid2; o < G * DH; o += NW * 64) {
         const int h = o / DH, d = o % DH;
         float M = z == 0 ? s_cur[h] : -3.0e38f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) M = fmaxf(M, s_m[w][h]);
-        const float pc = z == 0 ? __expf(s_cur[h] - M) : 0.f;      // the new token's own term (split 0 only)
+        const float pc = z == 0 ? __builtin_amdgcn_exp2f(s_cur[h] - M) : 0.f;      // the new token's own term (split 0 only)
         float num = pc * (float)vb[d], den = pc;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            const float f = __expf(s_m[w][h] - M);
+            const float f = __builtin_amdgcn_exp2f(s_m[w][h] - M);
             num += f * s_o[w][h][d];
             den += f * s_l[w][h];
         }
@@ -374,7 +468,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
             float* pw = ws + ((((size_t)b * num_kv_heads + hkv) * nsplit + z) * G + h) * (DH + 2);
             pw[d] = num;
             if (d == 0) {
-                pw[DH] = M;
+                pw[DH] = M * 0.6931471805599453f;   // the merge kernel works in natural-log units
                 pw[DH + 1] = den;
             }
         }

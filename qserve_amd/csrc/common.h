@@ -53,6 +53,17 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // cvt.rni.sat.{s8,u8}.f32 equivalents: round-to-nearest-even then saturate (NaN -> 0)
+// butterfly exchange with an explicitly supplied lane id: __shfl_xor derives its own (loop-invariant) lane id, which the
+// register allocator then keeps alive - or spills - across a long loop
+__device__ __forceinline__ float xor_lane(float x, unsigned lid, int mask) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)((lid ^ (unsigned)mask) << 2), __builtin_bit_cast(int, x)));
+}
+__device__ __forceinline__ unsigned fresh_lane_id() {   // opaque to CSE: not shared with earlier derivations
+    unsigned lid;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
+    return lid;
+}
+
 __device__ __forceinline__ int rni_sat_s8(float x) {
     float r = rintf(x);
     r = fminf(fmaxf(r, -128.f), 127.f);   // fmaxf/fminf drop NaN -> -128 ; handle below

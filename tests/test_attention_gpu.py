@@ -104,10 +104,11 @@ def test_decode_long_context(gpu, int4):
     run_case(gpu, 2, 32, 8, [1536, 1025], int4, seed=7)
 
 
+@pytest.mark.parametrize("int4", [True, False])
 @pytest.mark.parametrize("H,Hkv", [(8, 8), (4, 2), (8, 1)])
-def test_decode_long_context_other_group_sizes(gpu, H, Hkv):
+def test_decode_long_context_other_group_sizes(gpu, H, Hkv, int4):
     """Several pages per wave (the in-wave online-softmax rescale path) for MHA, G = 2 and G = 8 as well."""
-    run_case(gpu, 2, H, Hkv, [1100, 577], True, seed=H * 3 + Hkv)
+    run_case(gpu, 2, H, Hkv, [1100, 577], int4, seed=H * 3 + Hkv)
 
 
 def test_decode_very_long_context_kv8(gpu):
