@@ -488,10 +488,14 @@ int launch_decode(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Fl
     switch (G) {
         case 1: QS_LAUNCH_G(1); break;
         case 2: QS_LAUNCH_G(2); break;
+        case 3: QS_LAUNCH_G(3); break;
         case 4: QS_LAUNCH_G(4); break;
+        case 5: QS_LAUNCH_G(5); break;
+        case 6: QS_LAUNCH_G(6); break;
+        case 7: QS_LAUNCH_G(7); break;
         case 8: QS_LAUNCH_G(8); break;
         default:
-            qs_set_error("single_query_attention: num_heads/num_kv_heads = %d not in {1,2,4,8}", G);
+            qs_set_error("single_query_attention: num_heads/num_kv_heads = %d not in 1..8", G);
             return QS_ENOSUP;
     }
 #undef QS_LAUNCH_G

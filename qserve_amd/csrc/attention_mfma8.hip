@@ -93,7 +93,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
     const int64_t* vtab = ktab + max_blocks;
     const float inv_sqrt = 0.08838834764831845f;
     const float qk_scale = inv_sqrt * 1.4426950408889634f;   // scores live in the log2 domain: exp2 everywhere
-    constexpr bool COMPACT = (G <= 4);                         // softmax on compacted lanes (see the page loop)
+    constexpr bool COMPACT = (G == 1 || G == 2 || G == 4);     // softmax on compacted lanes (see the page loop)
     const int li = lane & 15, tg = lane >> 4;
     uint8_t* const s_kw = s_kv + wave * (PAGE_TOK * DHB);                // this wave's K page buffer
     uint8_t* const s_vw = s_kv + (NW + wave) * (PAGE_TOK * DHB);         // this wave's V page buffer
@@ -510,10 +510,14 @@ int qs_launch_decode_mfma8(int G, dim3 grid, hipStream_t st, const _Float16* q, 
     switch (G) {
         case 1: QS_LAUNCH_G(1); break;
         case 2: QS_LAUNCH_G(2); break;
+        case 3: QS_LAUNCH_G(3); break;
         case 4: QS_LAUNCH_G(4); break;
+        case 5: QS_LAUNCH_G(5); break;
+        case 6: QS_LAUNCH_G(6); break;
+        case 7: QS_LAUNCH_G(7); break;
         case 8: QS_LAUNCH_G(8); break;
         default:
-            qs_set_error("single_query_attention: num_heads/num_kv_heads = %d not in {1,2,4,8}", G);
+            qs_set_error("single_query_attention: num_heads/num_kv_heads = %d not in 1..8", G);
             return QS_ENOSUP;
     }
 #undef QS_LAUNCH_G

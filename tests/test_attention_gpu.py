@@ -93,7 +93,7 @@ def run_case(gpu, B, H, Hkv, lengths, int4, seed):
 
 
 @pytest.mark.parametrize("int4", [True, False])
-@pytest.mark.parametrize("H,Hkv", [(32, 8), (8, 8), (4, 2), (8, 1)])
+@pytest.mark.parametrize("H,Hkv", [(32, 8), (8, 8), (4, 2), (8, 1), (7, 1), (6, 2), (5, 1)])
 def test_decode_ragged_lengths(gpu, int4, H, Hkv):
     # length 1 (no history), exact page boundaries, one past, ragged tail
     run_case(gpu, 6, H, Hkv, [1, 2, 64, 65, 129, 200], int4, seed=H + Hkv)
@@ -105,7 +105,7 @@ def test_decode_long_context(gpu, int4):
 
 
 @pytest.mark.parametrize("int4", [True, False])
-@pytest.mark.parametrize("H,Hkv", [(8, 8), (4, 2), (8, 1)])
+@pytest.mark.parametrize("H,Hkv", [(8, 8), (4, 2), (8, 1), (7, 1), (3, 1)])
 def test_decode_long_context_other_group_sizes(gpu, H, Hkv, int4):
     """Several pages per wave (the in-wave online-softmax rescale path) for MHA, G = 2 and G = 8 as well."""
     run_case(gpu, 2, H, Hkv, [1100, 577], int4, seed=H * 3 + Hkv)
