@@ -213,3 +213,33 @@ def test_piecewise_graphs_equal_eager_steps(gpu):
     for o in outs[1:]:
         for a, b in zip(outs[0], o):
             assert torch.equal(a, b)
+
+
+MODEL_SHAPES = {   # one layer of the reference's other supported dense models (qserve README model list)
+    "llama2-13b": dict(hidden=5120, heads=40, kv_heads=40, inter=13824),
+    "yi-34b": dict(hidden=7168, heads=56, kv_heads=8, inter=20480),
+    "llama2-70b": dict(hidden=8192, heads=64, kv_heads=8, inter=28672),
+    "qwen1.5-72b": dict(hidden=8192, heads=64, kv_heads=64, inter=24576),
+    "mistral-7b": dict(hidden=4096, heads=32, kv_heads=8, inter=14336),
+}
+
+
+@pytest.mark.parametrize("name", sorted(MODEL_SHAPES))
+@pytest.mark.parametrize("gs", [-1, 128])
+def test_other_model_shapes_run_and_fuse_identically(gpu, name, gs):
+    """Every kernel of the path at the layer shapes of the other dense models the reference lists (hidden sizes 5120 /
+    7168 / 8192, GQA groups 1 / 7 / 8, K not a multiple of 1024): prefill + decode steps, eager and captured, fused
+    pairs == op-by-op."""
+    from qserve_amd.decode import DecodeEngine
+    cfg = dict(MODEL_SHAPES[name], name=name, layers=1, vocab=1024, rope_theta=1e4, eps=1e-5)
+    outs = []
+    for fuse in (False, True):
+        eng = DecodeEngine(cfg, batch=6, prompt_len=70, max_new=8, group_size=gs, device="cuda:0", seed=9, fuse_pairs=fuse)
+        eng.prefill(70)
+        eng.step()
+        eng.capture()
+        eng.run()
+        torch.cuda.synchronize()
+        assert torch.isfinite(eng.hidden.float()).all()
+        outs.append((eng.hidden.clone(), eng.tokens.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
