@@ -33,7 +33,7 @@ def main():
     shapes = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]] or shard_shapes()
     g = torch.Generator(device="cuda").manual_seed(0)
     for M, N, K in shapes:
-        nl = max(2, min(32, int(600e6 // (N * K // 2))))
+        nl = int(os.environ["NLW"]) if os.environ.get("NLW") else max(2, min(32, int(600e6 // (N * K // 2))))
         Ws = [torch.randint(-128, 128, (N, K // 2), dtype=torch.int8, device="cuda", generator=g) for _ in range(nl)]
         A = torch.randint(-127, 128, (M, K), dtype=torch.int8, device="cuda", generator=g)
         ws = torch.rand(N, device="cuda").half() * 0.01
@@ -62,10 +62,10 @@ def main():
                 torch.cuda.synchronize()
             finally:
                 _lib.lib.qs_set_gemm_variant(-1)
-        best = min((t, v) for v, t in res.items() if t is not None and v != -1)
+        best = min((t, v) for v, t in res.items() if t is not None and (v != -1 or len(res) == 1))
         print(f"M={M:4d} N={N:5d} K={K:5d}  " + "  ".join(
             f"{v}:{'   n/a' if t is None else f'{t:6.2f}'}" for v, t in res.items()) +
-            f"   best {best[1]} ({res[-1] / best[0]:.2f}x of dispatcher)", flush=True)
+            f"   best {best[1]}" + (f" ({res[-1] / best[0]:.2f}x of dispatcher)" if -1 in res else ""), flush=True)
         del Ws
 
 
