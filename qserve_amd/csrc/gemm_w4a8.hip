@@ -424,7 +424,9 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         else if (g_variant < 1000 || g_variant > 3002) {
             const long nb = N / 256;
             // measured crossovers (scripts/bench_gemm_big.py, N=4096..28672): the tiles must (nearly) fill 256 CUs
-            if (((M + 255) / 256) * nb >= 192) tmt = 8;
+            // (M >= 192: a 256-token tile must be mostly real tokens - without this bound every N >= 49 152 took the tiled
+            // kernel even at M = 64 and ran at 2 TB/s)
+            if (M >= 192 && ((M + 255) / 256) * nb >= 192) tmt = 8;
             else if (M >= 256 && ((M + 127) / 128) * nb >= (MODE == 0 ? 96 : 192)) tmt = 4;
         }
         if (tmt)
@@ -483,6 +485,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
                 const int mt = geo[i][0], wn = geo[i][1];
                 if (N % (64 * wn) != 0 || (K / 64) % ks != 0 || (K / 64 / ks) % (16 / wn) != 0) continue;
                 const int mb = (mt_all + mt - 1) / mt;
+                if (ks > 1 && (long)mb * (N / (64 * wn)) > 256) continue;   // K slices are for under-filled grids only
                 const long blocks = (long)mb * (N / (64 * wn)) * ks;
                 const long cost = ((blocks + 255) / 256) * (16 * mt + 32 * wn) * (long)(K / ks) * (ks > 1 ? 11 : 10) / 10 +
                                   seam(ks, mt);

@@ -226,6 +226,39 @@ def test_tp_shard_shapes_exact(gpu, M, N, K):
     assert ulp_diff_f16(out.cpu().numpy(), out_ref).max() == 0
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 49152, 1024), (37, 57344, 2048), (16, 65536, 1024)])
+def test_very_wide_n(gpu, M, N, K):
+    """N >= 49152 (single-GPU 70 B-class gate_up; more than one round of workgroups): per-channel exact vs a device
+    integer matmul + oracle epilogue, per-group vs the oracle."""
+    import qserve_backend.qgemm_w4a8_per_chn as op
+    import qserve_backend.qgemm_w4a8_per_group as opg
+    g = torch.Generator(device=gpu).manual_seed(N + K + M)
+    W = torch.randint(-128, 128, (N, K // 2), dtype=torch.int8, device=gpu, generator=g)
+    A = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=gpu, generator=g)
+    acc = torch.full((M, N), -7, dtype=torch.int32, device=gpu)
+    op.gemm_forward_acc(A, W, acc)
+    assert torch.equal(acc.to(torch.int64), int_matmul_torch(A, unpack_qweight_torch(W)))
+    r = np.random.default_rng(N + K)
+    ws = r.uniform(0.001, 0.01, N).astype(np.float16)
+    wz = r.uniform(-0.05, 0.05, N).astype(np.float16)
+    sa = r.uniform(0.005, 0.05, M).astype(np.float16)
+    ss = r.uniform(-20, 20, M).astype(np.float16)
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+    op.gemm_forward_cuda(A, W, dev(ws), dev(sa), dev(wz), dev(ss), out)
+    assert ulp_diff_f16(out.cpu().numpy(), w4a8.epilogue_per_chn(acc.cpu().numpy(), ws, sa, wz, ss)).max() == 0
+    if M <= 16:      # the numpy per-group oracle at this width takes a few seconds
+        pr = synth.per_group_problem(M, N, K, seed=5)
+        acc_ref, out_ref = w4a8.gemm_per_group(pr["A"], pr["qweight"], pr["s2_zeros"], pr["s2_scales"], pr["wscales"],
+                                               pr["ascales"])
+        Ag, Wg, Z, S = dev(pr["A"]), dev(pr["qweight"]), dev(pr["s2_zeros"]), dev(pr["s2_scales"])
+        accg = torch.full((M, N), -7, dtype=torch.int32, device=gpu)
+        opg.gemm_forward_acc(Ag, Wg, Z, S, accg)
+        assert np.array_equal(accg.cpu().numpy(), acc_ref)
+        outg = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+        opg.gemm_forward_cuda(Ag, Wg, Z, S, dev(pr["wscales"]), dev(pr["ascales"]), outg)
+        assert ulp_diff_f16(outg.cpu().numpy(), out_ref).max() == 0
+
+
 def test_config1_4096_cubed_per_channel(gpu):
     """configs[0] of BASELINE.json (the reference's CPU-runnable case) on the GPU, exact."""
     import qserve_backend.qgemm_w4a8_per_chn as op
