@@ -451,7 +451,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         const int v = g_variant - 4100, ks = v / 100 + 1, mt = (v % 100) / 10, wn = v % 10;
         const int mb = ((M + 15) / 16 + mt - 1) / mt;
         QS_REQUIRE((mt == 1 || mt == 2 || mt == 4) && (wn == 1 || wn == 2) && !(mt == 1 && wn == 2) &&
-                       N % (64 * wn) == 0 && (K / 64) % ks == 0 && (K / 64 / ks) % (16 / wn) == 0,
+                       N % (64 * wn) == 0 && (K / 64) % ks == 0 && (K / 64 / ks) % (8 / wn) == 0,
                    "w4a8 gemm: forced ring geometry mt=%d wn=%d ksplit=%d does not fit M=%d N=%d K=%d", mt, wn, ks, M, N,
                    K);
         int* slabs = nullptr;
@@ -483,7 +483,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         for (int ks = 1; ks <= (g_variant == 4001 ? 1 : 4); ks *= 2)
             for (int i = 0; i < 5; ++i) {
                 const int mt = geo[i][0], wn = geo[i][1];
-                if (N % (64 * wn) != 0 || (K / 64) % ks != 0 || (K / 64 / ks) % (16 / wn) != 0) continue;
+                if (N % (64 * wn) != 0 || (K / 64) % ks != 0 || (K / 64 / ks) % (8 / wn) != 0) continue;
                 const int mb = (mt_all + mt - 1) / mt;
                 if (ks > 1 && (long)mb * (N / (64 * wn)) > 256) continue;   // K slices are for under-filled grids only
                 const long blocks = (long)mb * (N / (64 * wn)) * ks;
@@ -491,6 +491,20 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
                                   seam(ks, mt);
                 if (best < 0 || cost < best) best = cost, bmt = mt, bwn = wn, bks = ks;
             }
+        // the older register-staged split-K kernel takes any K and cuts the tokens down to 16 per workgroup: same byte
+        // model, ~20 % slower at equal bytes (measured) - it wins where K leaves the ring kernel only coarse geometries
+        // (Llama-2-7B down_proj: K = 11 008 = 172 stages, two-unit workgroups only)
+        if (best >= 0 && units < 256 && units % 8 == 0 && M > 16 && M <= 128) {
+            int mto = 1;
+            for (int cand = 4; cand >= 1; cand >>= 1)
+                if (cand <= mt_all && (long)units * ((mt_all + cand - 1) / cand) >= 192) {
+                    mto = cand;
+                    break;
+                }
+            const long blocks_o = (long)units * ((mt_all + mto - 1) / mto);
+            const long cost_o = ((blocks_o + 255) / 256) * (16 * mto + 32) * (long)K * 12 / 10;
+            if (cost_o < best) best = -1;
+        }
         if (best >= 0) {
             int mb = (mt_all + bmt - 1) / bmt;
             int* slabs = nullptr;
@@ -500,7 +514,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
                 bks = 1;
                 for (int i = 0; i < 5; ++i) {
                     const int mt = geo[i][0], wn = geo[i][1];
-                    if (N % (64 * wn) != 0 || (K / 64) % (16 / wn) != 0) continue;
+                    if (N % (64 * wn) != 0 || (K / 64) % (8 / wn) != 0) continue;
                     const long blocks = (long)((mt_all + mt - 1) / mt) * (N / (64 * wn));
                     const long cost = ((blocks + 255) / 256) * (16 * mt + 32 * wn);
                     if (best < 0 || cost < best) best = cost, bmt = mt, bwn = wn;

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
     const int KT = K >> 5;
     const int nst = (K >> 6) / ksplit;                // 64-k stages of this workgroup's K slice
     const int u0 = kq * nst;                          // first global stage
-    const int nloc = nst / KG;                        // stages per group (dispatcher: (K/64/ksplit) % (2 KG) == 0)
+    const int nloc = nst / KG;                        // stages per group (dispatcher: (K/64/ksplit) % KG == 0)
 
     uint8_t* const ring = smem + kg * ns * GSTAGE;    // this group's ring: slot s = [A | W | meta]
     const u32 ring_lds = (u32)(size_t)(lptr_t)ring;
@@ -267,15 +267,17 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
         else wait_vm<0>();
     };
     int slot = 0;
-    for (int i = 0; i < nloc; i += 2) {               // nloc is even (dispatcher)
+    for (int i = 0; i < nloc; i += 2) {               // two rounds per trip (operand registers ping-pong); nloc may be odd
         wait_next(i);
         raw_barrier();
         round(i, slot, o0, o1);
         slot = slot + 1 == ns ? 0 : slot + 1;
-        wait_next(i + 1);
-        raw_barrier();
-        round(i + 1, slot, o1, o0);
-        slot = slot + 1 == ns ? 0 : slot + 1;
+        if (i + 1 < nloc) {
+            wait_next(i + 1);
+            raw_barrier();
+            round(i + 1, slot, o1, o0);
+            slot = slot + 1 == ns ? 0 : slot + 1;
+        }
     }
 
     // ---- reduce the KG partial tiles through LDS, fused epilogue -----------------------------------------------------
@@ -454,7 +456,7 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
 
 // Entry used by the dispatcher in gemm_w4a8.hip.  mt = m-tiles per workgroup (1, 2, 4), wn = units per workgroup
 // (1, 2); ksplit = K slices (1 = none; > 1 needs the slab / counter workspace: (N/64) * mblocks * ksplit * mt KiB * 4 and
-// (N/64) * mblocks counters); preconditions (checked there): N % (64*wn) == 0, (K/64/ksplit) % (2 * 8/wn) == 0,
+// (N/64) * mblocks counters); preconditions (checked there): N % (64*wn) == 0, (K/64/ksplit) % (8/wn) == 0,
 // M*K and N*K/2 below 4 GiB.
 int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, const uint8_t* W, const int8_t* zeros,
                         const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
