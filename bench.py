@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--max-new", type=int, default=512)
     ap.add_argument("--group-size", type=int, default=-1, choices=[-1, 128])
     ap.add_argument("--kv8", action="store_true")
-    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "qwen1.5-72b", "tiny"])
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama2-7b", "llama2-70b", "qwen1.5-72b", "tiny"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-bench", action="store_true")
@@ -192,7 +192,8 @@ def main():
     if args.gemm_variant != -1:
         from qserve_amd import _lib
         _lib.lib.qs_set_gemm_variant(args.gemm_variant)
-    cfg = {"llama3-8b": D.LLAMA3_8B, "qwen1.5-72b": D.QWEN15_72B, "tiny": D.TINY}[args.model]
+    cfg = {"llama3-8b": D.LLAMA3_8B, "llama2-7b": D.LLAMA2_7B, "llama2-70b": D.LLAMA2_70B, "qwen1.5-72b": D.QWEN15_72B,
+           "tiny": D.TINY}[args.model]
     eng = D.DecodeEngine(cfg, args.batch, args.prompt_len, args.max_new, group_size=args.group_size,
                          int4_kv=not args.kv8, device=dev, tp_rank=rank, tp_world=world,
                          fuse_pairs=not args.op_by_op)

@@ -39,6 +39,10 @@ LLAMA3_8B = dict(name="Llama-3-8B", hidden=4096, heads=32, kv_heads=8, inter=143
                  rope_theta=5e5, eps=1e-5)
 QWEN15_72B = dict(name="Qwen1.5-72B", hidden=8192, heads=64, kv_heads=64, inter=24576, layers=80, vocab=152064,
                   rope_theta=1e6, eps=1e-6)
+LLAMA2_7B = dict(name="Llama-2-7B", hidden=4096, heads=32, kv_heads=32, inter=11008, layers=32, vocab=32000,
+                 rope_theta=1e4, eps=1e-5)
+LLAMA2_70B = dict(name="Llama-2-70B", hidden=8192, heads=64, kv_heads=8, inter=28672, layers=80, vocab=32000,
+                  rope_theta=1e4, eps=1e-5)
 TINY = dict(name="tiny-llama", hidden=256, heads=4, kv_heads=2, inter=512, layers=2, vocab=512, rope_theta=1e4,
             eps=1e-5)
 
