@@ -97,11 +97,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     const int tsel = li >> 3, c = li & 7;
     // tile coordinates: consecutive workgroups walk M first inside a band of channels (weights of the band stay in L2).
     // (an XCD-aware variant - every XCD owning a contiguous 4 x 2 super-tile of the grid - measured no better.)
-    // Persistent: the launch holds at most one workgroup per CU and each walks the tile list with the grid stride -
-    // a tile hand-over inside the workgroup costs a barrier, not a workgroup launch (measured: ~5 us per tile).
-    const int ntiles = nbm * (N / BN);
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int bm = tile % nbm, bn = tile / nbm;
+    const int bm = blockIdx.x % nbm, bn = blockIdx.x / nbm;
     const int m0 = bm * BM, n0 = bn * BN;
     const int KT = K >> 5;
     const int nh = K >> 6;                            // stages
@@ -284,8 +280,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
             for (int cl = 0; cl < 4; ++cl)
                 *reinterpret_cast<v4i*>(reinterpret_cast<int*>(out) + (size_t)m * N + ncol0 + 8 * cl) = acc[mt][cl];
         }
-        __syncthreads();                               // every wave left the k loop before the next tile's DMA starts
-        continue;
+        return;
     }
     h4 ws4[4], wz4[4];
     _Float16 sa_h[MT], ss_h[MT];
@@ -332,8 +327,6 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
         const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane & 7) * 16);
         if (m < M) *reinterpret_cast<v4u*>(orow + (size_t)m * N) = v;
     }
-    __syncthreads();                                   // the staging area is ring space of the next tile
-    }   // tile loop
 }
 
 template <int MT, int MODE, int OUTK, int DBG = 0>
@@ -356,15 +349,7 @@ int launch_tiled(const int8_t* A, const uint8_t* W, const int8_t* zeros, const i
         configured = true;
     }
     const int nbm = (M + BM - 1) / BM;
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-               prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
-    const int ntiles = nbm * (N / BN);
-    dim3 grid(ntiles < ncu ? ntiles : ncu);
+    dim3 grid(nbm * (N / BN));
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, A, W, zeros, scales8,
                        reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
                        reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K,
