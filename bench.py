@@ -154,8 +154,17 @@ def cpu_baseline(args, cfg):
     t_attn_all = time.perf_counter() - t0
     t_attn = t_attn_all / nseq
     step_s = cfg["layers"] * (t_layer + B * t_attn)
-    return dict(value=B / step_s, unit="tokens/s", cores=os.cpu_count(), kind="port",
-                sample=f"numpy oracle, {t_gemm + t_attn_all:.1f} s of CPU work: one layer's per-channel GEMMs (M={B}) "
+    threads = os.cpu_count()
+    try:                                   # threads numpy's BLAS actually uses for the GEMM slices (the rest is 1 thread)
+        from threadpoolctl import threadpool_info
+        blas = [p["num_threads"] for p in threadpool_info() if p.get("user_api") == "blas"]
+        if blas:
+            threads = max(blas)
+    except Exception:
+        pass
+    return dict(value=B / step_s, unit="tokens/s", cores=threads, kind="port",
+                sample=f"numpy oracle (GEMM slices on numpy's BLAS threads = `cores`, everything else single-threaded), "
+                       f"{t_gemm + t_attn_all:.1f} s of CPU work: one layer's per-channel GEMMs (M={B}) "
                        f"x {reps} weight sets = {t_layer:.2f} s per layer; decode attention {t_attn:.3f} s/sequence at "
                        f"L={L} ({nseq} sequences timed); step = {cfg['layers']} layers x (GEMMs + {B} sequences)")
 
