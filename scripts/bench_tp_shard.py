@@ -23,9 +23,11 @@ def main():
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--modes", nargs="+", default=["weak", "strong"])
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama2-70b", "qwen1.5-72b"])
     a = ap.parse_args()
     torch.cuda.set_device(0)
-    cfg = dict(D.LLAMA3_8B, layers=a.layers)
+    base = {"llama3-8b": D.LLAMA3_8B, "llama2-70b": D.LLAMA2_70B, "qwen1.5-72b": D.QWEN15_72B}[a.model]
+    cfg = dict(base, layers=min(a.layers, base["layers"]))
     for tp in a.tp:
         for mode in a.modes:
             B = 64 * tp if mode == "weak" else 64
