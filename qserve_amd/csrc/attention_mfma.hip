@@ -235,7 +235,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         float se = 0.f, so = 0.f;   // sums over lo-form / hi-form operand positions of this lane's 32 dims
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const h8 x = *reinterpret_cast<const h8*>(&s_qp[COMPACT ? (li & (G - 1)) : li][32 * tg + 8 * w]);
+            const h8 x = *reinterpret_cast<const h8*>(&s_qp[COMPACT ? (li & (G - 1)) : (G == 8 ? (li & 7) : li)][32 * tg + 8 * w]);
             se += (float)x[0] + (float)x[1] + (float)x[4] + (float)x[5];
             so += (float)x[2] + (float)x[3] + (float)x[6] + (float)x[7];
         }
@@ -298,6 +298,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         float m_new;
         float scc[4];    // COMPACT: this lane's 4 scores
         v4f scf[4];      // otherwise: 16 scores of head li
+        float sc8[8];    // G == 8: two lane groups, 8 scores per lane
         if constexpr (COMPACT) {
             // Only the columns li < G of the 16x16 results are real heads.  Instead of running the softmax on 16
             // values per lane with 3/4 of the lanes idle, tile t' moves to the lanes li = G t' + h (DPP row_shr inside
@@ -346,6 +347,50 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
                 mx = fmaxf(mx, xor_lane(mx, lid, G));
                 mx = fmaxf(mx, xor_lane(mx, lid, 2 * G));
             }
+            mx = fmaxf(mx, xor_lane(mx, lid, 16));
+            mx = fmaxf(mx, xor_lane(mx, lid, 32));
+            m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            if (__any(alpha != 1.0f)) {
+                l_part *= alpha;
+                corr *= alpha;
+                psum *= alpha;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] *= alpha;
+            }
+        } else if constexpr (G == 8) {
+            // two lane groups: li < 8 keeps tiles 0 and 2 of head li, li >= 8 takes tiles 1 and 3 of head li - 8 (row_shr:8
+            // into the upper two 4-lane banks): 8 scores per lane, every lane busy
+            const int tq2 = li_ >> 3;
+            const h4 ksa = *(const __attribute__((address_space(3))) h4*)(ml + 32 * tq2);
+            const h4 kza = *(const __attribute__((address_space(3))) h4*)(ml + 2 * PAGE_TOK + 32 * tq2);
+            const h4 ksb = *(const __attribute__((address_space(3))) h4*)(ml + 32 * (2 + tq2));
+            const h4 kzb = *(const __attribute__((address_space(3))) h4*)(ml + 2 * PAGE_TOK + 32 * (2 + tq2));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float c0 = craw[0][r], c1 = craw[1][r], c2 = craw[2][r], c3 = craw[3][r];
+                const int xa = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, c0), __builtin_bit_cast(int, c1), 0x118,
+                                                           0xF, 0xC, false);
+                const int xb = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, c2), __builtin_bit_cast(int, c3), 0x118,
+                                                           0xF, 0xC, false);
+                sc8[r] = ((float)ksa[r] * qk_scale) * (__builtin_bit_cast(float, xa) - (float)kza[r] * qsum);
+                sc8[4 + r] = ((float)ksb[r] * qk_scale) * (__builtin_bit_cast(float, xb) - (float)kzb[r] * qsum);
+            }
+            if (!full) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (16 * tq2 + 4 * tg_ + r >= valid) sc8[r] = -3.0e38f;
+                    if (16 * (2 + tq2) + 4 * tg_ + r >= valid) sc8[4 + r] = -3.0e38f;
+                }
+            }
+            // K buffer consumed -> request K(p+NW)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (more) dma_k(page_addr(0, p + NW));
+            float mx = sc8[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc8[j]);
+            mx = fmaxf(mx, xor_lane(mx, lid, 8));
             mx = fmaxf(mx, xor_lane(mx, lid, 16));
             mx = fmaxf(mx, xor_lane(mx, lid, 32));
             m_new = fmaxf(m_run, mx);
@@ -435,6 +480,39 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             pbv[1][1] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 2 * G, 0xF, 0xF, true);
             pbv[1][2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + 3 * G, 0xF, 0xF, true);
             pbv[1][3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 3 * G, 0xF, 0xF, true);
+        } else if constexpr (G == 8) {
+            const int tq2 = li_ >> 3;
+            const h4 vsa = *(const __attribute__((address_space(3))) h4*)(ml + 4 * PAGE_TOK + 32 * tq2);
+            const h4 vza = *(const __attribute__((address_space(3))) h4*)(ml + 6 * PAGE_TOK + 32 * tq2);
+            const h4 vsb = *(const __attribute__((address_space(3))) h4*)(ml + 4 * PAGE_TOK + 32 * (2 + tq2));
+            const h4 vzb = *(const __attribute__((address_space(3))) h4*)(ml + 6 * PAGE_TOK + 32 * (2 + tq2));
+            float pp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = j & 3, t = j < 4 ? tq2 : 2 + tq2;
+                const float pe = __builtin_amdgcn_exp2f(sc8[j] - m_new);   // 0 for masked tokens
+                l_part += pe;
+                float ps = (float)(_Float16)(pe * (float)(j < 4 ? vsa[r] : vsb[r]));
+                float pz = ps * (float)(j < 4 ? vza[r] : vzb[r]);
+                if (!full && 16 * t + 4 * tg_ + r >= valid) {                  // garbage (possibly NaN) scales of unused slots
+                    ps = 0.f;
+                    pz = 0.f;
+                }
+                corr += pz;
+                psum += ps;
+                pp[j] = ps;
+            }
+            const int pka0 = (int)pack_h2(pp[0], pp[1]), pka1 = (int)pack_h2(pp[2], pp[3]);
+            const int pkb0 = (int)pack_h2(pp[4], pp[5]), pkb1 = (int)pack_h2(pp[6], pp[7]);
+            // B operand for lane (head li < 8, kg = tg): tiles 0 / 2 are its own, tiles 1 / 3 sit in lane li + 8
+            pbv[0][0] = (u32)pka0;
+            pbv[0][1] = (u32)pka1;
+            pbv[0][2] = (u32)__builtin_amdgcn_update_dpp(0, pka0, 0x108, 0xF, 0xF, true);
+            pbv[0][3] = (u32)__builtin_amdgcn_update_dpp(0, pka1, 0x108, 0xF, 0xF, true);
+            pbv[1][0] = (u32)pkb0;
+            pbv[1][1] = (u32)pkb1;
+            pbv[1][2] = (u32)__builtin_amdgcn_update_dpp(0, pkb0, 0x108, 0xF, 0xF, true);
+            pbv[1][3] = (u32)__builtin_amdgcn_update_dpp(0, pkb1, 0x108, 0xF, 0xF, true);
         } else {
             v4f (&sc)[4] = scf;
 #pragma unroll
@@ -497,6 +575,11 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     // (lane-derived values are re-derived here so that none of them has to survive the page loop in a register)
     const u32 lid2 = fresh_lane_id();
     const int li2 = lid2 & 15, tg2 = lid2 >> 4, tid2 = wave * 64 + (int)lid2;
+    if constexpr (G == 8) {   // two lane groups per head
+        l_part += xor_lane(l_part, lid2, 8);
+        corr += xor_lane(corr, lid2, 8);
+        psum += xor_lane(psum, lid2, 8);
+    }
     if constexpr (COMPACT) {   // the head's tokens were spread over the lanes li = G t' + h as well
         l_part += xor_lane(l_part, lid2, G);
         l_part += xor_lane(l_part, lid2, 2 * G);

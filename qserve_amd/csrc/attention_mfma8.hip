@@ -198,7 +198,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const h8 x = *reinterpret_cast<const h8*>(&s_qp[COMPACT ? (li & (G - 1)) : li][32 * tg + 8 * w]);
+            const h8 x = *reinterpret_cast<const h8*>(&s_qp[COMPACT ? (li & (G - 1)) : (G == 8 ? (li & 7) : li)][32 * tg + 8 * w]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += (float)x[j];
         }
@@ -259,6 +259,8 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
         float m_new;
         float scc[4];
         v4f scf[4];
+        float sc8[8];                                   // G == 8: two lane groups, 8 scores per lane
+        const int tq2 = li_ >> 3;
         const int tq_raw = li_ / G;
         const bool lane_ok = G == 4 || !COMPACT || tq_raw < 4;
         const int tq = G == 4 ? tq_raw : min(tq_raw, 3);
@@ -291,6 +293,29 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
                 for (int r = 0; r < 4; ++r)
                     if (16 * tq + 4 * tg_ + r >= valid) sc[r] = -3.0e38f;   // also discards NaN from garbage scales
             }
+        } else if constexpr (G == 8) {
+            // two lane groups (see attention_mfma.hip): li < 8 keeps tiles 0 / 2 of head li, li >= 8 takes tiles 1 / 3
+            const h4 ksa = LDS_AT(h4, ml + 32 * tq2);
+            const h4 kza = LDS_AT(h4, ml + 2 * PAGE_TOK + 32 * tq2);
+            const h4 ksb = LDS_AT(h4, ml + 32 * (2 + tq2));
+            const h4 kzb = LDS_AT(h4, ml + 2 * PAGE_TOK + 32 * (2 + tq2));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float c0 = craw[0][r], c1 = craw[1][r], c2 = craw[2][r], c3 = craw[3][r];
+                const int xa = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, c0), __builtin_bit_cast(int, c1), 0x118,
+                                                           0xF, 0xC, false);
+                const int xb = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, c2), __builtin_bit_cast(int, c3), 0x118,
+                                                           0xF, 0xC, false);
+                sc8[r] = ((float)ksa[r] * qk_scale) * (__builtin_bit_cast(float, xa) - (float)kza[r] * qsum);
+                sc8[4 + r] = ((float)ksb[r] * qk_scale) * (__builtin_bit_cast(float, xb) - (float)kzb[r] * qsum);
+            }
+            if (!full) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (16 * tq2 + 4 * tg_ + r >= valid) sc8[r] = -3.0e38f;
+                    if (16 * (2 + tq2) + 4 * tg_ + r >= valid) sc8[4 + r] = -3.0e38f;
+                }
+            }
         } else {
             v4f (&sc)[4] = scf;
 #pragma unroll
@@ -318,6 +343,11 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
                 mx = fmaxf(fmaxf(scc[0], scc[1]), fmaxf(scc[2], scc[3]));
                 mx = fmaxf(mx, xor_lane(mx, lid, G));
                 mx = fmaxf(mx, xor_lane(mx, lid, 2 * G));
+            } else if constexpr (G == 8) {
+                mx = sc8[0];
+#pragma unroll
+                for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc8[j]);
+                mx = fmaxf(mx, xor_lane(mx, lid, 8));
             } else {
                 mx = scf[0][0];
 #pragma unroll
@@ -369,6 +399,39 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
             pbv[1][1] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 2 * G, 0xF, 0xF, true);
             pbv[1][2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + 3 * G, 0xF, 0xF, true);
             pbv[1][3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 3 * G, 0xF, 0xF, true);
+        } else if constexpr (G == 8) {
+            const h4 vsa = LDS_AT(h4, ml + 4 * PAGE_TOK + 32 * tq2);
+            const h4 vza = LDS_AT(h4, ml + 6 * PAGE_TOK + 32 * tq2);
+            const h4 vsb = LDS_AT(h4, ml + 4 * PAGE_TOK + 32 * (2 + tq2));
+            const h4 vzb = LDS_AT(h4, ml + 6 * PAGE_TOK + 32 * (2 + tq2));
+            float pp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = j & 3, t = j < 4 ? tq2 : 2 + tq2;
+                const float pe = __builtin_amdgcn_exp2f(sc8[j] - m_new);   // 0 for masked tokens
+                l_part += pe;
+                float ps = (float)(_Float16)(pe * (float)(j < 4 ? vsa[r] : vsb[r]));
+                float pz = ps * (float)(j < 4 ? vza[r] : vzb[r]);
+                if (!full && 16 * t + 4 * tg_ + r >= valid) {
+                    ps = 0.f;
+                    pz = 0.f;
+                }
+                corr += pz;
+                psum += ps;
+                pp[j] = ps;
+            }
+            const int pka0 = (int)(odd ? pack_h2(pp[1], pp[0]) : pack_h2(pp[0], pp[1]));
+            const int pka1 = (int)(odd ? pack_h2(pp[3], pp[2]) : pack_h2(pp[2], pp[3]));
+            const int pkb0 = (int)(odd ? pack_h2(pp[5], pp[4]) : pack_h2(pp[4], pp[5]));
+            const int pkb1 = (int)(odd ? pack_h2(pp[7], pp[6]) : pack_h2(pp[6], pp[7]));
+            pbv[0][0] = (u32)pka0;
+            pbv[0][1] = (u32)pka1;
+            pbv[0][2] = (u32)__builtin_amdgcn_update_dpp(0, pka0, 0x108, 0xF, 0xF, true);
+            pbv[0][3] = (u32)__builtin_amdgcn_update_dpp(0, pka1, 0x108, 0xF, 0xF, true);
+            pbv[1][0] = (u32)pkb0;
+            pbv[1][1] = (u32)pkb1;
+            pbv[1][2] = (u32)__builtin_amdgcn_update_dpp(0, pkb0, 0x108, 0xF, 0xF, true);
+            pbv[1][3] = (u32)__builtin_amdgcn_update_dpp(0, pkb1, 0x108, 0xF, 0xF, true);
         } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -418,6 +481,11 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
 
     // ---- per-wave partials -> LDS.  Lane (head li, tg) holds out dims 8*(4tg + r) + e in acc[e][r] ---------------
     const u32 lid2 = fresh_lane_id();   // nothing lane-derived lives across the page loop
+    if constexpr (G == 8) {
+        l_part += xor_lane(l_part, lid2, 8);
+        corr += xor_lane(corr, lid2, 8);
+        psum += xor_lane(psum, lid2, 8);
+    }
     if constexpr (COMPACT) {
         l_part += xor_lane(l_part, lid2, G);
         l_part += xor_lane(l_part, lid2, 2 * G);

@@ -34,7 +34,7 @@ def timeit(fn, reps=32, replays=6):
 
 
 dev = torch.device("cuda:0")
-B, H, Hkv = int(os.environ.get("B", "64")), 32, 8
+B, H, Hkv = int(os.environ.get("B", "64")), int(os.environ.get("H", "32")), int(os.environ.get("HKV", "8"))
 VARS = [int(x) for x in os.environ.get("VARS", "0,1").split(",")]   # 0 auto, 1 VALU, 100+n = n KV splits
 int4 = "--kv8" not in sys.argv
 NL = int(os.environ.get("NL", "8"))   # KV pools rotated per launch (1 = Infinity-Cache-resident)
