@@ -121,7 +121,8 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     if (tl < 0) return;
     const float inv_sqrt = 0.08838834764831845f;
     const float qk_scale = inv_sqrt * 1.4426950408889634f;   // scores live in the log2 domain: exp2 everywhere
-    constexpr bool COMPACT = (G == 1 || G == 2 || G == 4);     // softmax on compacted lanes (see the page loop)
+    constexpr int GP = G <= 1 ? 1 : G <= 2 ? 2 : G <= 4 ? 4 : 8;   // group size padded to a power of two (lane mapping)
+    constexpr bool COMPACT = (GP <= 4);                            // softmax on compacted lanes (see the page loop)
     const int li = lane & 15, tg = lane >> 4;
     uint8_t* const s_kw = s_kv + wave * (PAGE_TOK * DHB);                // this wave's K page buffer
     uint8_t* const s_vw = s_kv + (NW + wave) * (PAGE_TOK * DHB);         // this wave's V page buffer
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         float se = 0.f, so = 0.f;   // sums over lo-form / hi-form operand positions of this lane's 32 dims
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const h8 x = *reinterpret_cast<const h8*>(&s_qp[COMPACT ? (li & (G - 1)) : (G == 8 ? (li & 7) : li)][32 * tg + 8 * w]);
+            const h8 x = *reinterpret_cast<const h8*>(&s_qp[li & (GP - 1)][32 * tg + 8 * w]);
             se += (float)x[0] + (float)x[1] + (float)x[4] + (float)x[5];
             so += (float)x[2] + (float)x[3] + (float)x[6] + (float)x[7];
         }
@@ -303,9 +304,9 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             // Only the columns li < G of the 16x16 results are real heads.  Instead of running the softmax on 16
             // values per lane with 3/4 of the lanes idle, tile t' moves to the lanes li = G t' + h (DPP row_shr inside
             // the 16-lane row): every lane li < 4G then owns 4 scores of head h = li % G, tokens 16t' + 4tg + r.
-            const int tq_raw = li_ / G;                   // tile owned by this lane; lanes li >= 4G stay idle (G < 4)
-            const bool lane_ok = G == 4 || tq_raw < 4;
-            const int tq = G == 4 ? tq_raw : min(tq_raw, 3);
+            const int tq_raw = li_ / GP;                   // tile owned by this lane; lanes li >= 4G stay idle (G < 4)
+            const bool lane_ok = GP == 4 || tq_raw < 4;
+            const int tq = GP == 4 ? tq_raw : min(tq_raw, 3);
             float (&sc)[4] = scc;
             const h4 ks = *(const __attribute__((address_space(3))) h4*)(ml + 32 * tq);
             const h4 kz = *(const __attribute__((address_space(3))) h4*)(ml + 2 * PAGE_TOK + 32 * tq);
@@ -314,14 +315,14 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
                 // (scalar copies first: __builtin_bit_cast of a vector-element lvalue reads element 0)
                 const float c0 = craw[0][r], c1 = craw[1][r], c2 = craw[2][r], c3 = craw[3][r];
                 int x = __builtin_bit_cast(int, c0);
-                if constexpr (G == 4) {   // whole 4-lane banks move: bank-masked DPP writes
+                if constexpr (GP == 4) {   // whole 4-lane banks move: bank-masked DPP writes
                     x = __builtin_amdgcn_update_dpp(x, __builtin_bit_cast(int, c1), 0x114, 0xF, 0x2, false);
                     x = __builtin_amdgcn_update_dpp(x, __builtin_bit_cast(int, c2), 0x118, 0xF, 0x4, false);
                     x = __builtin_amdgcn_update_dpp(x, __builtin_bit_cast(int, c3), 0x11C, 0xF, 0x8, false);
                 } else {
-                    const int s1 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c1), 0x110 + G, 0xF, 0xF, true);
-                    const int s2 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c2), 0x110 + 2 * G, 0xF, 0xF, true);
-                    const int s3 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c3), 0x110 + 3 * G, 0xF, 0xF, true);
+                    const int s1 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c1), 0x110 + GP, 0xF, 0xF, true);
+                    const int s2 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c2), 0x110 + 2 * GP, 0xF, 0xF, true);
+                    const int s3 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c3), 0x110 + 3 * GP, 0xF, 0xF, true);
                     x = tq_raw == 1 ? s1 : x;
                     x = tq_raw == 2 ? s2 : x;
                     x = tq_raw == 3 ? s3 : x;
@@ -338,14 +339,14 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (more) dma_k(page_addr(0, p + NW));
             float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-            if constexpr (G == 4) {
+            if constexpr (GP == 4) {
                 mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx),
                                                                                      0x124, 0xF, 0xF, true)));   // row_ror:4
                 mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx),
                                                                                      0x128, 0xF, 0xF, true)));   // row_ror:8
             } else {
-                mx = fmaxf(mx, xor_lane(mx, lid, G));
-                mx = fmaxf(mx, xor_lane(mx, lid, 2 * G));
+                mx = fmaxf(mx, xor_lane(mx, lid, GP));
+                mx = fmaxf(mx, xor_lane(mx, lid, 2 * GP));
             }
             mx = fmaxf(mx, xor_lane(mx, lid, 16));
             mx = fmaxf(mx, xor_lane(mx, lid, 32));
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] *= alpha;
             }
-        } else if constexpr (G == 8) {
+        } else if constexpr (GP == 8) {
             // two lane groups: li < 8 keeps tiles 0 and 2 of head li, li >= 8 takes tiles 1 and 3 of head li - 8 (row_shr:8
             // into the upper two 4-lane banks): 8 scores per lane, every lane busy
             const int tq2 = li_ >> 3;
@@ -446,9 +447,9 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         if (more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // V(p) landed (K(p+NW) may still be in flight)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (COMPACT) {
-            const int tq_raw = li_ / G;
-            const bool lane_ok = G == 4 || tq_raw < 4;
-            const int tq = G == 4 ? tq_raw : min(tq_raw, 3);
+            const int tq_raw = li_ / GP;
+            const bool lane_ok = GP == 4 || tq_raw < 4;
+            const int tq = GP == 4 ? tq_raw : min(tq_raw, 3);
             float (&sc)[4] = scc;
             const h4 vs = *(const __attribute__((address_space(3))) h4*)(ml + 4 * PAGE_TOK + 32 * tq);
             const h4 vz = *(const __attribute__((address_space(3))) h4*)(ml + 6 * PAGE_TOK + 32 * tq);
@@ -474,13 +475,13 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             // output columns are never read)
             pbv[0][0] = (u32)pk0;
             pbv[0][1] = (u32)pk1;
-            pbv[0][2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + G, 0xF, 0xF, true);
-            pbv[0][3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + G, 0xF, 0xF, true);
-            pbv[1][0] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + 2 * G, 0xF, 0xF, true);
-            pbv[1][1] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 2 * G, 0xF, 0xF, true);
-            pbv[1][2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + 3 * G, 0xF, 0xF, true);
-            pbv[1][3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 3 * G, 0xF, 0xF, true);
-        } else if constexpr (G == 8) {
+            pbv[0][2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + GP, 0xF, 0xF, true);
+            pbv[0][3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + GP, 0xF, 0xF, true);
+            pbv[1][0] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + 2 * GP, 0xF, 0xF, true);
+            pbv[1][1] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 2 * GP, 0xF, 0xF, true);
+            pbv[1][2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + 3 * GP, 0xF, 0xF, true);
+            pbv[1][3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 3 * GP, 0xF, 0xF, true);
+        } else if constexpr (GP == 8) {
             const int tq2 = li_ >> 3;
             const h4 vsa = *(const __attribute__((address_space(3))) h4*)(ml + 4 * PAGE_TOK + 32 * tq2);
             const h4 vza = *(const __attribute__((address_space(3))) h4*)(ml + 6 * PAGE_TOK + 32 * tq2);
@@ -575,18 +576,18 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     // (lane-derived values are re-derived here so that none of them has to survive the page loop in a register)
     const u32 lid2 = fresh_lane_id();
     const int li2 = lid2 & 15, tg2 = lid2 >> 4, tid2 = wave * 64 + (int)lid2;
-    if constexpr (G == 8) {   // two lane groups per head
+    if constexpr (GP == 8) {   // two lane groups per head
         l_part += xor_lane(l_part, lid2, 8);
         corr += xor_lane(corr, lid2, 8);
         psum += xor_lane(psum, lid2, 8);
     }
     if constexpr (COMPACT) {   // the head's tokens were spread over the lanes li = G t' + h as well
-        l_part += xor_lane(l_part, lid2, G);
-        l_part += xor_lane(l_part, lid2, 2 * G);
-        corr += xor_lane(corr, lid2, G);
-        corr += xor_lane(corr, lid2, 2 * G);
-        psum += xor_lane(psum, lid2, G);
-        psum += xor_lane(psum, lid2, 2 * G);
+        l_part += xor_lane(l_part, lid2, GP);
+        l_part += xor_lane(l_part, lid2, 2 * GP);
+        corr += xor_lane(corr, lid2, GP);
+        corr += xor_lane(corr, lid2, 2 * GP);
+        psum += xor_lane(psum, lid2, GP);
+        psum += xor_lane(psum, lid2, 2 * GP);
     }
     l_part += xor_lane(l_part, lid2, 16);
     l_part += xor_lane(l_part, lid2, 32);

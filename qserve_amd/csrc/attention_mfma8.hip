@@ -93,7 +93,8 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
     const int64_t* vtab = ktab + max_blocks;
     const float inv_sqrt = 0.08838834764831845f;
     const float qk_scale = inv_sqrt * 1.4426950408889634f;   // scores live in the log2 domain: exp2 everywhere
-    constexpr bool COMPACT = (G == 1 || G == 2 || G == 4);     // softmax on compacted lanes (see the page loop)
+    constexpr int GP = G <= 1 ? 1 : G <= 2 ? 2 : G <= 4 ? 4 : 8;   // group size padded to a power of two (lane mapping)
+    constexpr bool COMPACT = (GP <= 4);                            // softmax on compacted lanes (see the page loop)
     const int li = lane & 15, tg = lane >> 4;
     uint8_t* const s_kw = s_kv + wave * (PAGE_TOK * DHB);                // this wave's K page buffer
     uint8_t* const s_vw = s_kv + (NW + wave) * (PAGE_TOK * DHB);         // this wave's V page buffer
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const h8 x = *reinterpret_cast<const h8*>(&s_qp[COMPACT ? (li & (G - 1)) : (G == 8 ? (li & 7) : li)][32 * tg + 8 * w]);
+            const h8 x = *reinterpret_cast<const h8*>(&s_qp[li & (GP - 1)][32 * tg + 8 * w]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += (float)x[j];
         }
@@ -261,9 +262,9 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
         v4f scf[4];
         float sc8[8];                                   // G == 8: two lane groups, 8 scores per lane
         const int tq2 = li_ >> 3;
-        const int tq_raw = li_ / G;
-        const bool lane_ok = G == 4 || !COMPACT || tq_raw < 4;
-        const int tq = G == 4 ? tq_raw : min(tq_raw, 3);
+        const int tq_raw = li_ / GP;
+        const bool lane_ok = GP == 4 || !COMPACT || tq_raw < 4;
+        const int tq = GP == 4 ? tq_raw : min(tq_raw, 3);
         if constexpr (COMPACT) {
             float (&sc)[4] = scc;
             const h4 ks = LDS_AT(h4, ml + 32 * tq);
@@ -273,14 +274,14 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
                 // (scalar copies first: __builtin_bit_cast of a vector-element lvalue reads element 0)
                 const float c0 = craw[0][r], c1 = craw[1][r], c2 = craw[2][r], c3 = craw[3][r];
                 int x = __builtin_bit_cast(int, c0);
-                if constexpr (G == 4) {
+                if constexpr (GP == 4) {
                     x = __builtin_amdgcn_update_dpp(x, __builtin_bit_cast(int, c1), 0x114, 0xF, 0x2, false);
                     x = __builtin_amdgcn_update_dpp(x, __builtin_bit_cast(int, c2), 0x118, 0xF, 0x4, false);
                     x = __builtin_amdgcn_update_dpp(x, __builtin_bit_cast(int, c3), 0x11C, 0xF, 0x8, false);
                 } else {
-                    const int s1 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c1), 0x110 + G, 0xF, 0xF, true);
-                    const int s2 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c2), 0x110 + 2 * G, 0xF, 0xF, true);
-                    const int s3 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c3), 0x110 + 3 * G, 0xF, 0xF, true);
+                    const int s1 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c1), 0x110 + GP, 0xF, 0xF, true);
+                    const int s2 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c2), 0x110 + 2 * GP, 0xF, 0xF, true);
+                    const int s3 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c3), 0x110 + 3 * GP, 0xF, 0xF, true);
                     x = tq_raw == 1 ? s1 : x;
                     x = tq_raw == 2 ? s2 : x;
                     x = tq_raw == 3 ? s3 : x;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
                 for (int r = 0; r < 4; ++r)
                     if (16 * tq + 4 * tg_ + r >= valid) sc[r] = -3.0e38f;   // also discards NaN from garbage scales
             }
-        } else if constexpr (G == 8) {
+        } else if constexpr (GP == 8) {
             // two lane groups (see attention_mfma.hip): li < 8 keeps tiles 0 / 2 of head li, li >= 8 takes tiles 1 / 3
             const h4 ksa = LDS_AT(h4, ml + 32 * tq2);
             const h4 kza = LDS_AT(h4, ml + 2 * PAGE_TOK + 32 * tq2);
@@ -341,9 +342,9 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
             float mx;
             if constexpr (COMPACT) {
                 mx = fmaxf(fmaxf(scc[0], scc[1]), fmaxf(scc[2], scc[3]));
-                mx = fmaxf(mx, xor_lane(mx, lid, G));
-                mx = fmaxf(mx, xor_lane(mx, lid, 2 * G));
-            } else if constexpr (G == 8) {
+                mx = fmaxf(mx, xor_lane(mx, lid, GP));
+                mx = fmaxf(mx, xor_lane(mx, lid, 2 * GP));
+            } else if constexpr (GP == 8) {
                 mx = sc8[0];
 #pragma unroll
                 for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc8[j]);
@@ -393,13 +394,13 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
             const int pk1 = (int)(odd ? pack_h2(pp[3], pp[2]) : pack_h2(pp[2], pp[3]));
             pbv[0][0] = (u32)pk0;
             pbv[0][1] = (u32)pk1;
-            pbv[0][2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + G, 0xF, 0xF, true);
-            pbv[0][3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + G, 0xF, 0xF, true);
-            pbv[1][0] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + 2 * G, 0xF, 0xF, true);
-            pbv[1][1] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 2 * G, 0xF, 0xF, true);
-            pbv[1][2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + 3 * G, 0xF, 0xF, true);
-            pbv[1][3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 3 * G, 0xF, 0xF, true);
-        } else if constexpr (G == 8) {
+            pbv[0][2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + GP, 0xF, 0xF, true);
+            pbv[0][3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + GP, 0xF, 0xF, true);
+            pbv[1][0] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + 2 * GP, 0xF, 0xF, true);
+            pbv[1][1] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 2 * GP, 0xF, 0xF, true);
+            pbv[1][2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + 3 * GP, 0xF, 0xF, true);
+            pbv[1][3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 3 * GP, 0xF, 0xF, true);
+        } else if constexpr (GP == 8) {
             const h4 vsa = LDS_AT(h4, ml + 4 * PAGE_TOK + 32 * tq2);
             const h4 vza = LDS_AT(h4, ml + 6 * PAGE_TOK + 32 * tq2);
             const h4 vsb = LDS_AT(h4, ml + 4 * PAGE_TOK + 32 * (2 + tq2));
@@ -481,18 +482,18 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
 
     // ---- per-wave partials -> LDS.  Lane (head li, tg) holds out dims 8*(4tg + r) + e in acc[e][r] ---------------
     const u32 lid2 = fresh_lane_id();   // nothing lane-derived lives across the page loop
-    if constexpr (G == 8) {
+    if constexpr (GP == 8) {
         l_part += xor_lane(l_part, lid2, 8);
         corr += xor_lane(corr, lid2, 8);
         psum += xor_lane(psum, lid2, 8);
     }
     if constexpr (COMPACT) {
-        l_part += xor_lane(l_part, lid2, G);
-        l_part += xor_lane(l_part, lid2, 2 * G);
-        corr += xor_lane(corr, lid2, G);
-        corr += xor_lane(corr, lid2, 2 * G);
-        psum += xor_lane(psum, lid2, G);
-        psum += xor_lane(psum, lid2, 2 * G);
+        l_part += xor_lane(l_part, lid2, GP);
+        l_part += xor_lane(l_part, lid2, 2 * GP);
+        corr += xor_lane(corr, lid2, GP);
+        corr += xor_lane(corr, lid2, 2 * GP);
+        psum += xor_lane(psum, lid2, GP);
+        psum += xor_lane(psum, lid2, 2 * GP);
     }
     l_part += xor_lane(l_part, lid2, 16);
     l_part += xor_lane(l_part, lid2, 32);
