@@ -298,8 +298,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         u32 pbv[2][4];   // P'^T operands (B of P.V) of the two half pages
         float m_new;
         float scc[4];    // COMPACT: this lane's 4 scores
-        v4f scf[4];      // otherwise: 16 scores of head li
-        float sc8[8];    // G == 8: two lane groups, 8 scores per lane
+        float sc8[8];    // GP == 8: two lane groups, 8 scores per lane
         if constexpr (COMPACT) {
             // Only the columns li < G of the 16x16 results are real heads.  Instead of running the softmax on 16
             // values per lane with 3/4 of the lanes idle, tile t' moves to the lanes li = G t' + h (DPP row_shr inside
@@ -360,7 +359,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] *= alpha;
             }
-        } else if constexpr (GP == 8) {
+        } else {   // GP == 8
             // two lane groups: li < 8 keeps tiles 0 and 2 of head li, li >= 8 takes tiles 1 and 3 of head li - 8 (row_shr:8
             // into the upper two 4-lane banks): 8 scores per lane, every lane busy
             const int tq2 = li_ >> 3;
@@ -392,45 +391,6 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
 #pragma unroll
             for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc8[j]);
             mx = fmaxf(mx, xor_lane(mx, lid, 8));
-            mx = fmaxf(mx, xor_lane(mx, lid, 16));
-            mx = fmaxf(mx, xor_lane(mx, lid, 32));
-            m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            if (__any(alpha != 1.0f)) {
-                l_part *= alpha;
-                corr *= alpha;
-                psum *= alpha;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] *= alpha;
-            }
-        } else {
-            v4f (&sc)[4] = scf;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                // undo offsets, apply scale / zero point
-                const h4 ks = *(const __attribute__((address_space(3))) h4*)(ml + 2 * (16 * t));
-                const h4 kz = *(const __attribute__((address_space(3))) h4*)(ml + 2 * (PAGE_TOK + 16 * t));
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    sc[t][r] = ((float)ks[r] * qk_scale) * (craw[t][r] - (float)kz[r] * qsum);
-            }
-            if (!full) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (16 * t + 4 * tg_ + r >= valid) sc[t][r] = -3.0e38f;   // also discards NaN from garbage scales
-            }
-            // K buffer consumed -> request K(p+NW)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (more) dma_k(page_addr(0, p + NW));
-            // online softmax (per head = per li; the 4 tg lanes of a head hold 16 tokens each)
-            float mx = sc[0][0];
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][r]);
             mx = fmaxf(mx, xor_lane(mx, lid, 16));
             mx = fmaxf(mx, xor_lane(mx, lid, 32));
             m_new = fmaxf(m_run, mx);
@@ -481,7 +441,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             pbv[1][1] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 2 * GP, 0xF, 0xF, true);
             pbv[1][2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + 3 * GP, 0xF, 0xF, true);
             pbv[1][3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 3 * GP, 0xF, 0xF, true);
-        } else if constexpr (GP == 8) {
+        } else {   // GP == 8
             const int tq2 = li_ >> 3;
             const h4 vsa = *(const __attribute__((address_space(3))) h4*)(ml + 4 * PAGE_TOK + 32 * tq2);
             const h4 vza = *(const __attribute__((address_space(3))) h4*)(ml + 6 * PAGE_TOK + 32 * tq2);
@@ -514,30 +474,6 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             pbv[1][1] = (u32)pkb1;
             pbv[1][2] = (u32)__builtin_amdgcn_update_dpp(0, pkb0, 0x108, 0xF, 0xF, true);
             pbv[1][3] = (u32)__builtin_amdgcn_update_dpp(0, pkb1, 0x108, 0xF, 0xF, true);
-        } else {
-            v4f (&sc)[4] = scf;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const h4 vs = *(const __attribute__((address_space(3))) h4*)(ml + 2 * (2 * PAGE_TOK + 16 * t));
-                const h4 vz = *(const __attribute__((address_space(3))) h4*)(ml + 2 * (3 * PAGE_TOK + 16 * t));
-                float pp[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pe = __builtin_amdgcn_exp2f(sc[t][r] - m_new);   // 0 for masked tokens
-                    l_part += pe;
-                    float ps = (float)(_Float16)(pe * (float)vs[r]);
-                    float pz = ps * (float)vz[r];
-                    if (!full && 16 * t + 4 * tg_ + r >= valid) {
-                        ps = 0.f;
-                        pz = 0.f;
-                    }
-                    corr += pz;
-                    psum += ps;
-                    pp[r] = ps;
-                }
-                pbv[t >> 1][2 * (t & 1)] = pack_h2(pp[0], pp[1]);
-                pbv[t >> 1][2 * (t & 1) + 1] = pack_h2(pp[2], pp[3]);
-            }
         }
         // ---------------- P.V : two half pages of 32 tokens ----------------
 #pragma unroll

@@ -259,8 +259,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
         u32 pbv[2][4];
         float m_new;
         float scc[4];
-        v4f scf[4];
-        float sc8[8];                                   // G == 8: two lane groups, 8 scores per lane
+        float sc8[8];                                   // GP == 8: two lane groups, 8 scores per lane
         const int tq2 = li_ >> 3;
         const int tq_raw = li_ / GP;
         const bool lane_ok = GP == 4 || !COMPACT || tq_raw < 4;
@@ -294,7 +293,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
                 for (int r = 0; r < 4; ++r)
                     if (16 * tq + 4 * tg_ + r >= valid) sc[r] = -3.0e38f;   // also discards NaN from garbage scales
             }
-        } else if constexpr (GP == 8) {
+        } else {   // GP == 8
             // two lane groups (see attention_mfma.hip): li < 8 keeps tiles 0 / 2 of head li, li >= 8 takes tiles 1 / 3
             const h4 ksa = LDS_AT(h4, ml + 32 * tq2);
             const h4 kza = LDS_AT(h4, ml + 2 * PAGE_TOK + 32 * tq2);
@@ -317,22 +316,6 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
                     if (16 * (2 + tq2) + 4 * tg_ + r >= valid) sc8[4 + r] = -3.0e38f;
                 }
             }
-        } else {
-            v4f (&sc)[4] = scf;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const h4 ks = LDS_AT(h4, ml + 2 * (16 * t));
-                const h4 kz = LDS_AT(h4, ml + 2 * (PAGE_TOK + 16 * t));
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sc[t][r] = ((float)ks[r] * qk_scale) * (craw[t][r] - (float)kz[r] * qsum);
-            }
-            if (!full) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (16 * t + 4 * tg_ + r >= valid) sc[t][r] = -3.0e38f;   // also discards NaN from garbage scales
-            }
         }
         // K buffer consumed -> request K(p+NW)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -344,17 +327,11 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
                 mx = fmaxf(fmaxf(scc[0], scc[1]), fmaxf(scc[2], scc[3]));
                 mx = fmaxf(mx, xor_lane(mx, lid, GP));
                 mx = fmaxf(mx, xor_lane(mx, lid, 2 * GP));
-            } else if constexpr (GP == 8) {
+            } else {   // GP == 8
                 mx = sc8[0];
 #pragma unroll
                 for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc8[j]);
                 mx = fmaxf(mx, xor_lane(mx, lid, 8));
-            } else {
-                mx = scf[0][0];
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, scf[t][r]);
             }
             mx = fmaxf(mx, xor_lane(mx, lid, 16));
             mx = fmaxf(mx, xor_lane(mx, lid, 32));
@@ -400,7 +377,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
             pbv[1][1] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 2 * GP, 0xF, 0xF, true);
             pbv[1][2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + 3 * GP, 0xF, 0xF, true);
             pbv[1][3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 3 * GP, 0xF, 0xF, true);
-        } else if constexpr (GP == 8) {
+        } else {   // GP == 8
             const h4 vsa = LDS_AT(h4, ml + 4 * PAGE_TOK + 32 * tq2);
             const h4 vza = LDS_AT(h4, ml + 6 * PAGE_TOK + 32 * tq2);
             const h4 vsb = LDS_AT(h4, ml + 4 * PAGE_TOK + 32 * (2 + tq2));
@@ -433,29 +410,6 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
             pbv[1][1] = (u32)pkb1;
             pbv[1][2] = (u32)__builtin_amdgcn_update_dpp(0, pkb0, 0x108, 0xF, 0xF, true);
             pbv[1][3] = (u32)__builtin_amdgcn_update_dpp(0, pkb1, 0x108, 0xF, 0xF, true);
-        } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const h4 vs = LDS_AT(h4, ml + 2 * (2 * PAGE_TOK + 16 * t));
-                const h4 vz = LDS_AT(h4, ml + 2 * (3 * PAGE_TOK + 16 * t));
-                float pp[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pe = __builtin_amdgcn_exp2f(scf[t][r] - m_new);   // 0 for masked tokens
-                    l_part += pe;
-                    float ps = (float)(_Float16)(pe * (float)vs[r]);
-                    float pz = ps * (float)vz[r];
-                    if (!full && 16 * t + 4 * tg_ + r >= valid) {
-                        ps = 0.f;
-                        pz = 0.f;
-                    }
-                    corr += pz;
-                    psum += ps;
-                    pp[r] = ps;
-                }
-                pbv[t >> 1][2 * (t & 1)] = odd ? pack_h2(pp[1], pp[0]) : pack_h2(pp[0], pp[1]);
-                pbv[t >> 1][2 * (t & 1) + 1] = odd ? pack_h2(pp[3], pp[2]) : pack_h2(pp[2], pp[3]);
-            }
         }
         // ---------------- P.V : two half pages of 32 tokens ----------------
 #pragma unroll
