@@ -17,8 +17,13 @@
 //     so the inner loop spends 5 VALU ops per 8 cache elements instead of 13.
 //   * P.V on the same instruction: A = V^T: lane (8-dim group, kg) reads one dword per token for its 8 tokens;
 //     v_perm_b32 pairs byte bb of two tokens (0x00BB00AA) and the two nibble masks give the fp16 pairs of dims 2bb and
-//     2bb+1 (exact integers 0..15), i.e. the 8x8 transposition costs one perm per 4 elements.  B = P'^T with
+//     2bb+1 (offset form 1024 + n / 1024 + 16 n), i.e. the 8x8 transposition costs one perm per 4 elements.  B = P'^T with
 //     P' = fp16(p * vsc[tok]); the zero-point term sum_t P'_t vzr_t is subtracted from every output dim at the end.
+//   * softmax on compacted lanes: only G of the 16 result columns are heads, so the 4 score tiles of a page are moved
+//     (DPP row_shr, bank-masked) onto the idle lanes of their 16-lane row - 4 scores per lane for G <= 4 (tile t' on
+//     lanes G't' + h), 8 per lane for G = 5..8 (two lane groups) - the scale / zero-point / exp2 / P' work shrinks
+//     accordingly and the P' operands return with row_shl moves; scores live in the log2 domain; V operands stay in
+//     offset form like K and the offsets leave through sum(P') at the end.
 //   * cache integers are exact in fp16 and every accumulation is fp32: the result is the exact attention over the
 //     de-quantised cache up to fp16 rounding of q, P' and the output (parity bar 1e-3, tests/test_attention_gpu.py).
 #include "common.h"
