@@ -85,6 +85,13 @@ int qs_w8a8_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscal
  *   3100 + bits ... TIMING EXPERIMENTS ONLY (kernel parts switched off, results are wrong by design). */
 void qs_set_gemm_variant(int variant);
 
+/* Plan only: runs the W4A8 GEMM dispatcher for an (M, N, K) problem without touching the device and reports its choice
+ * in plan5 = {family, p0, p1, p2, p3}: family 1 = split-K kernel (m_tiles, waves, cross-block slices, xcd mapping),
+ * 2 = LDS-pair kernel, 3 = ring kernel (m_tiles, units, token blocks, K slices), 4 = tiled kernel (8 = 256-token tile,
+ * 4 = 128-token tile).  No reference counterpart: it makes the selection heuristics testable on a CPU-only machine
+ * (tests/test_dispatch_plan.py).  per_group: 0 = per-channel, 1 = per-group-128.  Honours qs_set_gemm_variant. */
+int qs_w4a8_gemm_plan(int per_group, int M, int N, int K, int* plan5);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Decode attention over the paged, quantised KV cache.
  * Replaces qserve_backend.fused_attention.single_query_attention

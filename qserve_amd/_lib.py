@@ -20,6 +20,7 @@ SIGNATURES = {
     "qs_w4a8_per_group_gemm_acc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_w8a8_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_set_gemm_variant": (None, [_i]),
+    "qs_w4a8_gemm_plan": (_i, [_i, _i, _i, _i, _vp]),
     "qs_set_attention_variant": (None, [_i]),
     "qs_single_query_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _i, _i, _i, _i,
                                        _i, _f, _i, _i, _i, _vp]),

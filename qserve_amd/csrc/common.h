@@ -53,6 +53,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // cvt.rni.sat.{s8,u8}.f32 equivalents: round-to-nearest-even then saturate (NaN -> 0)
+// Plan-only mode of the GEMM dispatcher (qs_w4a8_gemm_plan): the launchers record which kernel family / geometry they
+// were asked for and return without touching the device - the selection heuristics become testable on a CPU-only box.
+struct QsGemmPlan {
+    int active;   // 1 while qs_w4a8_gemm_plan runs the dispatcher
+    int family;   // 1 split-K, 2 LDS-pair, 3 ring, 4 tiled
+    int p[4];     // ring: m_tiles, units, token blocks, K slices; tiled: m-tiles per wave (8 = 256-token tile, 4 = 128);
+                  // split-K: m_tiles, waves, cross-block slices, xcd mapping
+};
+extern thread_local QsGemmPlan g_qs_plan;
+
 // butterfly exchange with an explicitly supplied lane id: __shfl_xor derives its own (loop-invariant) lane id, which the
 // register allocator then keeps alive - or spills - across a long loop
 __device__ __forceinline__ float xor_lane(float x, unsigned lid, int mask) {

@@ -296,6 +296,9 @@ __global__ __launch_bounds__(MT <= 2 ? 512 : 256, 2) void w4a8_gemm_splitk(const
 }
 
 int g_variant = -1;
+}  // namespace
+thread_local QsGemmPlan g_qs_plan = {0, 0, {0, 0, 0, 0}};
+namespace {
 
 // Split-K workspace (per device): int32 slabs + arrival counters, allocated lazily on first use (never while a
 // stream is being captured: a failed allocation simply disables cross-block split-K).
@@ -339,6 +342,11 @@ template <int MT, int MODE, int OUTK, int NSTAGE>
 int launch_splitk(const int8_t* A, const uint8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
                   const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K, int NW,
                   int S, bool xcd_map, hipStream_t stream) {
+    if (g_qs_plan.active) {
+        g_qs_plan.family = 1;
+        g_qs_plan.p[0] = MT, g_qs_plan.p[1] = NW, g_qs_plan.p[2] = S, g_qs_plan.p[3] = xcd_map ? 1 : 0;
+        return QS_OK;
+    }
     auto kern = w4a8_gemm_splitk<MT, MODE, OUTK, NSTAGE>;
     size_t smem = NW > 1 ? (size_t)NW * MT * 16 * 64 * sizeof(int) : 16;
     static size_t configured = 0;   // per instantiation
@@ -440,6 +448,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         *slabs = nullptr;
         *counters = nullptr;
         if (ks <= 1) return true;
+        if (g_qs_plan.active) return true;      // plan-only: assume the workspace exists
         Workspace* ws = get_workspace(stream);
         const size_t tiles = (size_t)units * mb;
         if (!ws || tiles > (size_t)ws->ncounters || tiles * ks * mt * 4096 > ws->slab_bytes) return false;
@@ -582,6 +591,19 @@ extern "C" void qs_set_gemm_variant(int variant) {
         return;
     }
     g_variant = variant;
+}
+
+extern "C" int qs_w4a8_gemm_plan(int per_group, int M, int N, int K, int* plan5) {
+    QS_REQUIRE(plan5, "w4a8 gemm plan: null output");
+    const int8_t* d8 = reinterpret_cast<const int8_t*>(uintptr_t(256));   // never dereferenced in plan-only mode
+    void* dv = reinterpret_cast<void*>(uintptr_t(256));
+    g_qs_plan = {1, 0, {0, 0, 0, 0}};
+    const int rc = per_group ? dispatch<1, 0>(d8, d8, d8, d8, dv, dv, nullptr, nullptr, dv, M, N, K, nullptr)
+                             : dispatch<0, 0>(d8, d8, nullptr, nullptr, dv, dv, dv, dv, dv, M, N, K, nullptr);
+    plan5[0] = g_qs_plan.family;
+    for (int i = 0; i < 4; ++i) plan5[1 + i] = g_qs_plan.p[i];
+    g_qs_plan.active = 0;
+    return rc;
 }
 
 extern "C" int qs_w4a8_per_chn_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscales,

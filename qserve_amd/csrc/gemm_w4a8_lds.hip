@@ -325,6 +325,11 @@ int launch_pair(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
 int qs_launch_gemm_pair(int mode, int outk, const int8_t* A, const uint8_t* W, const int8_t* zeros,
                         const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
                         const void* assums, void* out, int M, int N, int K, hipStream_t stream) {
+    if (g_qs_plan.active) {
+        g_qs_plan.family = 2;
+        g_qs_plan.p[0] = g_qs_plan.p[1] = g_qs_plan.p[2] = g_qs_plan.p[3] = 0;
+        return QS_OK;
+    }
     const int mtile = M <= 16 ? 1 : M <= 32 ? 2 : M <= 48 ? 3 : 4;
     if (mode == 0 && outk == 0 && mtile == 4 && g_tiled_dbg) {   // timing experiments only (wrong results by design)
         if (g_tiled_dbg == 1) return launch_pair<4, 0, 0, 1>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, stream);

@@ -462,6 +462,11 @@ int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, con
                         const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
                         const void* assums, void* out, int M, int N, int K, int mblocks, int ksplit, int* slabs,
                         unsigned* counters, hipStream_t stream) {
+    if (g_qs_plan.active) {
+        g_qs_plan.family = 3;
+        g_qs_plan.p[0] = mt, g_qs_plan.p[1] = wn, g_qs_plan.p[2] = mblocks, g_qs_plan.p[3] = ksplit;
+        return QS_OK;
+    }
 #define QS_R(MTV, WNV, MODEV, OUTV)                                                                                   \
     return ksplit > 1 ? launch_ring<MTV, WNV, MODEV, OUTV, true>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, \
                                                                  M, N, K, mblocks, ksplit, slabs, counters, stream)      \

@@ -363,6 +363,11 @@ int launch_tiled(const int8_t* A, const uint8_t* W, const int8_t* zeros, const i
 int qs_launch_gemm_tiled(int mode, int outk, const int8_t* A, const uint8_t* W, const int8_t* zeros,
                          const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
                          const void* assums, void* out, int M, int N, int K, int mtile, hipStream_t stream) {
+    if (g_qs_plan.active) {
+        g_qs_plan.family = 4;
+        g_qs_plan.p[0] = mtile == 0 ? (M > 128 ? 8 : 4) : mtile, g_qs_plan.p[1] = g_qs_plan.p[2] = g_qs_plan.p[3] = 0;
+        return QS_OK;
+    }
 #define QS_T(MTV, MODEV, OUTV) \
     return launch_tiled<MTV, MODEV, OUTV>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, stream)
     const bool big = mtile == 0 ? M > 128 : mtile == 8;

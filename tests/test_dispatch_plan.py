@@ -1,0 +1,78 @@
+"""The GEMM dispatcher's choices, checked without a GPU through the plan-only entry (qs_w4a8_gemm_plan).  These pin the
+measured heuristics of DESIGN.md 5.1 - a change here must come with new measurements (scripts/bench_gemm_shard.py)."""
+import pytest
+
+from qserve_amd.plan import gemm_plan
+
+
+def ring(mt, wn, mb, ks=1):
+    return dict(family="ring", m_tiles=mt, units=wn, token_blocks=mb, k_slices=ks)
+
+
+LLAMA3_DECODE = [   # bs = 64 step of BASELINE configs[1]
+    ((64, 6144, 4096), ring(2, 1, 2)),          # qkv: 192 workgroups of 32 tokens x 64 channels
+    ((64, 4096, 4096), ring(1, 1, 4)),          # o: 256 workgroups of 16 tokens
+    ((64, 28672, 4096), ring(4, 2, 1)),         # gate_up: 224 workgroups of 64 tokens x 128 channels
+    ((64, 4096, 14336), ring(2, 2, 2, 4)),      # down: 4 K slices meeting in the workspace
+]
+
+
+@pytest.mark.parametrize("shape,expect", LLAMA3_DECODE)
+def test_llama3_decode_shapes(shape, expect):
+    assert gemm_plan(*shape) == expect
+
+
+def test_small_batches_keep_whole_tokens_per_workgroup():
+    assert gemm_plan(16, 6144, 4096) == ring(1, 1, 1)
+    assert gemm_plan(16, 28672, 4096) == ring(2, 2, 1)        # padded 32-token tile, one round of 224 workgroups
+    assert gemm_plan(16, 4096, 14336) == ring(1, 1, 1, 4)     # under-filled grid: 4 K slices fill the chip
+    assert gemm_plan(32, 28672, 4096) == ring(2, 2, 1)
+
+
+def test_compute_bound_shapes_take_the_tiled_kernel():
+    assert gemm_plan(4096, 4096, 4096) == dict(family="tiled", tile_tokens=256)       # configs[0]
+    assert gemm_plan(65536, 28672, 4096) == dict(family="tiled", tile_tokens=256)     # prefill gate_up
+    assert gemm_plan(1024, 4096, 4096) == dict(family="tiled", tile_tokens=128)
+    assert gemm_plan(512, 3584, 4096)["family"] == "ring"                              # too few tiles: ring 64 x 128
+
+
+def test_tiled_kernel_needs_real_tokens():
+    """Regression: N/256 >= 192 alone used to select the 256-token tile at M = 64 (every N >= 49152 ran at 2 TB/s)."""
+    for N in (49152, 57344, 65536):
+        assert gemm_plan(64, N, 8192) == ring(4, 2, 1)
+    assert gemm_plan(191, 57344, 8192)["family"] == "ring"
+    assert gemm_plan(192, 57344, 8192) == dict(family="tiled", tile_tokens=256)
+
+
+def test_k_slices_only_for_under_filled_grids():
+    assert gemm_plan(64, 49152, 4096)["k_slices"] == 1
+    assert gemm_plan(64, 8192, 8192)["k_slices"] == 1
+    assert gemm_plan(64, 8192, 24576) == ring(4, 2, 1, 4)       # Qwen1.5-72B down_proj
+    assert gemm_plan(128, 4096, 14336) == ring(2, 2, 4, 2)
+
+
+def test_awkward_k_falls_back_or_uses_two_unit_workgroups():
+    assert gemm_plan(64, 4096, 11008)["family"] == "splitk"      # Llama-2-7B down_proj: 172 stages, 16-token workgroups win
+    assert gemm_plan(64, 5120, 13824)["family"] == "ring"        # Llama-2-13B down_proj: 216 stages = 4 groups x 54
+    assert gemm_plan(64, 4096, 512)["family"] == "splitk"        # short K at decode batch: fixed costs
+    assert gemm_plan(512, 4096, 1792)["family"] in ("ring", "pair")
+
+
+@pytest.mark.parametrize("tp", [2, 4, 8])
+def test_tensor_parallel_shards_use_the_ring_kernel(tp):
+    M = 64 * tp
+    for N, K in ((6144 // tp, 4096), (4096, 4096 // tp), (28672 // tp, 4096)):
+        assert gemm_plan(M, N, K)["family"] == "ring", (M, N, K)
+
+
+def test_per_group_follows_the_same_model():
+    assert gemm_plan(64, 4096, 14336, per_group=True) == ring(2, 2, 2, 4)
+    assert gemm_plan(128, 28672, 4096, per_group=True) == ring(4, 2, 2)
+    assert gemm_plan(2048, 4096, 4096, per_group=True)["family"] in ("tiled", "ring", "pair")
+
+
+def test_rejected_shapes_raise():
+    with pytest.raises(RuntimeError):
+        gemm_plan(64, 4000, 4096)       # N % 64
+    with pytest.raises(RuntimeError):
+        gemm_plan(64, 4096, 4000)       # K % 128
