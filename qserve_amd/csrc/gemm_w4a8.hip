@@ -485,7 +485,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         // ticket -> slab loads (one batch for mt <= 2, one per slice for mt = 4); K-sliced streams are charged 10 % extra
         auto seam = [](int ks, int mt) -> long {   // measured 3-7 us: three dependent system-scope round trips
             if (ks <= 1) return 0;
-            return ((ks == 2 ? 150L : 250L) + (mt > 2 ? 74L * (ks - 2) : 0)) * 1024;
+            return ((ks == 2 ? 150L : 250L) + (mt > 2 ? 40L * (ks - 2) : 0)) * 1024;
         };
         long best = -1;
         int bmt = 0, bwn = 0, bks = 1;
