@@ -118,6 +118,13 @@ int qs_single_query_attention(const void* q, const void* k, const void* v, const
  * 1 = VALU kernels, 100 + n = matrix-core kernels with exactly n KV splits. */
 void qs_set_attention_variant(int variant);
 
+/* Plan only (no device access, CPU-testable like qs_w4a8_gemm_plan): which decode attention kernel the dispatcher
+ * takes for (batch, heads, kv heads, page-table width, longest context) and how it splits the context:
+ * plan3 = {family, kv_splits, waves per workgroup}; family 1 = matrix-core KV4 kernel, 2 = matrix-core KV8 kernel,
+ * 3 = VALU kernel (page tables wider than 192 entries, or forced by qs_set_attention_variant(1)). */
+int qs_attention_plan(int batch, int num_heads, int num_kv_heads, int max_blocks, int timestep, int int4_kv_cache,
+                      int* plan3);
+
 /* Prefill KV writer.  Replaces qserve_backend.fused_attention.apply_bias_rope_update_kv_cache
  *   (kernels/csrc/fused_attention/update_kv_cache.h:11-27, update_kv_cache.cu:20-108).
  *   qkv half [num_tokens, (H+2Hkv)*Dh] modified in place (rotated q and k are written back);

@@ -22,6 +22,7 @@ SIGNATURES = {
     "qs_set_gemm_variant": (None, [_i]),
     "qs_w4a8_gemm_plan": (_i, [_i, _i, _i, _i, _vp]),
     "qs_set_attention_variant": (None, [_i]),
+    "qs_attention_plan": (_i, [_i, _i, _i, _i, _i, _i, _vp]),
     "qs_single_query_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _i, _i, _i, _i,
                                        _i, _f, _i, _i, _i, _vp]),
     "qs_apply_bias_rope_update_kv_cache": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i,

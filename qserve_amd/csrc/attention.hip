@@ -482,6 +482,14 @@ template <bool INT4>
 int launch_decode(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
                   const int64_t* kvp, const int* len, _Float16* out, int H, int Hkv, int64_t qs, int64_t kvs, int mb,
                   int timestep, float base) {
+    if (G < 1 || G > 8) {
+        qs_set_error("single_query_attention: num_heads/num_kv_heads = %d not in 1..8", G);
+        return QS_ENOSUP;
+    }
+    if (g_qs_attn_plan.active) {
+        g_qs_attn_plan.family = 3, g_qs_attn_plan.nsplit = 1, g_qs_attn_plan.waves = TPB / 64;
+        return QS_OK;
+    }
 #define QS_LAUNCH_G(GG)                                                                                            \
     hipLaunchKernelGGL((decode_attention_kernel<GG, INT4>), grid, dim3(TPB), 0, st, q, k, v, kvp, len, out, H, Hkv, \
                        qs, kvs, mb, timestep, base)
@@ -560,6 +568,24 @@ extern "C" int qs_single_query_attention(const void* q, const void* k, const voi
     return launch_decode<false>(G, grid, st, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v, kv_pointers,
                                 length_per_sample, (_Float16*)out, num_heads, num_kv_heads, q_stride0, kv_stride0,
                                 max_blocks, timestep, rotary_base);
+}
+
+thread_local QsAttnPlan g_qs_attn_plan = {0, 0, 0, 0};
+extern "C" int qs_attention_plan(int batch, int num_heads, int num_kv_heads, int max_blocks, int timestep,
+                                 int int4_kv_cache, int* plan3) {
+    QS_REQUIRE(plan3, "attention plan: null output");
+    void* d = reinterpret_cast<void*>(uintptr_t(256));          // never dereferenced in plan-only mode
+    g_qs_attn_plan = {1, 0, 0, 0};
+    const int rc = qs_single_query_attention(d, d, d, reinterpret_cast<const int64_t*>(d), nullptr, d, batch, num_heads,
+                                             num_kv_heads, 128, (int64_t)(num_heads + 2 * num_kv_heads) * 128,
+                                             (int64_t)(num_heads + 2 * num_kv_heads) * 128, max_blocks,
+                                             max_blocks * 64, 64, num_kv_heads * (int4_kv_cache ? 64 : 128), timestep,
+                                             128, 10000.f, 1, int4_kv_cache, 1, nullptr);
+    plan3[0] = g_qs_attn_plan.family;
+    plan3[1] = g_qs_attn_plan.nsplit;
+    plan3[2] = g_qs_attn_plan.waves;
+    g_qs_attn_plan.active = 0;
+    return rc;
 }
 
 extern "C" int qs_apply_bias_rope_update_kv_cache(void* qkv, const int32_t* seq_lens, const int32_t* padding_offset,

@@ -509,8 +509,12 @@ void qs_launch_attention_merge(const float* ws, _Float16* out, int H, int Hkv, i
 int qs_launch_decode_mfma8(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
                            const int64_t* kvp, const int* len, _Float16* out, int H, int Hkv, int64_t qs, int64_t kvs,
                            int mb, int timestep, float base, int max_pos, int force_split) {
+    if (G < 1 || G > 8) {
+        qs_set_error("single_query_attention: num_heads/num_kv_heads = %d not in 1..8", G);
+        return QS_ENOSUP;
+    }
     int tab_len = 0;
-    const float2* tab = qs_rope_table(base, max_pos, st, &tab_len);
+    const float2* tab = g_qs_attn_plan.active ? nullptr : qs_rope_table(base, max_pos, st, &tab_len);
     const int blocks = (int)(grid.x * grid.y);
     const int pages_max = (timestep + PAGE_TOK - 1) / PAGE_TOK;
     int nsplit = 1;
@@ -520,6 +524,10 @@ int qs_launch_decode_mfma8(int G, dim3 grid, hipStream_t st, const _Float16* q, 
         const int cap = pages_max / (2 * NW) > 1 ? pages_max / (2 * NW) : 1;
         if (nsplit > cap) nsplit = cap;
         if (nsplit > 32) nsplit = 32;
+    }
+    if (g_qs_attn_plan.active) {
+        g_qs_attn_plan.family = 2, g_qs_attn_plan.nsplit = nsplit, g_qs_attn_plan.waves = NW;
+        return QS_OK;
     }
     float* ws = nullptr;
     if (nsplit > 1) {

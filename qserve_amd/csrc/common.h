@@ -62,6 +62,12 @@ struct QsGemmPlan {
                   // split-K: m_tiles, waves, cross-block slices, xcd mapping
 };
 extern thread_local QsGemmPlan g_qs_plan;
+// the same for the decode attention dispatcher (qs_attention_plan): family 1 = matrix-core KV4, 2 = matrix-core KV8,
+// 3 = VALU kernel; nsplit = KV splits (workgroups per sequence and KV head), waves = waves per workgroup
+struct QsAttnPlan {
+    int active, family, nsplit, waves;
+};
+extern thread_local QsAttnPlan g_qs_attn_plan;
 
 // butterfly exchange with an explicitly supplied lane id: __shfl_xor derives its own (loop-invariant) lane id, which the
 // register allocator then keeps alive - or spills - across a long loop

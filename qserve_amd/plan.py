@@ -19,3 +19,14 @@ def gemm_plan(M, N, K, per_group=False):
     if fam == "splitk":
         return dict(family=fam, m_tiles=buf[1], waves=buf[2], slices=buf[3], xcd_map=bool(buf[4]))
     return dict(family=fam)
+
+
+ATTN_FAMILIES = {1: "mfma_kv4", 2: "mfma_kv8", 3: "valu"}
+
+
+def attention_plan(batch, num_heads, num_kv_heads, max_blocks, timestep, int4_kv_cache=True):
+    """-> dict(family, kv_splits, waves): the decode attention dispatcher's choice (`qs_attention_plan`)."""
+    buf = (C.c_int * 3)()
+    check(lib.qs_attention_plan(batch, num_heads, num_kv_heads, max_blocks, timestep, int(bool(int4_kv_cache)),
+                                C.cast(buf, C.c_void_p)), "attention plan")
+    return dict(family=ATTN_FAMILIES.get(buf[0], "none"), kv_splits=buf[1], waves=buf[2])

@@ -2,7 +2,7 @@
 measured heuristics of DESIGN.md 5.1 - a change here must come with new measurements (scripts/bench_gemm_shard.py)."""
 import pytest
 
-from qserve_amd.plan import gemm_plan
+from qserve_amd.plan import attention_plan, gemm_plan
 
 
 def ring(mt, wn, mb, ks=1):
@@ -76,3 +76,29 @@ def test_rejected_shapes_raise():
         gemm_plan(64, 4000, 4096)       # N % 64
     with pytest.raises(RuntimeError):
         gemm_plan(64, 4096, 4000)       # K % 128
+
+
+# ---- decode attention ----------------------------------------------------------------------------------------------
+def test_attention_headline_config_is_one_workgroup_per_sequence_and_kv_head():
+    assert attention_plan(64, 32, 8, 24, 1536) == dict(family="mfma_kv4", kv_splits=1, waves=8)     # 512 workgroups
+    assert attention_plan(128, 32, 8, 24, 1536)["kv_splits"] == 1
+
+
+def test_attention_small_batches_split_the_context():
+    p = attention_plan(8, 32, 8, 129, 8192, int4_kv_cache=False)        # BASELINE configs[4]: 64 workgroups -> split
+    assert p["family"] == "mfma_kv8" and p["waves"] == 4 and p["kv_splits"] == 8
+    p = attention_plan(1, 32, 8, 129, 8192)
+    assert p["family"] == "mfma_kv4" and 2 <= p["kv_splits"] <= 32
+    assert attention_plan(1, 32, 8, 4, 200)["kv_splits"] == 1          # too short to give every wave two pages
+
+
+def test_attention_wide_page_tables_take_the_valu_kernel():
+    assert attention_plan(4, 32, 8, 193, 12000)["family"] == "valu"
+    assert attention_plan(4, 32, 8, 192, 12000)["family"] == "mfma_kv4"
+
+
+def test_attention_rejects_bad_head_counts():
+    with pytest.raises(RuntimeError):
+        attention_plan(4, 30, 8, 24, 1000)          # heads not a multiple of kv heads
+    with pytest.raises(RuntimeError):
+        attention_plan(4, 72, 8, 24, 1000)          # group of 9 query heads
