@@ -338,7 +338,8 @@ class DecodeEngine:
         while True:
             g = torch.cuda.CUDAGraph()
             partial = None
-            with torch.cuda.graph(g, pool=pool):
+            # thread-local error mode: the process group's watchdog thread may poll its events while a piece is captured
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                 try:
                     partial = next(gen)
                 except StopIteration:
