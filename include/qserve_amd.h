@@ -15,10 +15,13 @@
  *   - return value: 0 on success, a negative QS_E* code on rejected arguments (nothing was launched),
  *     a positive hipError_t if the launch failed.  qs_last_error() returns a thread-local message;
  *   - callers own every tensor buffer (ownership rules of the reference, SURVEY.md 8(b) "Conventions"); the library
- *     keeps three small device scratch areas of its own (RoPE cos/sin table, split-KV partials, split-K slabs),
- *     allocated lazily on a first eager call and never while the stream is being captured into a graph.  The scratch
- *     areas are per device: launches that use them (split-KV attention, K-sliced GEMMs) must not run concurrently on
- *     different streams of one device (the reference's engine is single-stream).
+ *     keeps three small device scratch areas of its own (RoPE cos/sin tables, split-KV partials, split-K slabs).  Each
+ *     is a fixed-size allocation made lazily on a first EAGER call (never while the stream is being captured into a
+ *     graph: such a call runs the variant that needs no scratch) and is NEVER freed, moved or grown afterwards, so a
+ *     hipGraph that captured its address stays valid for the life of the process.  Requests beyond the fixed capacity
+ *     fall back to the un-split variants.  The scratch areas are per device (the CURRENT device of the calling thread):
+ *     launches that use them (split-KV attention, K-sliced GEMMs) must not run concurrently on different streams of
+ *     one device (the reference's engine is single-stream).
  */
 #ifndef QSERVE_AMD_H
 #define QSERVE_AMD_H
@@ -99,8 +102,11 @@ int qs_w4a8_gemm_plan(int per_group, int M, int N, int K, int* plan5);
  *   q   half [B,H,Dh]   view, element strides (q_stride0, Dh, 1)
  *   k,v half [B,Hkv,Dh] views, element strides (kv_stride0, Dh, 1)          (un-rotated new token)
  *   kv_pointers int64 [B,2,max_blocks]: device ADDRESSES of K pages ([:,0,:]) and V pages ([:,1,:])
- *   length_per_sample int32 [B] (may be NULL -> every sequence uses `timestep`): context length INCLUDING
- *                     the new token
+ *   length_per_sample int32 [B]: context length INCLUDING the new token, i.e. the new token sits at position
+ *                     length-1 and attends to length-1 cached tokens.  May be NULL: then, exactly as in the reference
+ *                     (decoderMaskedMultiheadAttentionTemplate.hpp:901, tlength = length_per_sample ?
+ *                     length_per_sample[bi]-1 : timestep), every sequence has `timestep` CACHED tokens and the new token
+ *                     is written at position `timestep`
  *   out half [B,H,Dh] contiguous (the reference returns torch::empty_like(q))
  * Page layout (kvCacheUtils.h:47-126): [Hkv][tokens_per_block][Dh'] data, then half scale[Hkv][tpb], then
  * half zero[Hkv][tpb]; Dh' = size_per_token / Hkv bytes.

@@ -15,6 +15,27 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class guard:
+    """Device guard (the reference wraps its attention launch in at::cuda::CUDAGuard, fused_attention.cpp:203; the
+    library's per-device scratch and the launch itself follow the CURRENT device): make the tensor's device current for
+    the duration of the call.  One cached current_device() query when the device already matches."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, t):
+        self.idx = t.device.index
+
+    def __enter__(self):
+        self.prev = torch.cuda.current_device()
+        if self.idx is not None and self.prev != self.idx:
+            torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.idx is not None and self.prev != self.idx:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
 def expect(t, dtype, name, contiguous=True):
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")

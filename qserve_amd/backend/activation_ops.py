@@ -1,7 +1,7 @@
 """Mirror of `qserve_backend.activation_ops` (kernels/csrc/activation.cpp:25-39)."""
 import torch
 
-from ._util import check, expect, lib, ptr, stream
+from ._util import check, expect, guard, lib, ptr, stream
 
 
 def silu_and_mul(out, input):
@@ -9,8 +9,9 @@ def silu_and_mul(out, input):
     expect(out, torch.float16, "out")
     expect(input, torch.float16, "input")
     d = input.size(-1) // 2
-    check(lib.qs_silu_and_mul(ptr(out), ptr(input), input.numel() // input.size(-1), d, stream()),
-          "activation_ops.silu_and_mul")
+    with guard(out):
+        check(lib.qs_silu_and_mul(ptr(out), ptr(input), input.numel() // input.size(-1), d, stream()),
+              "activation_ops.silu_and_mul")
 
 
 def gelu_new(out, input):

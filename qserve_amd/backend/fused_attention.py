@@ -1,7 +1,7 @@
 """Mirror of `qserve_backend.fused_attention` (kernels/csrc/fused_attention/fused_attention.cpp:243-256)."""
 import torch
 
-from ._util import check, expect, lib, ptr, stream
+from ._util import check, expect, guard, lib, ptr, stream
 
 
 def single_query_attention(q, k, v, kv_pointers, length_per_sample, alibi_slopes, memory_max_seqlen,
@@ -26,13 +26,14 @@ def single_query_attention(q, k, v, kv_pointers, length_per_sample, alibi_slopes
     if alibi_slopes is not None:
         raise RuntimeError("alibi_slopes is not supported (the W4A8KV4 models never pass it)")
     out = torch.empty((q.size(0), nheads, headdim), dtype=q.dtype, device=q.device)
-    check(lib.qs_single_query_attention(ptr(q), ptr(k), ptr(v), ptr(kv_pointers), ptr(length_per_sample), ptr(out),
-                                        batch, nheads, nheads_kv, headdim, q.stride(0), k.stride(0),
-                                        kv_pointers.size(-1), int(memory_max_seqlen), int(tokens_per_block),
-                                        int(size_per_token), int(timestep), int(rotary_embedding_dim),
-                                        float(rotary_base), int(bool(neox_rotary_style)), int(bool(int4_kv_cache)),
-                                        int(bool(kv_cache_with_zeros)), stream()),
-          "fused_attention.single_query_attention")
+    with guard(q):
+        check(lib.qs_single_query_attention(ptr(q), ptr(k), ptr(v), ptr(kv_pointers), ptr(length_per_sample), ptr(out),
+                                            batch, nheads, nheads_kv, headdim, q.stride(0), k.stride(0),
+                                            kv_pointers.size(-1), int(memory_max_seqlen), int(tokens_per_block),
+                                            int(size_per_token), int(timestep), int(rotary_embedding_dim),
+                                            float(rotary_base), int(bool(neox_rotary_style)), int(bool(int4_kv_cache)),
+                                            int(bool(kv_cache_with_zeros)), stream()),
+              "fused_attention.single_query_attention")
     return out
 
 
@@ -48,19 +49,21 @@ def apply_bias_rope_update_kv_cache(qkv, seq_lens, padding_offset, kv_pointers, 
     if kv_pointers is not None:
         expect(kv_pointers, torch.int64, "kv_pointers")
         mb = kv_pointers.size(-1)
-    check(lib.qs_apply_bias_rope_update_kv_cache(ptr(qkv), ptr(seq_lens), ptr(padding_offset), ptr(kv_pointers),
-                                                 qkv.size(0), seq_lens.size(0), mb, int(head_num), int(kv_head_num),
-                                                 int(seq_len), int(tokens_per_block), int(size_per_token),
-                                                 int(rotary_embedding_dim), float(rotary_embedding_base),
-                                                 int(rotary_embedding_max_positions), int(bool(neox_rotary_style)),
-                                                 int(bool(int4_kv_cache)), int(bool(kv_cache_with_zeros)), stream()),
-          "fused_attention.apply_bias_rope_update_kv_cache")
+    with guard(qkv):
+        check(lib.qs_apply_bias_rope_update_kv_cache(ptr(qkv), ptr(seq_lens), ptr(padding_offset), ptr(kv_pointers),
+                                                     qkv.size(0), seq_lens.size(0), mb, int(head_num), int(kv_head_num),
+                                                     int(seq_len), int(tokens_per_block), int(size_per_token),
+                                                     int(rotary_embedding_dim), float(rotary_embedding_base),
+                                                     int(rotary_embedding_max_positions), int(bool(neox_rotary_style)),
+                                                     int(bool(int4_kv_cache)), int(bool(kv_cache_with_zeros)), stream()),
+              "fused_attention.apply_bias_rope_update_kv_cache")
 
 
 def compute_padding_offsets(cu_seqlens, max_seqlen, tot_num_tokens):
     """input_metadata_helper.h:12-13 -> int32 [tot_num_tokens]."""
     expect(cu_seqlens, torch.int32, "cu_seqlens")
     out = torch.empty((int(tot_num_tokens),), dtype=torch.int32, device=cu_seqlens.device)
-    check(lib.qs_compute_padding_offsets(ptr(out), ptr(cu_seqlens), cu_seqlens.size(0) - 1, int(max_seqlen), stream()),
-          "fused_attention.compute_padding_offsets")
+    with guard(out):
+        check(lib.qs_compute_padding_offsets(ptr(out), ptr(cu_seqlens), cu_seqlens.size(0) - 1, int(max_seqlen), stream()),
+              "fused_attention.compute_padding_offsets")
     return out

@@ -4,7 +4,7 @@ Only the per-token overloads used by the W4A8 models are implemented (llama_w4a8
 layers/activation.py:57,70); the per-tensor overloads and the dequant ops belong to the W8A8 path."""
 import torch
 
-from ._util import check, expect, lib, ptr, stream
+from ._util import check, expect, guard, lib, ptr, stream
 
 
 def invoke_quant(out, input, scale):
@@ -15,8 +15,9 @@ def invoke_quant(out, input, scale):
     expect(input, torch.float16, "input")
     expect(scale, torch.float16, "scale")
     hidden = input.size(-1)
-    check(lib.qs_invoke_quant(ptr(out), ptr(input), 0, ptr(scale), input.numel() // hidden, hidden, stream()),
-          "fused_kernels.invoke_quant")
+    with guard(out):
+        check(lib.qs_invoke_quant(ptr(out), ptr(input), 0, ptr(scale), input.numel() // hidden, hidden, stream()),
+              "fused_kernels.invoke_quant")
 
 
 def invoke_quant_fuse_sum(out, input, input_sum, scale):
@@ -28,8 +29,9 @@ def invoke_quant_fuse_sum(out, input, input_sum, scale):
     expect(input_sum, torch.float16, "input_sum")
     expect(scale, torch.float16, "scale")
     hidden = input.size(-1)
-    check(lib.qs_invoke_quant(ptr(out), ptr(input), ptr(input_sum), ptr(scale), input.numel() // hidden, hidden,
-                              stream()), "fused_kernels.invoke_quant_fuse_sum")
+    with guard(out):
+        check(lib.qs_invoke_quant(ptr(out), ptr(input), ptr(input_sum), ptr(scale), input.numel() // hidden, hidden,
+                                  stream()), "fused_kernels.invoke_quant_fuse_sum")
 
 
 def invoke_dequant(*args, **kwargs):

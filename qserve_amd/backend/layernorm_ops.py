@@ -1,7 +1,7 @@
 """Mirror of `qserve_backend.layernorm_ops` (kernels/csrc/layernorm.cpp:47-72)."""
 import torch
 
-from ._util import check, expect, lib, ptr, stream
+from ._util import check, expect, guard, lib, ptr, stream
 
 
 def rms_norm(out, input, weight, epsilon, use_quant=False):
@@ -11,8 +11,9 @@ def rms_norm(out, input, weight, epsilon, use_quant=False):
     expect(input, torch.float16, "input")
     expect(weight, torch.float16, "weight")
     hidden = input.size(-1)
-    check(lib.qs_rms_norm(ptr(out), ptr(input), ptr(weight), float(epsilon), input.numel() // hidden, hidden,
-                          stream()), "layernorm_ops.rms_norm")
+    with guard(out):
+        check(lib.qs_rms_norm(ptr(out), ptr(input), ptr(weight), float(epsilon), input.numel() // hidden, hidden,
+                              stream()), "layernorm_ops.rms_norm")
 
 
 def rms_norm_general(out, input, weight, scaling, epsilon, use_per_token_quant=False):
@@ -24,8 +25,9 @@ def rms_norm_general(out, input, weight, scaling, epsilon, use_per_token_quant=F
     expect(weight, torch.float16, "weight")
     expect(scaling, torch.float16, "scaling")
     hidden = input.size(-1)
-    check(lib.qs_rms_norm_general(ptr(out), ptr(input), ptr(weight), 0, ptr(scaling), float(epsilon),
-                                  input.numel() // hidden, hidden, stream()), "layernorm_ops.rms_norm_general")
+    with guard(out):
+        check(lib.qs_rms_norm_general(ptr(out), ptr(input), ptr(weight), 0, ptr(scaling), float(epsilon),
+                                      input.numel() // hidden, hidden, stream()), "layernorm_ops.rms_norm_general")
 
 
 def rms_norm_general_fuse_sum(out, input, weight, input_sum, scaling, epsilon, use_per_token_quant=False):
@@ -38,9 +40,10 @@ def rms_norm_general_fuse_sum(out, input, weight, input_sum, scaling, epsilon, u
     expect(input_sum, torch.float16, "input_sum")
     expect(scaling, torch.float16, "scaling")
     hidden = input.size(-1)
-    check(lib.qs_rms_norm_general(ptr(out), ptr(input), ptr(weight), ptr(input_sum), ptr(scaling), float(epsilon),
-                                  input.numel() // hidden, hidden, stream()),
-          "layernorm_ops.rms_norm_general_fuse_sum")
+    with guard(out):
+        check(lib.qs_rms_norm_general(ptr(out), ptr(input), ptr(weight), ptr(input_sum), ptr(scaling), float(epsilon),
+                                      input.numel() // hidden, hidden, stream()),
+              "layernorm_ops.rms_norm_general_fuse_sum")
 
 
 def invoke_dequant_add_residual_rms_norm_quant(*args, **kwargs):

@@ -1,7 +1,7 @@
 """Mirror of `qserve_backend.qgemm_w4a8_per_chn` (kernels/csrc/qgemm/w4a8_per_chn/pybind.cpp:13-16)."""
 import torch
 
-from ._util import check, expect, lib, ptr, stream
+from ._util import check, expect, guard, lib, ptr, stream
 
 
 def gemm_forward_cuda(in_feats, kernel, wscales, ascales, w_szs, a_ssums, out_feats):
@@ -14,8 +14,9 @@ def gemm_forward_cuda(in_feats, kernel, wscales, ascales, w_szs, a_ssums, out_fe
     for n, t in (("wscales", wscales), ("ascales", ascales), ("w_szs", w_szs), ("a_ssums", a_ssums)):
         expect(t, torch.float16, n)
     M, N, K = out_feats.size(-2), out_feats.size(-1), in_feats.size(1)
-    check(lib.qs_w4a8_per_chn_gemm(ptr(in_feats), ptr(kernel), ptr(wscales), ptr(ascales), ptr(w_szs), ptr(a_ssums),
-                                   ptr(out_feats), M, N, K, stream()), "qgemm_w4a8_per_chn.gemm_forward_cuda")
+    with guard(in_feats):
+        check(lib.qs_w4a8_per_chn_gemm(ptr(in_feats), ptr(kernel), ptr(wscales), ptr(ascales), ptr(w_szs), ptr(a_ssums),
+                                       ptr(out_feats), M, N, K, stream()), "qgemm_w4a8_per_chn.gemm_forward_cuda")
 
 
 def gemm_forward_acc(in_feats, kernel, acc_out):
@@ -24,5 +25,6 @@ def gemm_forward_acc(in_feats, kernel, acc_out):
     expect(kernel, torch.int8, "kernel")
     expect(acc_out, torch.int32, "acc_out")
     M, N, K = acc_out.size(-2), acc_out.size(-1), in_feats.size(1)
-    check(lib.qs_w4a8_per_chn_gemm_acc(ptr(in_feats), ptr(kernel), ptr(acc_out), M, N, K, stream()),
-          "qgemm_w4a8_per_chn.gemm_forward_acc")
+    with guard(in_feats):
+        check(lib.qs_w4a8_per_chn_gemm_acc(ptr(in_feats), ptr(kernel), ptr(acc_out), M, N, K, stream()),
+              "qgemm_w4a8_per_chn.gemm_forward_acc")

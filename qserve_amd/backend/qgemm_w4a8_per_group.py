@@ -1,7 +1,7 @@
 """Mirror of `qserve_backend.qgemm_w4a8_per_group` (kernels/csrc/qgemm/w4a8_per_group/pybind.cpp:13-16)."""
 import torch
 
-from ._util import check, expect, lib, ptr, stream
+from ._util import check, expect, guard, lib, ptr, stream
 
 
 def gemm_forward_cuda(in_feats, kernel, zeros, scales_i8, wscales, ascales, out_feats):
@@ -14,9 +14,10 @@ def gemm_forward_cuda(in_feats, kernel, zeros, scales_i8, wscales, ascales, out_
     expect(ascales, torch.float16, "ascales")
     expect(out_feats, torch.float16, "out_feats")
     M, N, K = out_feats.size(-2), out_feats.size(-1), in_feats.size(1)
-    check(lib.qs_w4a8_per_group_gemm(ptr(in_feats), ptr(kernel), ptr(zeros), ptr(scales_i8), ptr(wscales),
-                                     ptr(ascales), ptr(out_feats), M, N, K, stream()),
-          "qgemm_w4a8_per_group.gemm_forward_cuda")
+    with guard(in_feats):
+        check(lib.qs_w4a8_per_group_gemm(ptr(in_feats), ptr(kernel), ptr(zeros), ptr(scales_i8), ptr(wscales),
+                                         ptr(ascales), ptr(out_feats), M, N, K, stream()),
+              "qgemm_w4a8_per_group.gemm_forward_cuda")
 
 
 def gemm_forward_acc(in_feats, kernel, zeros, scales_i8, acc_out):
@@ -27,5 +28,6 @@ def gemm_forward_acc(in_feats, kernel, zeros, scales_i8, acc_out):
     expect(scales_i8, torch.int8, "scales_i8")
     expect(acc_out, torch.int32, "acc_out")
     M, N, K = acc_out.size(-2), acc_out.size(-1), in_feats.size(1)
-    check(lib.qs_w4a8_per_group_gemm_acc(ptr(in_feats), ptr(kernel), ptr(zeros), ptr(scales_i8), ptr(acc_out), M, N,
-                                         K, stream()), "qgemm_w4a8_per_group.gemm_forward_acc")
+    with guard(in_feats):
+        check(lib.qs_w4a8_per_group_gemm_acc(ptr(in_feats), ptr(kernel), ptr(zeros), ptr(scales_i8), ptr(acc_out), M, N,
+                                             K, stream()), "qgemm_w4a8_per_group.gemm_forward_acc")

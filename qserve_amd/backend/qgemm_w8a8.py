@@ -1,7 +1,7 @@
 """Mirror of `qserve_backend.qgemm_w8a8` (kernels/csrc/qgemm/w8a8/pybind.cpp)."""
 import torch
 
-from ._util import check, expect, lib, ptr, stream
+from ._util import check, expect, guard, lib, ptr, stream
 
 
 def w8a8_gemm_forward_cuda(in_feats, kernel, wscales, ascales, out_feats):
@@ -12,5 +12,6 @@ def w8a8_gemm_forward_cuda(in_feats, kernel, wscales, ascales, out_feats):
     expect(ascales, torch.float16, "ascales")
     expect(out_feats, torch.float16, "out_feats")
     M, N, K = out_feats.size(-2), out_feats.size(-1), in_feats.size(1)
-    check(lib.qs_w8a8_gemm(ptr(in_feats), ptr(kernel), ptr(wscales), ptr(ascales), ptr(out_feats), M, N, K, stream()),
-          "qgemm_w8a8.w8a8_gemm_forward_cuda")
+    with guard(in_feats):
+        check(lib.qs_w8a8_gemm(ptr(in_feats), ptr(kernel), ptr(wscales), ptr(ascales), ptr(out_feats), M, N, K, stream()),
+              "qgemm_w8a8.w8a8_gemm_forward_cuda")

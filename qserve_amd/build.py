@@ -68,6 +68,10 @@ def build(force=False, verbose=True, extra=()):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
+    ap.add_argument("--debug-asm", action="store_true",
+                    help="keep the gfx950 assembly of every kernel next to the objects (qserve_amd/_build/*.s) and print "
+                         "the per-kernel register / LDS / scratch usage (implies --force)")
     a = ap.parse_args()
-    build(force=a.force)
+    extra = ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"] if a.debug_asm else []
+    build(force=a.force or a.debug_asm, extra=extra)
     sys.exit(0)

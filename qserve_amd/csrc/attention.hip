@@ -147,7 +147,7 @@ __global__ __launch_bounds__(TPB) void decode_attention_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hkv = blockIdx.x, b = blockIdx.y;
-    const int tl = (lengths ? lengths[b] : timestep) - 1;      // tlength, Template.hpp:901
+    const int tl = lengths ? lengths[b] - 1 : timestep;          // tlength, Template.hpp:901
     if (tl < 0) return;
     const int64_t* ktab = kv_pointers + (size_t)b * 2 * max_blocks;
     const int64_t* vtab = ktab + max_blocks;

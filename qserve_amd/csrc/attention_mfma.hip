@@ -122,7 +122,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         kpage0 = ktab[wave];
         vpage0 = vtab[wave];
     }
-    const int tl = (lengths ? lengths[b] : timestep) - 1;
+    const int tl = lengths ? lengths[b] - 1 : timestep;   // tlength, Template.hpp:901
     if (tl < 0) return;
     const float inv_sqrt = 0.08838834764831845f;
     const float qk_scale = inv_sqrt * 1.4426950408889634f;   // scores live in the log2 domain: exp2 everywhere
@@ -609,9 +609,11 @@ struct RopeTable {
     float2* tab = nullptr;
     int len = 0;
     float base = 0.f;
-    bool failed = false;
 };
-RopeTable g_rope[16];
+// Tables are keyed by (device, base) and NEVER freed or replaced once handed out: a captured hipGraph may hold their
+// address.  A longer table for the same base is a new entry (the old one stays alive for the graphs that captured it).
+constexpr int ROPE_SLOTS = 8;
+RopeTable g_rope[16][ROPE_SLOTS];
 
 }  // namespace
 
@@ -621,41 +623,43 @@ const float2* qs_rope_table(float base, int max_pos, hipStream_t st, int* len_ou
     int dev = 0;
     *len_out = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    RopeTable& r = g_rope[dev];
     if (max_pos > 32768) max_pos = 32768;
-    if (r.tab && r.base == base && r.len >= max_pos) {
-        *len_out = r.len;
-        return r.tab;
+    if (max_pos <= 0) return nullptr;
+    RopeTable* slot = nullptr;
+    for (int i = 0; i < ROPE_SLOTS; ++i) {
+        RopeTable& r = g_rope[dev][i];
+        if (r.tab && r.base == base && r.len >= max_pos) {
+            *len_out = r.len;
+            return r.tab;
+        }
+        if (!r.tab && !slot) slot = &r;
     }
+    if (!slot) return nullptr;   // every slot taken by other (base, length) pairs: callers compute in-kernel
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
         (void)hipGetLastError();
         return nullptr;
-    }
-    if (r.tab) {
-        (void)hipFree(r.tab);
-        r.tab = nullptr;
-        r.len = 0;
     }
     void* p = nullptr;
     if (hipMalloc(&p, (size_t)max_pos * 64 * sizeof(float2)) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
-    r.tab = reinterpret_cast<float2*>(p);
-    r.len = max_pos;
-    r.base = base;
-    hipLaunchKernelGGL(rope_table_kernel, dim3((max_pos * 64 + 255) / 256), dim3(256), 0, st, r.tab, max_pos, base);
-    *len_out = r.len;
-    return r.tab;
+    slot->tab = reinterpret_cast<float2*>(p);
+    slot->len = max_pos;
+    slot->base = base;
+    hipLaunchKernelGGL(rope_table_kernel, dim3((max_pos * 64 + 255) / 256), dim3(256), 0, st, slot->tab, max_pos, base);
+    *len_out = slot->len;
+    return slot->tab;
 }
 
-// Library-managed split-KV workspace (per device, grow-only).  nullptr while a capture is running and the buffer is
-// too small (callers then run un-split).
+// Library-managed split-KV workspace: ONE fixed-size allocation per device, made on the first eager call that needs
+// it and never freed, moved or grown (captured hipGraphs keep its address).  Requests beyond its capacity, or a first
+// request that arrives while the stream is being captured, return nullptr: callers then run with fewer / no splits.
 namespace {
+constexpr size_t SPLIT_WS_BYTES = (size_t)32 << 20;   // heuristic needs < 1024 (workgroup, split) pairs x 8 heads x 520 B
 struct SplitWs {
     float* p = nullptr;
-    size_t bytes = 0;
 };
 SplitWs g_ws[16];
 }  // namespace
@@ -666,29 +670,23 @@ void qs_launch_attention_merge(const float* ws, _Float16* out, int H, int Hkv, i
 }
 float* qs_split_workspace(size_t bytes, hipStream_t st) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (bytes > SPLIT_WS_BYTES || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     SplitWs& w = g_ws[dev];
-    if (w.p && w.bytes >= bytes) return w.p;
+    if (w.p) return w.p;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
         (void)hipGetLastError();
         return nullptr;
     }
-    if (w.p) {
-        (void)hipStreamSynchronize(st);       // a previous launch on this stream may still read the old buffer
-        (void)hipFree(w.p);
-        w.p = nullptr;
-        w.bytes = 0;
-    }
     void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) {
+    if (hipMalloc(&p, SPLIT_WS_BYTES) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
     w.p = reinterpret_cast<float*>(p);
-    w.bytes = bytes;
     return w.p;
 }
+size_t qs_split_workspace_capacity() { return SPLIT_WS_BYTES; }
 
 // called from attention.hip's dispatcher for KV4.  force_split: 0 = heuristic, n > 0 = exactly n splits (tests)
 int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
@@ -717,7 +715,9 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
     }
     float* ws = nullptr;
     if (nsplit > 1) {
-        ws = qs_split_workspace((size_t)blocks * nsplit * G * (DH + 2) * sizeof(float), st);
+        const size_t per_split = (size_t)blocks * G * (DH + 2) * sizeof(float);
+        if (per_split * nsplit > qs_split_workspace_capacity()) nsplit = (int)(qs_split_workspace_capacity() / per_split);
+        ws = nsplit > 1 ? qs_split_workspace(per_split * nsplit, st) : nullptr;
         if (!ws) nsplit = 1;
     }
     grid.z = nsplit;

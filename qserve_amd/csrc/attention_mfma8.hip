@@ -87,7 +87,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hkv = blockIdx.x, b = blockIdx.y, z = blockIdx.z;
-    const int tl = (lengths ? lengths[b] : timestep) - 1;
+    const int tl = lengths ? lengths[b] - 1 : timestep;   // tlength, Template.hpp:901
     if (tl < 0) return;
     const int64_t* ktab = kv_pointers + (size_t)b * 2 * max_blocks;
     const int64_t* vtab = ktab + max_blocks;
@@ -503,6 +503,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
 // shared with attention_mfma.hip
 const float2* qs_rope_table(float base, int max_pos, hipStream_t st, int* len_out);
 float* qs_split_workspace(size_t bytes, hipStream_t st);
+size_t qs_split_workspace_capacity();
 void qs_launch_attention_merge(const float* ws, _Float16* out, int H, int Hkv, int G, int nsplit, int batch, hipStream_t st);
 
 // called from attention.hip's dispatcher for KV8.  force_split: 0 = heuristic, n > 0 = exactly n splits (tests)
@@ -531,7 +532,9 @@ int qs_launch_decode_mfma8(int G, dim3 grid, hipStream_t st, const _Float16* q, 
     }
     float* ws = nullptr;
     if (nsplit > 1) {
-        ws = qs_split_workspace((size_t)blocks * nsplit * G * (DH + 2) * sizeof(float), st);
+        const size_t per_split = (size_t)blocks * G * (DH + 2) * sizeof(float);
+        if (per_split * nsplit > qs_split_workspace_capacity()) nsplit = (int)(qs_split_workspace_capacity() / per_split);
+        ws = nsplit > 1 ? qs_split_workspace(per_split * nsplit, st) : nullptr;
         if (!ws) nsplit = 1;
     }
     grid.z = nsplit;

@@ -35,6 +35,14 @@ static inline int qs_launch_status(const char* what) {
     return QS_OK;
 }
 
+// per-device state (function attributes, scratch areas) is indexed by the CURRENT device of the calling thread
+constexpr int QS_MAX_DEVICES = 16;
+static inline int qs_device_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= QS_MAX_DEVICES) d = 0;
+    return d;
+}
+
 // wave64 reductions -------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

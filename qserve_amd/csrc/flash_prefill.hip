@@ -249,7 +249,8 @@ extern "C" int qs_flash_attn_varlen_fwd(const void* q, const void* k, const void
     const float scale_log2 = softmax_scale * 1.4426950408889634f;
     dim3 grid((max_seqlen_q + BM - 1) / BM, num_heads, batch);
     constexpr int SMEM = 2 * KS_BYTES + 2 * VT_BYTES;
-    static bool configured = false;
+    static bool configured_dev[QS_MAX_DEVICES] = {};   // the attribute belongs to the (kernel, device) pair
+    bool& configured = configured_dev[qs_device_slot()];
     if (!configured) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_fwd_kernel<true>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);

@@ -349,7 +349,8 @@ int launch_splitk(const int8_t* A, const uint8_t* W, const int8_t* zeros, const 
     }
     auto kern = w4a8_gemm_splitk<MT, MODE, OUTK, NSTAGE>;
     size_t smem = NW > 1 ? (size_t)NW * MT * 16 * 64 * sizeof(int) : 16;
-    static size_t configured = 0;   // per instantiation
+    static size_t configured_dev[QS_MAX_DEVICES] = {};   // per instantiation and device
+    size_t& configured = configured_dev[qs_device_slot()];
     if (smem > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -302,7 +302,8 @@ int launch_pair(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
                 hipStream_t stream) {
     auto kern = w4a8_gemm_pair<MT, MODE, OUTK, DBG>;
     const size_t smem = (size_t)2 * NS * (16 * MT * 128) + 4 * NS * WBYTES + 4 * NS * 256;
-    static bool configured = false;
+    static bool configured_dev[QS_MAX_DEVICES] = {};   // the attribute belongs to the (kernel, device) pair
+    bool& configured = configured_dev[qs_device_slot()];
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

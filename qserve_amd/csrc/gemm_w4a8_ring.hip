@@ -434,7 +434,8 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
     size_t smem = (size_t)KG * ns * GSTAGE;
     const size_t tail = (size_t)(KG - 1) * WN * MT * 4 * 4 * 64 * 4 + (size_t)WN * 16 * MT * 144;   // reduction + staging
     if (smem < tail) smem = tail;
-    static size_t configured = 0;
+    static size_t configured_dev[QS_MAX_DEVICES] = {};   // per instantiation and device
+    size_t& configured = configured_dev[qs_device_slot()];
     if (configured < smem) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));

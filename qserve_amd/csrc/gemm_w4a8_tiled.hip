@@ -338,7 +338,8 @@ int launch_tiled(const int8_t* A, const uint8_t* W, const int8_t* zeros, const i
     size_t smem = (size_t)NS * (BM * 64 + WSTAGE + 512);
     const size_t stage_out = (size_t)8 * 16 * MT * 144;          // epilogue staging aliases the rings
     if (smem < stage_out) smem = stage_out;
-    static bool configured = false;
+    static bool configured_dev[QS_MAX_DEVICES] = {};   // the attribute belongs to the (kernel, device) pair
+    bool& configured = configured_dev[qs_device_slot()];
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

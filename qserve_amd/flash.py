@@ -5,7 +5,7 @@ import math
 
 import torch
 
-from .backend._util import check, lib, ptr, stream
+from .backend._util import check, guard, lib, ptr, stream
 
 
 def _expect_f16(t, name):
@@ -37,8 +37,9 @@ def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, ma
         raise RuntimeError("flash_attn_varlen_func: cu_seqlens_q / cu_seqlens_k describe different batch sizes")
     out = torch.empty((q.size(0), q.size(1), 128), dtype=torch.float16, device=q.device)
     scale = 1.0 / math.sqrt(128.0) if softmax_scale is None else float(softmax_scale)
-    check(lib.qs_flash_attn_varlen_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(cu_seqlens_q), ptr(cu_seqlens_k), batch,
-                                       q.size(1), k.size(1), 128, q.stride(0), k.stride(0), v.stride(0), out.stride(0),
-                                       int(max_seqlen_q), int(max_seqlen_k), scale, 1 if causal else 0, stream()),
-          "flash_attn_varlen_func")
+    with guard(q):
+        check(lib.qs_flash_attn_varlen_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(cu_seqlens_q), ptr(cu_seqlens_k), batch,
+                                           q.size(1), k.size(1), 128, q.stride(0), k.stride(0), v.stride(0), out.stride(0),
+                                           int(max_seqlen_q), int(max_seqlen_k), scale, 1 if causal else 0, stream()),
+              "flash_attn_varlen_func")
     return out

@@ -8,7 +8,7 @@ they exist because at decode batch sizes each row kernel is a fixed ~5 us latenc
 """
 import torch
 
-from .backend._util import check, expect, lib, ptr, stream
+from .backend._util import check, expect, guard, lib, ptr, stream
 
 
 def add_residual_rms_norm_general(out, hidden, delta, weight, scaling, epsilon, input_sum=None):
@@ -23,10 +23,11 @@ def add_residual_rms_norm_general(out, hidden, delta, weight, scaling, epsilon, 
     if hidden.shape != delta.shape:
         raise RuntimeError(f"add_residual_rms_norm_general: hidden {tuple(hidden.shape)} vs delta {tuple(delta.shape)}")
     hid = hidden.size(-1)
-    check(lib.qs_add_residual_rms_norm_general(ptr(out), ptr(hidden), ptr(delta), ptr(weight),
-                                               ptr(input_sum) if input_sum is not None else 0, ptr(scaling),
-                                               float(epsilon), hidden.numel() // hid, hid, stream()),
-          "fused.add_residual_rms_norm_general")
+    with guard(out):
+        check(lib.qs_add_residual_rms_norm_general(ptr(out), ptr(hidden), ptr(delta), ptr(weight),
+                                                   ptr(input_sum) if input_sum is not None else 0, ptr(scaling),
+                                                   float(epsilon), hidden.numel() // hid, hid, stream()),
+              "fused.add_residual_rms_norm_general")
 
 
 def silu_and_mul_quant(out, input, scale, input_sum=None):
@@ -39,5 +40,6 @@ def silu_and_mul_quant(out, input, scale, input_sum=None):
     d = input.size(-1) // 2
     if out.size(-1) != d:
         raise RuntimeError(f"silu_and_mul_quant: out width {out.size(-1)} != {d}")
-    check(lib.qs_silu_and_mul_quant(ptr(out), ptr(input), ptr(input_sum) if input_sum is not None else 0, ptr(scale),
-                                    input.numel() // (2 * d), d, stream()), "fused.silu_and_mul_quant")
+    with guard(out):
+        check(lib.qs_silu_and_mul_quant(ptr(out), ptr(input), ptr(input_sum) if input_sum is not None else 0, ptr(scale),
+                                        input.numel() // (2 * d), d, stream()), "fused.silu_and_mul_quant")

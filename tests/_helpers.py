@@ -38,3 +38,44 @@ def int_matmul_torch(A, W):
     for k0 in range(0, K, step):
         acc += (A[:, k0:k0 + step].float() @ W[:, k0:k0 + step].float().T).round().to(torch.int64)
     return acc
+
+
+def pack_qweight_torch(q):
+    """uint4 values q [N,K] (torch, any device) -> reference packed int8 [N,K/2]: the torch twin of
+    oracle.w4a8.pack_qweight (w4a8_linear.py:196-226), for problem sizes where numpy packing would take minutes.
+    tests/test_gemm_gpu.py cross-checks it against the oracle packer."""
+    N, K = q.shape
+    w = q.to(torch.uint8).reshape(N // 32, 2, 2, 8, K // 32, 2, 4, 4)        # n32 a b c k32 d e f
+    w = w.permute(0, 4, 3, 6, 5, 2, 7, 1)                                     # n32 k32 c e d b f a
+    return ((w[..., 1] << 4) | w[..., 0]).contiguous().reshape(N, K // 2).view(torch.int8)
+
+
+def permute_group_meta_torch(x):
+    """[K/G, N] natural channel order -> the reference's per-32 storage order (oracle.w4a8.permute_group_meta)."""
+    ng, N = x.shape
+    return x.reshape(ng, N // 32, 4, 8).permute(0, 1, 3, 2).contiguous().reshape(ng, N)
+
+
+def per_group_problem_torch(M, N, K, device, seed=0):
+    """QoQ-style per-group problem inside the protective range, generated on the device (same recipe as
+    oracle.synth.per_group_problem(valid=True)).  Returns tensors + the dequantised int8 weights w8 [N,K]."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    ng = K // 128
+    A = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=device, generator=g)
+    w8 = torch.randint(-119, 120, (N, ng, 128), device=device, generator=g, dtype=torch.int32)
+    mx, mn = w8.amax(dim=2), w8.amin(dim=2)
+    s2 = torch.clamp(torch.ceil((mx - mn).float() / 15.0), min=1).to(torch.int32)
+    z = torch.clamp(torch.round(-mn.float() / s2.float()), 0, 15).to(torch.int32)
+    q = torch.clamp(torch.round(w8.float() / s2[..., None].float()) + z[..., None], 0, 15).to(torch.int32)
+    lo = torch.clamp(torch.ceil(-128.0 / s2.float() + z.float()), 0, 15).to(torch.int32)
+    hi = torch.minimum(torch.clamp(torch.floor(127.0 / s2.float() + z.float()), 0, 15).to(torch.int32), 255 // s2)
+    q = torch.minimum(torch.maximum(q, lo[..., None]), hi[..., None])
+    deq = (q - z[..., None]) * s2[..., None]
+    assert int((q * s2[..., None]).max()) <= 255 and int(deq.min()) >= -128 and int(deq.max()) <= 127
+    qweight = pack_qweight_torch(q.reshape(N, K))
+    s2_scales = permute_group_meta_torch(s2.t().contiguous()).to(torch.int8)
+    s2_zeros = permute_group_meta_torch((-z * s2).t().contiguous()).to(torch.int8)     # wraps mod 256 like the packer
+    wscales = (torch.rand((N,), device=device, generator=g) * 0.018 + 0.002).half()
+    ascales = (torch.rand((M,), device=device, generator=g) * 0.045 + 0.005).half()
+    return dict(A=A, qweight=qweight, s2_scales=s2_scales, s2_zeros=s2_zeros, wscales=wscales, ascales=ascales,
+                w8=deq.reshape(N, K).to(torch.int8))

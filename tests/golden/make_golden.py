@@ -95,8 +95,60 @@ def make_per_group(mod, N, K, seed, G=128):
     )
 
 
+def sha(t):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest()
+
+
+def full_size_inputs(kind, N, K, seed):
+    """Seeded inputs of the full-size digests; shared with tests/test_oracle_golden.py (which re-creates them from the
+    seed - torch's CPU generator is deterministic for a given torch build - instead of storing 8 MB of nibbles)."""
+    g = torch.Generator().manual_seed(seed)
+    if kind == "per_chn":
+        q = torch.randint(0, 16, (N, K), generator=g)
+        z = torch.randint(0, 16, (N,), generator=g)
+        s1 = (torch.rand((N,), generator=g) * 0.018 + 0.002).to(torch.float16)
+        return dict(q=q, z=z, s1=s1)
+    ng = K // 128
+    s2 = torch.randint(1, 9, (N, ng), generator=g)
+    z = torch.randint(0, 16, (N, ng), generator=g)
+    q = torch.randint(0, 16, (N, ng, 128), generator=g)
+    lo = torch.ceil((-128.0 / s2.float()) + z.float()).clamp(0, 15).long()
+    hi = torch.floor((127.0 / s2.float()) + z.float()).clamp(0, 15).long()
+    q = torch.maximum(torch.minimum(q, hi[..., None]), lo[..., None])
+    s1 = (torch.rand((N,), generator=g) * 0.018 + 0.002).to(torch.float16)
+    return dict(q=q.reshape(N, K), z=z, s2=s2, s1=s1)
+
+
+def make_full_size_digests(mod):
+    """One Llama-3-8B GEMM shape (o_proj, 4096 x 4096) per mode through the reference's from_linear: only SHA-256
+    digests of its outputs are stored (the inputs are re-created from the seed by the test)."""
+    import json
+    N = K = 4096
+    out = {"shape": [N, K], "torch": torch.__version__, "entries": {}}
+    i = full_size_inputs("per_chn", N, K, 11)
+    lin = torch.nn.Linear(K, N, bias=False)
+    lin.weight.data = (i["q"] - i["z"][:, None]).float() * i["s1"].float()[:, None]
+    ql = mod.W4A8OF16LinearDynamicInputScale.from_linear(lin, 4, -1, s1_scale=i["s1"].clone(),
+                                                         zeros=i["z"].clone().to(torch.int8))
+    out["entries"]["per_chn"] = dict(seed=11, qweight=sha(ql.qweight.numpy()), s1_scales=sha(ql.s1_scales.numpy()),
+                                     s1_szeros=sha(ql.s1_szeros.numpy()))
+    i = full_size_inputs("per_group", N, K, 12)
+    w8 = (i["q"].reshape(N, K // 128, 128) - i["z"][..., None]) * i["s2"][..., None]
+    lin = torch.nn.Linear(K, N, bias=False)
+    lin.weight.data = w8.reshape(N, K).float() * i["s1"].float()[:, None]
+    ql = mod.W4A8OF16LinearDynamicInputScale.from_linear(lin, 4, 128, s1_scale=i["s1"].clone(),
+                                                         s2_scale=i["s2"].clone().float(), zeros=i["z"].clone().float())
+    out["entries"]["per_group"] = dict(seed=12, qweight=sha(ql.qweight.numpy()), s1_scales=sha(ql.s1_scales.numpy()),
+                                       s2_scales=sha(ql.s2_scales.numpy()), s2_zeros=sha(ql.s2_zeros.numpy()))
+    with open(os.path.join(OUT, "w4a8_pack_llama3_8b_o_proj_digests.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def main():
     mod = load_reference_module()
+    make_full_size_digests(mod)
+    np.savez_compressed(os.path.join(OUT, "w4a8_pack_per_chn_128x512.npz"), **make_per_channel(mod, 128, 512, 5))
     np.savez_compressed(os.path.join(OUT, "w4a8_pack_per_chn_64x128.npz"), **make_per_channel(mod, 64, 128, 1))
     np.savez_compressed(os.path.join(OUT, "w4a8_pack_per_chn_96x256.npz"), **make_per_channel(mod, 96, 256, 2))
     np.savez_compressed(os.path.join(OUT, "w4a8_pack_per_group_64x256.npz"), **make_per_group(mod, 64, 256, 3))

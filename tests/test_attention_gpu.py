@@ -115,18 +115,21 @@ def test_decode_very_long_context_kv8(gpu):
     run_case(gpu, 1, 8, 2, [3000], False, seed=8)   # beyond the reference's 2048 smem-preload threshold
 
 
-def test_decode_matches_fp32_attention_at_benchmark_size(gpu):
-    """BASELINE config 2 size (bs=64, H=32, Hkv=8, L=1024): the oracle would take minutes, so compare with an
-    independent fp32 torch attention over the de-quantised pages on the GPU (size-independent property:
-    softmax attention of the same quantised inputs)."""
+def fp32_attention_case(gpu, B, L, int4, H=32, Hkv=8, lengths_none=False, seed=1):
+    """Sizes where the numpy oracle would take minutes: compare with an independent fp32 torch attention over the
+    de-quantised pages on the GPU (size-independent property: softmax attention of the same quantised inputs).
+    The cache is written by the prefill writer (L-1 tokens), then one decode step at context L; the kernel family and
+    the split-KV factor are the dispatcher's own choice.  lengths_none: pass length_per_sample=None and
+    timestep = L-1 cached tokens (the reference's NULL path, Template.hpp:901)."""
     import qserve_backend.fused_attention as fa
-    B, H, Hkv, L = 64, 32, 8, 1024
-    g = torch.Generator(device=gpu).manual_seed(1)
+    g = torch.Generator(device=gpu).manual_seed(seed)
     mb = (L + 63) // 64
     nblocks = B * mb
-    pools = DevPools(nblocks, Hkv, True, gpu, fill=0)
-    tables = torch.stack([torch.randperm(nblocks, generator=torch.Generator().manual_seed(2)).reshape(B, mb),
-                          torch.randperm(nblocks, generator=torch.Generator().manual_seed(3)).reshape(B, mb)], dim=1)
+    dhb = 64 if int4 else 128
+    spt = Hkv * dhb
+    pools = DevPools(nblocks, Hkv, int4, gpu, fill=0)
+    tables = torch.stack([torch.randperm(nblocks, generator=torch.Generator().manual_seed(seed + 1)).reshape(B, mb),
+                          torch.randperm(nblocks, generator=torch.Generator().manual_seed(seed + 2)).reshape(B, mb)], dim=1)
     ptrs = pools.pointers(tables.numpy())
     # history through the prefill writer
     T = B * (L - 1)
@@ -134,42 +137,97 @@ def test_decode_matches_fp32_attention_at_benchmark_size(gpu):
     seq = torch.full((B,), L - 1, dtype=torch.int32, device=gpu)
     cu = torch.arange(0, B + 1, dtype=torch.int32, device=gpu) * (L - 1)
     pad = fa.compute_padding_offsets(cu, L - 1, T)
-    fa.apply_bias_rope_update_kv_cache(qkv, seq, pad, ptrs, H, Hkv, L - 1, 64, Hkv * 64, 128, ROPE, 8192, True, True, True)
+    fa.apply_bias_rope_update_kv_cache(qkv, seq, pad, ptrs, H, Hkv, L - 1, 64, spt, 128, ROPE, 8192, True, int4, True)
+    del qkv
     new = torch.randn((B, (H + 2 * Hkv) * 128), generator=g, device=gpu, dtype=torch.float16)
     q, k, v = new.split([H * 128, Hkv * 128, Hkv * 128], dim=-1)
-    lens = torch.full((B,), L, dtype=torch.int32, device=gpu)
+    lens = None if lengths_none else torch.full((B,), L, dtype=torch.int32, device=gpu)
+    timestep = L - 1 if lengths_none else L
     out = fa.single_query_attention(q.reshape(B, H, 128), k.reshape(B, Hkv, 128), v.reshape(B, Hkv, 128), ptrs, lens,
-                                    None, 8192, 64, Hkv * 64, L, 128, ROPE, True, True, True)
+                                    None, 8192, 64, spt, timestep, 128, ROPE, True, int4, True)
     torch.cuda.synchronize()
 
     # independent reference on the GPU: gather pages, de-quantise (fp32), plain softmax attention
     def gather(pool, tab):
         pg = pool[tab.to(gpu)]                                     # [B, mb, page_bytes]
-        data = pg[..., : Hkv * 64 * 64].reshape(B, mb, Hkv, 64, 64)
-        sc = pg[..., Hkv * 64 * 64: Hkv * 64 * 64 + Hkv * 64 * 2].contiguous().view(torch.float16).reshape(B, mb, Hkv, 64)
-        zr = pg[..., Hkv * 64 * 64 + Hkv * 64 * 2:].contiguous().view(torch.float16).reshape(B, mb, Hkv, 64)
-        lo, hi = (data & 0xF).float(), (data >> 4).float()
-        vals = torch.stack([lo, hi], dim=-1).reshape(B, mb, Hkv, 64, 128)
+        nd = Hkv * 64 * dhb
+        data = pg[..., :nd].reshape(B, mb, Hkv, 64, dhb)
+        sc = pg[..., nd: nd + Hkv * 64 * 2].contiguous().view(torch.float16).reshape(B, mb, Hkv, 64)
+        zr = pg[..., nd + Hkv * 64 * 2:].contiguous().view(torch.float16).reshape(B, mb, Hkv, 64)
+        if int4:
+            lo, hi = (data & 0xF).float(), (data >> 4).float()
+            vals = torch.stack([lo, hi], dim=-1).reshape(B, mb, Hkv, 64, 128)
+        else:
+            vals = data.float()
         x = sc.float()[..., None] * (vals - zr.float()[..., None])
         return x.permute(0, 2, 1, 3, 4).reshape(B, Hkv, mb * 64, 128)[:, :, :L]   # includes the new token's slot
-    Kd, Vd = gather(pools.k, tables[:, 0]), gather(pools.v, tables[:, 1])
-    Kd, Vd = Kd.clone(), Vd.clone()
-    # rotate q like the kernel does (take it from a second prefill-style call on a copy: position L-1)
+    Kd, Vd = gather(pools.k, tables[:, 0]).clone(), gather(pools.v, tables[:, 1]).clone()
+    # rotate q like the kernel does (a prefill-style call without cache on a copy: position L-1 via padding offsets,
+    # global index = b*L + (L-1))
     qk = new.clone()
-    seq1 = torch.ones((B,), dtype=torch.int32, device=gpu)
-    # position L-1 via padding offsets: global index = b*L + (L-1)
     pad1 = (torch.arange(B, device=gpu, dtype=torch.int32) * L + (L - 1)) - torch.arange(B, device=gpu, dtype=torch.int32)
     fa.apply_bias_rope_update_kv_cache(qk, torch.full((B,), L, dtype=torch.int32, device=gpu), pad1, None, H, Hkv, L, 64,
-                                       Hkv * 64, 128, ROPE, 8192, True, True, True)
+                                       spt, 128, ROPE, 8192, True, int4, True)
     qr = qk[:, : H * 128].reshape(B, Hkv, H // Hkv, 128).float()
-    # the kernel uses the NEW token's rotated k and raw v un-quantised (Template.hpp:1356-1364, 2123-2153)
-    Kd[:, :, L - 1] = qk[:, H * 128:(H + Hkv) * 128].reshape(B, Hkv, 128).float()
-    Vd[:, :, L - 1] = new[:, (H + Hkv) * 128:].reshape(B, Hkv, 128).float()
+    # the new token's slot in the cache must now hold its quantised K / V (what later steps will read) ...
+    kq_new, vq_new = Kd[:, :, L - 1].clone(), Vd[:, :, L - 1].clone()
+    k_rot = qk[:, H * 128:(H + Hkv) * 128].reshape(B, Hkv, 128).float()
+    v_raw = new[:, (H + Hkv) * 128:].reshape(B, Hkv, 128).float()
+    step = (2.0 if int4 else 0.13)          # one quantisation step of an N(0,1) row: range/15 resp. range/255, generous
+    assert (kq_new - k_rot).abs().max().item() < step and (vq_new - v_raw).abs().max().item() < step
+    # ... while the kernel itself uses the NEW token's rotated k and raw v un-quantised (Template.hpp:1356-1364, 2123-2153)
+    Kd[:, :, L - 1] = k_rot
+    Vd[:, :, L - 1] = v_raw
     s = torch.einsum("bkgd,bktd->bkgt", qr, Kd) / (128 ** 0.5)
     p = torch.softmax(s, dim=-1)
     ref = torch.einsum("bkgt,bktd->bkgd", p, Vd).reshape(B, H, 128)
     err = (out.float() - ref).abs().max().item()
-    assert err < 1e-3, err
+    assert err < TOL, err
+    return out
+
+
+def test_decode_matches_fp32_attention_at_benchmark_size(gpu):
+    """BASELINE config 2 size (bs=64, H=32, Hkv=8, L=1024)."""
+    fp32_attention_case(gpu, 64, 1024, True)
+
+
+@pytest.mark.parametrize("L", [1280, 1535])
+def test_decode_config2_mid_and_end_of_generation(gpu, L):
+    """configs[1]: context 1024 -> +512; SURVEY 8(d) asks for start / mid / end."""
+    fp32_attention_case(gpu, 64, L, True, seed=L)
+
+
+@pytest.mark.parametrize("int4", [False, True], ids=["kv8", "kv4"])
+@pytest.mark.parametrize("L", [7680, 8191])
+def test_decode_config5_long_context_split_kv(gpu, L, int4):
+    """BASELINE config 5 (Llama-3-8B, KV8, 8k context, bs=8) and its KV4 twin: 120-128 pages per sequence, the dispatcher
+    splits the context over several workgroups per (sequence, kv head) and merges the partials."""
+    from qserve_amd import _lib
+    import ctypes
+    plan = (ctypes.c_int * 3)()
+    assert _lib.lib.qs_attention_plan(8, 32, 8, (L + 63) // 64, L, int(int4), plan) == 0
+    assert plan[0] == (1 if int4 else 2) and plan[1] > 1, f"expected a split-KV matrix-core launch, got {list(plan)}"
+    fp32_attention_case(gpu, 8, L, int4, seed=L + int4)
+
+
+@pytest.mark.parametrize("int4", [True, False], ids=["kv4", "kv8"])
+def test_decode_length_per_sample_none(gpu, int4):
+    """length_per_sample = None: every sequence has `timestep` cached tokens and the new token goes to position
+    `timestep` (Template.hpp:901).  Must equal the call with lengths = timestep + 1, bit for bit (output and pages),
+    and match the fp32 attention."""
+    import qserve_backend.fused_attention as fa
+    B, L, H, Hkv = 3, 200, 8, 2
+    out_none = fp32_attention_case(gpu, B, L, int4, H=H, Hkv=Hkv, lengths_none=True, seed=5)
+    out_len = fp32_attention_case(gpu, B, L, int4, H=H, Hkv=Hkv, lengths_none=False, seed=5)
+    assert torch.equal(out_none, out_len)
+    # VALU kernels take the same path
+    from qserve_amd import _lib
+    _lib.lib.qs_set_attention_variant(1)
+    try:
+        out_valu = fp32_attention_case(gpu, B, L, int4, H=H, Hkv=Hkv, lengths_none=True, seed=5)
+    finally:
+        _lib.lib.qs_set_attention_variant(0)
+    assert (out_valu.float() - out_none.float()).abs().max().item() < 2 * TOL
 
 
 def test_rejects_what_reference_rejects(gpu):

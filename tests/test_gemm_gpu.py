@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 import torch
 
-from _helpers import dev, int_matmul_torch, ulp_diff_f16, unpack_qweight_torch
+from _helpers import (dev, int_matmul_torch, pack_qweight_torch, per_group_problem_torch, ulp_diff_f16,
+                      unpack_qweight_torch)
 from oracle import synth, w4a8
 
 pytestmark = pytest.mark.gpu
@@ -285,6 +286,146 @@ def test_per_group_full_size_exact_on_device(gpu, M):
     w8 = (pr["q"].astype(np.int16) - np.repeat(pr["z"], 128, 1)) * np.repeat(pr["s2"], 128, 1)
     ref = int_matmul_torch(A, dev(w8.astype(np.int8)))
     assert torch.equal(acc.to(torch.int64), ref)
+
+
+def test_torch_problem_generator_matches_oracle_packer(gpu):
+    """The device-side generator used for the full-size cases packs exactly like the (reference-pinned) oracle packer."""
+    pr = per_group_problem_torch(8, 64, 256, gpu, seed=3)
+    q = unpack_qweight_torch(pr["qweight"]).cpu().numpy()
+    assert np.array_equal(w4a8.pack_qweight(q), pr["qweight"].cpu().numpy())
+    assert np.array_equal(pack_qweight_torch(torch.from_numpy(q)).numpy(), pr["qweight"].cpu().numpy())
+    w8 = w4a8.dequant_per_group_w8(pr["qweight"].cpu().numpy(), pr["s2_zeros"].cpu().numpy(), pr["s2_scales"].cpu().numpy())
+    assert np.array_equal(w8, pr["w8"].cpu().numpy())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 28672, 4096), (128, 4096, 14336), (128, 6144, 4096), (128, 4096, 4096)])
+def test_config3_per_group_full_shapes(gpu, M, N, K):
+    """BASELINE.json configs[2] (Llama-3-8B g128, bs=128): every GEMM of the layer at its real size through the
+    dispatcher's own choice (gate_up: ring(4,2,2); down: K-sliced ring) - int32 accumulators exact against an independent
+    integer matmul of the level-2 de-quantised weights, fp16 output bit-exact against the oracle epilogue."""
+    import qserve_backend.qgemm_w4a8_per_group as op
+    pr = per_group_problem_torch(M, N, K, gpu, seed=N + K)
+    acc = torch.full((M, N), -7, dtype=torch.int32, device=gpu)
+    op.gemm_forward_acc(pr["A"], pr["qweight"], pr["s2_zeros"], pr["s2_scales"], acc)
+    ref = int_matmul_torch(pr["A"], pr["w8"])
+    assert torch.equal(acc.to(torch.int64), ref)
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+    op.gemm_forward_cuda(pr["A"], pr["qweight"], pr["s2_zeros"], pr["s2_scales"], pr["wscales"], pr["ascales"], out)
+    out_ref = w4a8.epilogue_per_group(ref.cpu().numpy().astype(np.int32), pr["wscales"].cpu().numpy(),
+                                      pr["ascales"].cpu().numpy())
+    assert ulp_diff_f16(out.cpu().numpy(), out_ref).max() == 0
+
+
+@pytest.mark.parametrize("M", [64, 128])
+@pytest.mark.parametrize("N,K", [(28672, 4096), (4096, 14336), (6144, 4096), (4096, 4096)])
+def test_config2_per_channel_full_shapes_fp16(gpu, M, N, K):
+    """BASELINE.json configs[1] GEMM shapes at decode batch: accumulators exact AND the fp16 epilogue bit-exact at full size
+    (the small-shape tests pin the epilogue, the large-shape ones so far only the accumulators)."""
+    import qserve_backend.qgemm_w4a8_per_chn as op
+    g = torch.Generator(device=gpu).manual_seed(N + K + M)
+    W = torch.randint(-128, 128, (N, K // 2), dtype=torch.int8, device=gpu, generator=g)
+    A = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=gpu, generator=g)
+    acc = torch.full((M, N), -7, dtype=torch.int32, device=gpu)
+    op.gemm_forward_acc(A, W, acc)
+    ref = int_matmul_torch(A, unpack_qweight_torch(W))
+    assert torch.equal(acc.to(torch.int64), ref)
+    r = np.random.default_rng(N + K)
+    ws = r.uniform(0.002, 0.02, N).astype(np.float16)
+    z = r.integers(0, 16, N)
+    wz = (z.astype(np.float16) * ws).astype(np.float16)
+    sa = r.uniform(0.005, 0.05, M).astype(np.float16)
+    ss = (sa.astype(np.float32) * A.cpu().numpy().astype(np.int64).sum(1).astype(np.float32)).astype(np.float16)
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+    op.gemm_forward_cuda(A, W, dev(ws), dev(sa), dev(wz), dev(ss), out)
+    assert ulp_diff_f16(out.cpu().numpy(), w4a8.epilogue_per_chn(ref.cpu().numpy().astype(np.int32), ws, sa, wz, ss)).max() == 0
+
+
+def _float_reference(A, sa, Wdeq):
+    """A_deq . W_deq^T in float64: what the quantised GEMM approximates (SURVEY 8d config 1 "plumbing" reference)."""
+    return (A.astype(np.float64) * sa.astype(np.float64)[:, None]) @ Wdeq.T
+
+
+@pytest.mark.parametrize("name", ["w4a8_pack_per_chn_64x128", "w4a8_pack_per_chn_128x512"])
+def test_reference_packed_golden_per_channel_into_hip_gemm(gpu, name):
+    """qweight / s1_scales / s1_szeros PRODUCED BY THE REFERENCE's from_linear (tests/golden/*.npz) go straight into the
+    HIP GEMM; the expected accumulator is computed from the ORIGINAL nibbles q (never touching the oracle's unpacker)."""
+    import os
+    import qserve_backend.qgemm_w4a8_per_chn as op
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    N, K = d["q"].shape
+    r = np.random.default_rng(N + K)
+    M = 37
+    A = r.integers(-127, 128, (M, K), dtype=np.int8)
+    sa = r.uniform(0.005, 0.05, M).astype(np.float16)
+    ss = (sa.astype(np.float32) * A.astype(np.int64).sum(1).astype(np.float32)).astype(np.float16)
+    acc_ref = (A.astype(np.int64) @ d["q"].astype(np.int64).T).astype(np.int32)
+    acc = torch.full((M, N), -7, dtype=torch.int32, device=gpu)
+    op.gemm_forward_acc(dev(A), dev(d["qweight"]), acc)
+    assert np.array_equal(acc.cpu().numpy(), acc_ref)
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+    op.gemm_forward_cuda(dev(A), dev(d["qweight"]), dev(d["s1_scales"]), dev(sa), dev(d["s1_szeros"]), dev(ss), out)
+    o = out.cpu().numpy()
+    assert ulp_diff_f16(o, w4a8.epilogue_per_chn(acc_ref, d["s1_scales"], sa, d["s1_szeros"], ss)).max() == 0
+    # and it is the GEMM it claims to be: A_deq . ((q - z) s1)^T up to fp16 rounding of ssum / szero / output
+    Wdeq = (d["q"].astype(np.float64) - d["z"].astype(np.float64)[:, None]) * d["s1"].astype(np.float64)[:, None]
+    ref = _float_reference(A, sa, Wdeq)
+    assert np.abs(o.astype(np.float64) - ref).max() <= 2e-3 * np.abs(ref).max() + 0.05
+
+
+@pytest.mark.parametrize("name", ["w4a8_pack_per_group_64x256", "w4a8_pack_per_group_128x384"])
+def test_reference_packed_golden_per_group_into_hip_gemm(gpu, name):
+    import os
+    import qserve_backend.qgemm_w4a8_per_group as op
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    N, K = d["q"].shape
+    r = np.random.default_rng(N + K)
+    M = 21
+    A = r.integers(-127, 128, (M, K), dtype=np.int8)
+    sa = r.uniform(0.005, 0.05, M).astype(np.float16)
+    w8 = (d["q"].astype(np.int64) - np.repeat(d["z"].astype(np.int64), 128, 1)) * np.repeat(d["s2"].astype(np.int64), 128, 1)
+    acc_ref = (A.astype(np.int64) @ w8.T).astype(np.int32)
+    acc = torch.full((M, N), -7, dtype=torch.int32, device=gpu)
+    op.gemm_forward_acc(dev(A), dev(d["qweight"]), dev(d["s2_zeros"]), dev(d["s2_scales"]), acc)
+    assert np.array_equal(acc.cpu().numpy(), acc_ref)
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+    op.gemm_forward_cuda(dev(A), dev(d["qweight"]), dev(d["s2_zeros"]), dev(d["s2_scales"]), dev(d["s1_scales"]), dev(sa), out)
+    o = out.cpu().numpy()
+    assert ulp_diff_f16(o, w4a8.epilogue_per_group(acc_ref, d["s1_scales"], sa)).max() == 0
+    ref = _float_reference(A, sa, w8.astype(np.float64) * d["s1"].astype(np.float64)[:, None])
+    assert np.abs(o.astype(np.float64) - ref).max() <= 2e-3 * np.abs(ref).max() + 0.05
+
+
+@pytest.mark.parametrize("kind", ["per_chn", "per_group"])
+@pytest.mark.parametrize("M", [64, 2048])
+def test_reference_pinned_full_size_checkpoint_into_hip_gemm(gpu, kind, M):
+    """Llama-3-8B o_proj-sized tensors whose bytes are SHA-256-verified against the reference's from_linear
+    (tests/test_oracle_golden.py::full_size_reference_pinned) through the decode (M=64) and tiled (M=2048) kernels."""
+    from test_oracle_golden import full_size_reference_pinned
+    i, p = full_size_reference_pinned(kind)
+    N, K = i["q"].shape
+    g = torch.Generator(device=gpu).manual_seed(M)
+    A = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=gpu, generator=g)
+    sa = (torch.rand((M,), device=gpu, generator=g) * 0.045 + 0.005).half()
+    acc = torch.full((M, N), -7, dtype=torch.int32, device=gpu)
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+    if kind == "per_chn":
+        import qserve_backend.qgemm_w4a8_per_chn as op
+        ref = int_matmul_torch(A, dev(i["q"].astype(np.int8)))
+        op.gemm_forward_acc(A, dev(p["qweight"]), acc)
+        assert torch.equal(acc.to(torch.int64), ref)
+        ss = (sa.float() * A.sum(dim=1, dtype=torch.int64).float()).half()
+        op.gemm_forward_cuda(A, dev(p["qweight"]), dev(p["s1_scales"]), sa, dev(p["s1_szeros"]), ss, out)
+        exp = w4a8.epilogue_per_chn(ref.cpu().numpy().astype(np.int32), p["s1_scales"], sa.cpu().numpy(), p["s1_szeros"],
+                                    ss.cpu().numpy())
+    else:
+        import qserve_backend.qgemm_w4a8_per_group as op
+        w8 = (i["q"].astype(np.int16) - np.repeat(i["z"].astype(np.int16), 128, 1)) * np.repeat(i["s2"].astype(np.int16), 128, 1)
+        ref = int_matmul_torch(A, dev(w8.astype(np.int8)))
+        op.gemm_forward_acc(A, dev(p["qweight"]), dev(p["s2_zeros"]), dev(p["s2_scales"]), acc)
+        assert torch.equal(acc.to(torch.int64), ref)
+        op.gemm_forward_cuda(A, dev(p["qweight"]), dev(p["s2_zeros"]), dev(p["s2_scales"]), dev(p["s1_scales"]), sa, out)
+        exp = w4a8.epilogue_per_group(ref.cpu().numpy().astype(np.int32), p["s1_scales"], sa.cpu().numpy())
+    assert ulp_diff_f16(out.cpu().numpy(), exp).max() == 0
 
 
 def test_w8a8_module(gpu):

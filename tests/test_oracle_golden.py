@@ -34,6 +34,54 @@ def test_pack_per_group_matches_reference(path):
     assert np.array_equal(w8, ref)
 
 
+def _full_size_inputs(kind, N, K, seed):
+    """Same seeded recipe as tests/golden/make_golden.py::full_size_inputs (kept in sync by the digest test below)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    if kind == "per_chn":
+        q = torch.randint(0, 16, (N, K), generator=g)
+        z = torch.randint(0, 16, (N,), generator=g)
+        s1 = (torch.rand((N,), generator=g) * 0.018 + 0.002).to(torch.float16)
+        return dict(q=q.numpy(), z=z.numpy(), s1=s1.numpy())
+    ng = K // 128
+    s2 = torch.randint(1, 9, (N, ng), generator=g)
+    z = torch.randint(0, 16, (N, ng), generator=g)
+    q = torch.randint(0, 16, (N, ng, 128), generator=g)
+    lo = torch.ceil((-128.0 / s2.float()) + z.float()).clamp(0, 15).long()
+    hi = torch.floor((127.0 / s2.float()) + z.float()).clamp(0, 15).long()
+    q = torch.maximum(torch.minimum(q, hi[..., None]), lo[..., None])
+    s1 = (torch.rand((N,), generator=g) * 0.018 + 0.002).to(torch.float16)
+    return dict(q=q.reshape(N, K).numpy(), z=z.numpy(), s2=s2.numpy(), s1=s1.numpy())
+
+
+def full_size_reference_pinned(kind):
+    """Oracle-packed Llama-3-8B o_proj-sized checkpoint tensors, verified byte-for-byte (SHA-256) against what the
+    reference's own from_linear produced for the same seeded inputs (tests/golden/make_golden.py).  Returns the raw
+    inputs and the packed tensors; used by the CPU pin below and by the GPU parity tests."""
+    import hashlib
+    import json
+    meta = json.load(open(os.path.join(GOLD, "w4a8_pack_llama3_8b_o_proj_digests.json")))
+    N, K = meta["shape"]
+    ent = meta["entries"][kind]
+    i = _full_size_inputs(kind, N, K, ent["seed"])
+    if kind == "per_chn":
+        qw, s1, sz = w4a8.pack_per_channel(i["q"], i["z"], i["s1"])
+        packed = dict(qweight=qw, s1_scales=s1, s1_szeros=sz)
+    else:
+        qw, s1, s2s, s2z = w4a8.pack_per_group(i["q"], i["z"], i["s2"], i["s1"])
+        packed = dict(qweight=qw, s1_scales=s1, s2_scales=s2s, s2_zeros=s2z)
+    for name, t in packed.items():
+        got = hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest()
+        assert got == ent[name], f"{kind}.{name}: oracle packer output differs from the reference's from_linear"
+    return i, packed
+
+
+@pytest.mark.parametrize("kind", ["per_chn", "per_group"])
+def test_pack_full_size_matches_reference_digest(kind):
+    """4096 x 4096 (Llama-3-8B o_proj): the oracle packer reproduces the reference's from_linear byte for byte."""
+    full_size_reference_pinned(kind)
+
+
 def test_golden_files_present():
     assert len(glob.glob(os.path.join(GOLD, "*.npz"))) >= 4
 
