@@ -36,13 +36,17 @@ class guard:
         return False
 
 
+def on_device(t):
+    return t.is_cuda
+
+
 def expect(t, dtype, name, contiguous=True):
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
     if t.dtype != dtype:
         # the reference's data_ptr<T>() throws on a dtype mismatch
         raise RuntimeError(f"expected scalar type {dtype} for {name} but found {t.dtype}")
-    if not t.is_cuda:
+    if not on_device(t):
         raise RuntimeError(f"{name} must be on CUDA")   # wording of the reference's CHECK_DEVICE
     if contiguous and not t.is_contiguous():
         raise RuntimeError(f"{name} must be contiguous")

@@ -5,11 +5,11 @@ import math
 
 import torch
 
-from .backend._util import check, guard, lib, ptr, stream
+from .backend._util import check, guard, lib, on_device, ptr, stream
 
 
 def _expect_f16(t, name):
-    if not isinstance(t, torch.Tensor) or t.dtype != torch.float16 or not t.is_cuda:
+    if not isinstance(t, torch.Tensor) or t.dtype != torch.float16 or not on_device(t):
         raise RuntimeError(f"flash_attn_varlen_func: {name} must be a CUDA float16 tensor")
     if t.dim() != 3 or t.stride(2) != 1 or t.stride(1) != t.size(2):
         raise RuntimeError(f"flash_attn_varlen_func: {name} must be [tokens, heads, head_dim] with contiguous heads "
@@ -30,7 +30,7 @@ def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, ma
     if k.size(1) != v.size(1) or q.size(1) % k.size(1) != 0 or k.size(0) != v.size(0):
         raise RuntimeError("flash_attn_varlen_func: inconsistent head / token counts")
     for c, n in ((cu_seqlens_q, "cu_seqlens_q"), (cu_seqlens_k, "cu_seqlens_k")):
-        if c.dtype != torch.int32 or not c.is_cuda or not c.is_contiguous():
+        if c.dtype != torch.int32 or not on_device(c) or not c.is_contiguous():
             raise RuntimeError(f"flash_attn_varlen_func: {n} must be a contiguous CUDA int32 tensor")
     batch = cu_seqlens_q.numel() - 1
     if cu_seqlens_k.numel() - 1 != batch:
