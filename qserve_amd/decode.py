@@ -27,18 +27,17 @@ import qserve_backend.qgemm_w4a8_per_group as gemm_grp
 
 from . import fused as fusedmod
 from . import tp as tpmod
-from ._lib import check as _check, lib as _lib
+from .backend._util import check as _check, lib as _lib, stream
 
 
 def residual_add_(a, b):
     """a += b (fp16), the residual add the reference does with a torch add (llama_w4a8_unpad.py:348,360)."""
-    _check(_lib.qs_residual_add(a.data_ptr(), b.data_ptr(), a.numel(), torch.cuda.current_stream().cuda_stream),
-           "residual_add")
+    _check(_lib.qs_residual_add(a.data_ptr(), b.data_ptr(), a.numel(), stream()), "residual_add")
 
 LLAMA3_8B = dict(name="Llama-3-8B", hidden=4096, heads=32, kv_heads=8, inter=14336, layers=32, vocab=128256,
                  rope_theta=5e5, eps=1e-5)
 QWEN15_72B = dict(name="Qwen1.5-72B", hidden=8192, heads=64, kv_heads=64, inter=24576, layers=80, vocab=152064,
-                  rope_theta=1e6, eps=1e-6)
+                  rope_theta=1e6, eps=1e-6, qkv_bias=True)     # attention_bias: q/k/v projections carry a bias
 LLAMA2_7B = dict(name="Llama-2-7B", hidden=4096, heads=32, kv_heads=32, inter=11008, layers=32, vocab=32000,
                  rope_theta=1e4, eps=1e-5)
 LLAMA2_70B = dict(name="Llama-2-70B", hidden=8192, heads=64, kv_heads=8, inter=28672, layers=80, vocab=32000,
@@ -48,10 +47,14 @@ TINY = dict(name="tiny-llama", hidden=256, heads=4, kv_heads=2, inter=512, layer
 
 
 class W4A8Linear:
-    """Synthetic stand-in for W4A8OF16LinearDynamicInputScale (w4a8_linear.py:12-134): same buffers, same call."""
+    """Stand-in for W4A8OF16LinearDynamicInputScale (w4a8_linear.py:12-134): same buffers, same call, same bias rule
+    (`output_buffer += bias` after the op, :116-118 / :132-134).  Built either from synthetic random tensors or from
+    checkpoint tensors (`from_tensors`, fed by qserve_amd.loader).  `defer_bias`: row-parallel shard under tensor
+    parallelism - the caller adds the bias once, after the all-reduce."""
 
-    def __init__(self, n, k, group_size, device, gen):
+    def __init__(self, n, k, group_size, device, gen, bias=False):
         self.n, self.k, self.group_size = n, k, group_size
+        self.defer_bias = False
         self.qweight = torch.randint(-128, 128, (n, k // 2), dtype=torch.int8, device=device, generator=gen)
         self.s1_scales = (torch.rand((n,), device=device, generator=gen) * 0.004 + 0.001).half()
         if group_size == -1:
@@ -62,6 +65,22 @@ class W4A8Linear:
             self.s2_scales = torch.randint(1, 9, (k // 128, n), dtype=torch.int8, device=device, generator=gen)
             zz = torch.randint(0, 16, (k // 128, n), device=device, generator=gen).to(torch.int16)
             self.s2_zeros = (-(zz * self.s2_scales.to(torch.int16))).to(torch.int8)
+        self.bias = ((torch.rand((n,), device=device, generator=gen) - 0.5) * 0.1).half() if bias else None
+
+    @classmethod
+    def from_tensors(cls, d, group_size, defer_bias=False):
+        """d: {"qweight", "s1_scales", "s1_szeros" | ("s2_scales", "s2_zeros"), ["bias"]} already on the device."""
+        self = cls.__new__(cls)
+        self.n, self.k, self.group_size = d["qweight"].shape[0], d["qweight"].shape[1] * 2, group_size
+        self.qweight, self.s1_scales = d["qweight"], d["s1_scales"]
+        if group_size == -1:
+            self.s1_szeros = d["s1_szeros"]
+        else:
+            self.s2_scales, self.s2_zeros = d["s2_scales"], d["s2_zeros"]
+            assert tuple(self.s2_scales.shape) == (self.k // 128, self.n)
+        self.bias = d.get("bias")
+        self.defer_bias = defer_bias
+        return self
 
     def __call__(self, x, input_scales, input_sum, out):
         if self.group_size == -1:   # forward_per_chn, w4a8_linear.py:105-118
@@ -69,11 +88,15 @@ class W4A8Linear:
         else:                       # forward_per_group, :120-134
             gemm_grp.gemm_forward_cuda(x, self.qweight, self.s2_zeros, self.s2_scales, self.s1_scales, input_scales,
                                        out)
+        if self.bias is not None and not self.defer_bias:
+            out += self.bias
 
 
 class DecodeEngine:
     def __init__(self, cfg, batch, prompt_len, max_new, group_size=-1, int4_kv=True, device="cuda:0", seed=0,
-                 tp_rank=0, tp_world=1, with_lm_head=True, fuse_pairs=True):
+                 tp_rank=0, tp_world=1, with_lm_head=True, fuse_pairs=True, weights=None):
+        """weights: None = synthetic random-quantised tensors of the right shapes; otherwise this rank's tensors as
+        qserve_amd.loader.load_llama_w4a8 returns them (checkpoint path)."""
         self.cfg, self.B, self.dev = cfg, batch, torch.device(device)
         # fuse_pairs: issue (residual add + layer norm) and (silu_and_mul + quant) as one launch each
         # (qserve_amd/fused.py: bit-identical to the op pairs; False = the reference's exact op-by-op sequence)
@@ -88,20 +111,35 @@ class DecodeEngine:
         self.qkv_n = (self.H + 2 * self.Hkv) * 128
         gen = torch.Generator(device=self.dev).manual_seed(seed + 1000 * tp_rank)
         self.layers = []
-        for _ in range(cfg["layers"]):
-            self.layers.append(dict(
-                ln1=(torch.rand((hid,), device=self.dev, generator=gen) + 0.5).half(),
-                ln2=(torch.rand((hid,), device=self.dev, generator=gen) + 0.5).half(),
-                qkv=W4A8Linear(self.qkv_n, hid, group_size, self.dev, gen),
-                o=W4A8Linear(hid, self.H * 128, group_size, self.dev, gen),
-                gate_up=W4A8Linear(2 * inter, hid, group_size, self.dev, gen),
-                down=W4A8Linear(hid, inter, group_size, self.dev, gen),
-            ))
-        self.norm_w = (torch.rand((hid,), device=self.dev, generator=gen) + 0.5).half()
         self.with_lm_head = with_lm_head
-        if with_lm_head:
-            self.embed = (torch.randn((cfg["vocab"], hid), device=self.dev, generator=gen) * 0.05).half()
-            self.lm_head = (torch.randn((cfg["vocab"], hid), device=self.dev, generator=gen) * 0.02).half()
+        if weights is None:
+            for _ in range(cfg["layers"]):
+                self.layers.append(dict(
+                    ln1=(torch.rand((hid,), device=self.dev, generator=gen) + 0.5).half(),
+                    ln2=(torch.rand((hid,), device=self.dev, generator=gen) + 0.5).half(),
+                    qkv=W4A8Linear(self.qkv_n, hid, group_size, self.dev, gen, bias=bool(cfg.get("qkv_bias"))),
+                    o=W4A8Linear(hid, self.H * 128, group_size, self.dev, gen),
+                    gate_up=W4A8Linear(2 * inter, hid, group_size, self.dev, gen),
+                    down=W4A8Linear(hid, inter, group_size, self.dev, gen),
+                ))
+            self.norm_w = (torch.rand((hid,), device=self.dev, generator=gen) + 0.5).half()
+            if with_lm_head:
+                self.embed = (torch.randn((cfg["vocab"], hid), device=self.dev, generator=gen) * 0.05).half()
+                self.lm_head = (torch.randn((cfg["vocab"], hid), device=self.dev, generator=gen) * 0.02).half()
+        else:
+            to = lambda d: {k: v.to(self.dev).contiguous() for k, v in d.items()}   # noqa: E731
+            for L in weights["layers"]:
+                self.layers.append(dict(
+                    ln1=L["ln1"].to(self.dev), ln2=L["ln2"].to(self.dev),
+                    qkv=W4A8Linear.from_tensors(to(L["qkv"]), group_size),
+                    o=W4A8Linear.from_tensors(to(L["o"]), group_size, defer_bias=tp_world > 1),
+                    gate_up=W4A8Linear.from_tensors(to(L["gate_up"]), group_size),
+                    down=W4A8Linear.from_tensors(to(L["down"]), group_size, defer_bias=tp_world > 1),
+                ))
+                assert self.layers[-1]["qkv"].n == self.qkv_n and self.layers[-1]["down"].k == inter
+            self.norm_w = weights["norm"].to(self.dev)
+            if with_lm_head:
+                self.embed, self.lm_head = weights["embed"].to(self.dev), weights["lm_head"].to(self.dev)
         # ---- paged KV pools (cache_engine.py:59-115) and pointer tables (model_runner.py:396-414)
         self.max_len = prompt_len + max_new
         self.mb = (self.max_len + 63) // 64 + 1            # README.md:369 page budget rule (+1 page)
@@ -215,6 +253,8 @@ class DecodeEngine:
                 fused_kernels.invoke_quant(qo, attn, q_scale)
             L["o"](qo, q_scale, q_sum, proj)
             tpmod.all_reduce_sum_(proj)
+            if L["o"].defer_bias and L["o"].bias is not None:
+                proj += L["o"].bias
             add_norm_quant(h, proj, L["ln2"])
             L["gate_up"](qa, q_scale, q_sum, gate_up)
             if fuse:
@@ -227,6 +267,8 @@ class DecodeEngine:
                     fused_kernels.invoke_quant(q_mlp, mlp_act, q_scale)
             L["down"](q_mlp, q_scale, q_sum, proj)
             tpmod.all_reduce_sum_(proj)
+            if L["down"].defer_bias and L["down"].bias is not None:
+                proj += L["down"].bias
             if li + 1 < nl:
                 add_norm_quant(h, proj, self.layers[li + 1]["ln1"])
             else:
@@ -283,6 +325,8 @@ class DecodeEngine:
             L["o"](qo, self.q_scale, self.q_sum, self.proj_out)
             if self.tp_world > 1:
                 yield self.proj_out
+                if L["o"].defer_bias and L["o"].bias is not None:
+                    self.proj_out += L["o"].bias          # once, after the reduce
             add_norm_quant(h, self.proj_out, L["ln2"])
             L["gate_up"](qa, self.q_scale, self.q_sum, self.gate_up_buf)
             if fuse:
@@ -296,6 +340,8 @@ class DecodeEngine:
             L["down"](self.q_mlp, self.q_scale, self.q_sum, self.proj_out)
             if self.tp_world > 1:
                 yield self.proj_out
+                if L["down"].defer_bias and L["down"].bias is not None:
+                    self.proj_out += L["down"].bias
             if li + 1 < nl:
                 add_norm_quant(h, self.proj_out, self.layers[li + 1]["ln1"])   # next layer's input norm
             else:

@@ -17,13 +17,36 @@ import torch
 
 
 def shard_column_parallel(qweight, vecs_n=(), mats_gn=(), rank=0, world=1):
-    """Split the OUTPUT dim N.  qweight int8 [N, K/2]; vecs_n: per-channel [N] tensors (s1_scales, s1_szeros, bias);
-    mats_gn: [K/128, N] tensors (s2_scales, s2_zeros).  Returns (qweight_r, [vecs...], [mats...])."""
+    """Split the OUTPUT dim N of ONE separately packed projection (q_proj, gate_proj, ...).  qweight int8 [N, K/2];
+    vecs_n: per-channel [N] tensors (s1_scales, s1_szeros, bias); mats_gn: [K/128, N] tensors (s2_scales, s2_zeros).
+    Returns (qweight_r, [vecs...], [mats...]).
+
+    NOT for an already fused `qkv_proj` / `gate_up_proj` tensor: a contiguous slice of [q; k; v] would hand rank 0 only
+    query heads.  Fused tensors go through `shard_fused_column_parallel` (or are sharded per projection before the
+    fusion, `qserve_amd.loader.fuse_column_parallel`)."""
     N = qweight.shape[0]
     assert N % (32 * world) == 0, "column-parallel split must fall on 32-row tiles"
     n0, n1 = rank * N // world, (rank + 1) * N // world
     return (qweight[n0:n1].contiguous(), [v[n0:n1].contiguous() for v in vecs_n],
             [m[:, n0:n1].contiguous() for m in mats_gn])
+
+
+def shard_fused_column_parallel(qweight, sizes, vecs_n=(), mats_gn=(), rank=0, world=1, replicas=None):
+    """Column-parallel shard of a FUSED projection whose rows are the concatenation of blocks of `sizes` rows
+    ([q; k; v] -> sizes = [H*128, Hkv*128, Hkv*128]; [gate; up] -> [inter, inter]): every block is split over the ranks
+    separately (block i over world // replicas[i] shards; replicas > 1 = KV heads shared by several ranks) and the
+    rank's pieces are concatenated again, so each rank gets its own q heads AND its kv heads."""
+    assert sum(sizes) == qweight.shape[0]
+    replicas = replicas or [1] * len(sizes)
+    idx, off = [], 0
+    for n, rep in zip(sizes, replicas):
+        shards = world // rep
+        assert n % (32 * shards) == 0, "column-parallel split must fall on 32-row tiles"
+        per, sid = n // shards, rank // rep
+        idx.append((off + sid * per, off + (sid + 1) * per))
+        off += n
+    cat = lambda t, dim: torch.cat([t[a:b] if dim == 0 else t[:, a:b] for a, b in idx], dim=dim).contiguous()  # noqa: E731
+    return cat(qweight, 0), [cat(v, 0) for v in vecs_n], [cat(m, 1) for m in mats_gn]
 
 
 def shard_row_parallel(qweight, mats_gn=(), rank=0, world=1, group_size=-1):
@@ -54,17 +77,19 @@ def all_reduce_sum_(t, group=None):
 
 
 class RowParallelLinear:
-    """y = all_reduce( gemm(x_shard, W_shard) ) (+ bias once, after the reduce).
+    """y = all_reduce( gemm(x_shard) ) (+ bias once, after the reduce).
 
-    `gemm` is any callable with the signature of `qserve_backend.qgemm_w4a8_per_chn.gemm_forward_cuda` or the
-    per-group one; every rank quantises its own activation slice, so ascales / a_ssums are per shard (the
-    zero-point term is linear in K, partial corrections add up: SURVEY 8e)."""
+    `gemm(x_q, ascales, a_ssums, out)` is a closure over this rank's weight shard, e.g.
+        lambda x, sa, ss, out: qgemm_w4a8_per_chn.gemm_forward_cuda(x, qweight_r, s1_scales, sa, s1_szeros, ss, out)
+    (the signature `W4A8OF16LinearDynamicInputScale.forward` has, w4a8_linear.py:105-134).  Every rank quantises its
+    own activation slice, so ascales / a_ssums are per shard (the zero-point term is linear in K, partial corrections
+    add up: SURVEY 8e)."""
 
-    def __init__(self, gemm, weight_args, bias=None, group=None):
-        self.gemm, self.weight_args, self.bias, self.group = gemm, weight_args, bias, group
+    def __init__(self, gemm, bias=None, group=None):
+        self.gemm, self.bias, self.group = gemm, bias, group
 
     def __call__(self, x_q, ascales, a_ssums, out):
-        self.gemm(x_q, ascales, a_ssums, out, *self.weight_args)
+        self.gemm(x_q, ascales, a_ssums, out)
         all_reduce_sum_(out, self.group)
         if self.bias is not None:
             out += self.bias

@@ -249,7 +249,7 @@ def install(monkeypatch):
     import importlib
     mods = [importlib.import_module("qserve_amd.backend." + m) for m in
             ("qgemm_w4a8_per_chn", "qgemm_w4a8_per_group", "qgemm_w8a8", "fused_attention", "fused_kernels",
-             "layernorm_ops", "activation_ops")] + [fusedmod, flashmod, U]
+             "layernorm_ops", "activation_ops")] + [fusedmod, flashmod, U, importlib.import_module("qserve_amd.decode")]
     for m in mods:
         for attr, repl in (("stream", lambda: 0), ("expect", expect_host), ("guard", _NoGuard),
                            ("on_device", lambda t: True)):

@@ -44,7 +44,7 @@ def _worker(rank, port, ret):
         ssum_r = (pc["ascales"].astype(np.float32) * pc["A"][:, k0:k1].astype(np.int64).sum(1).astype(np.float32)).astype(np.float16)
         part = w4a8.epilogue_per_chn(acc_r, pc["wscales"], pc["ascales"], pc["w_szs"], ssum_r).astype(np.float32)
         tt = torch.from_numpy(part)
-        rp = tp.RowParallelLinear(lambda x, a, s, out, *w: None, ())     # gemm already done above
+        rp = tp.RowParallelLinear(lambda x, a, s, out: None)     # gemm already done above
         rp(None, None, None, tt)
         assert np.allclose(tt.numpy(), out_full.astype(np.float32), rtol=2e-3, atol=0.1)
 
@@ -81,8 +81,16 @@ def test_tp2_sharding_and_allreduce_gloo():
 
 def test_shard_shapes_llama3_tp8():
     # Llama-3-8B, TP=8: column shards of qkv / gate_up, row shards of o / down stay on tile boundaries
-    qkv = torch.zeros((6144, 2048), dtype=torch.int8)
-    assert tp.shard_column_parallel(qkv, (), (), 3, 8)[0].shape == (768, 2048)
+    q_proj = torch.zeros((4096, 2048), dtype=torch.int8)
+    assert tp.shard_column_parallel(q_proj, (), (), 3, 8)[0].shape == (512, 2048)
+    # the fused [q; k; v] tensor: every rank must get 4 query heads + 1 k head + 1 v head, not a contiguous slice
+    qkv = torch.arange(6144, dtype=torch.int32)[:, None].expand(6144, 4).contiguous()
+    rows = tp.shard_fused_column_parallel(qkv, [4096, 1024, 1024], (), (), 3, 8)[0][:, 0]
+    assert rows.tolist() == list(range(1536, 2048)) + list(range(4096 + 384, 4096 + 512)) + list(range(5120 + 384, 5120 + 512))
+    # fewer KV heads than ranks: KV heads replicated over world / Hkv ranks (llama_w4a8_unpad.py:118-127)
+    rows = tp.shard_fused_column_parallel(qkv, [4096, 1024, 1024], (), (), 5, 16, [1, 2, 2])[0][:, 0]
+    assert rows.tolist() == list(range(5 * 256, 6 * 256)) + list(range(4096 + 2 * 128, 4096 + 3 * 128)) + \
+        list(range(5120 + 2 * 128, 5120 + 3 * 128))
     down = torch.zeros((4096, 7168), dtype=torch.int8)
     qw, _ = tp.shard_row_parallel(down, (), 7, 8, group_size=128)
     assert qw.shape == (4096, 896)      # K/8 = 1792 -> 896 bytes per row, 14 groups of 128
