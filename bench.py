@@ -1,22 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- decode throughput of the W4A8KV4 hot path on MI355X (contract: see the task statement).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4,5}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 A "step" = one decode step of a Llama-3-8B-shaped W4A8KV4 model (BASELINE.json configs[1]: per-channel W4A8, KV4,
 bs=64, context 1024 -> +512) over synthetic random-quantised weights and a cache written by the prefill writer:
-32 layers x (4 W4A8 GEMMs + paged KV4 attention + the 5 activation-side kernels) + final norm + fp16 lm_head +
-greedy sampling, replayed from a hipGraph.  N > 1 = tensor parallel over N GPUs (column/row shards, 2 RCCL
-all-reduces per layer), strong scaling (the batch and the model are fixed).
+32 layers x (4 W4A8 GEMMs + paged KV4 attention + the activation-side kernels) + final norm + fp16 lm_head +
+greedy sampling, replayed from a hipGraph.  N > 1 = tensor parallel over N GPUs (column / row shards of the quantised
+weights, 2 RCCL all-reduces per layer); default WEAK scaling (64 sequences per GPU, `--scaling strong` keeps the
+global batch).  `python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run.
 
-Prints ONE JSON line on rank 0 with the contract's keys plus `roofline` (dominant kernel, timed live with HIP events
-on the launch stream) and `cpu_baseline` (the numpy oracle timed on this box's host cores on a bounded sample).
+`--config` selects the other BASELINE.json configurations (3: g128 bs=128; 4: Qwen1.5-72B TP=8 global bs=64, strong;
+5: KV8, 8k context, bs=8); they are parity-test cases first and bench lines only on request.
+
+Prints ONE JSON line on rank 0 with the contract's keys plus
+  roofline         the single kernel with the largest per-step time, timed live with HIP events on the launch stream
+  roofline_family  the W4A8 GEMM family (all four decode GEMMs of a layer): family bytes / family time
+  cpu_baseline     the PyTorch-CPU dequant + matmul / attention path (oracle/torch_cpu.py) on this box's host cores
+  kernels[]        every hot-path kernel at the step's shapes; attention at start / mid / end of generation; the
+                   compute-bound 4096^3 GEMMs (BASELINE configs[0]) with their fraction of the INT8 MFMA peak
+  config.*         step time at mid / end context, eager (no hipGraph) and op-by-op rates, the reference's end-to-end
+                   protocol (prefill + 511 decode steps, qserve_benchmark.py:48-67,108) MEASURED, not composed.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,33 +36,68 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+INT8_PEAK_TOPS = 5000.0   # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4 GHz dense (guide's ubench ceiling: >= 3944)
+
+CONFIGS = {   # BASELINE.json `configs` index -> flags
+    2: dict(model="llama3-8b", batch=64, prompt_len=1024, max_new=512, group_size=-1, kv8=False),
+    3: dict(model="llama3-8b", batch=128, prompt_len=1024, max_new=512, group_size=128, kv8=False),
+    4: dict(model="qwen1.5-72b", batch=64, prompt_len=1024, max_new=512, group_size=-1, kv8=False, scaling="strong", gpus=8),
+    5: dict(model="llama3-8b", batch=8, prompt_len=7680, max_new=512, group_size=-1, kv8=True),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--prompt-len", type=int, default=1024)
-    ap.add_argument("--max-new", type=int, default=512)
-    ap.add_argument("--group-size", type=int, default=-1, choices=[-1, 128])
-    ap.add_argument("--kv8", action="store_true")
-    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama2-7b", "llama2-70b", "qwen1.5-72b", "tiny"])
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS),
+                    help="BASELINE.json configs[] index (1-based as in the task text: 2 = the headline configuration)")
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--prompt-len", type=int, default=None)
+    ap.add_argument("--max-new", type=int, default=None)
+    ap.add_argument("--group-size", type=int, default=None, choices=[-1, 128])
+    ap.add_argument("--kv8", action="store_true", default=None)
+    ap.add_argument("--model", default=None, choices=["llama3-8b", "llama2-7b", "llama2-70b", "qwen1.5-72b", "tiny"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-bench", action="store_true")
-    ap.add_argument("--no-prefill", action="store_true", help="skip the prompt-phase measurement")
+    ap.add_argument("--no-prefill", action="store_true", help="skip the prompt phase / end-to-end protocol measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the context sweep and the eager / op-by-op timings")
     ap.add_argument("--op-by-op", action="store_true",
                     help="issue the reference's ops one by one (no fused pairs) in the timed step")
     ap.add_argument("--gemm-variant", type=int, default=-1, help="A/B: qs_set_gemm_variant code (include/qserve_amd.h)")
+    ap.add_argument("--attn-variant", type=int, default=0, help="A/B: qs_set_attention_variant code")
     ap.add_argument("--tp-full-graph", action="store_true",
                     help="N>1: capture the all-reduces into the step's hipGraph as well (default: one graph per segment "
                          "between the collectives, collectives issued eagerly - independent of capture support in RCCL)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="N>1 (tensor parallel): weak = --batch sequences PER GPU (global batch = batch x N, so every "
                          "rank keeps N=1's GEMM MACs and KV bytes); strong = --batch is the global batch")
-    return ap.parse_args()
+    a = ap.parse_args()
+    preset = CONFIGS[a.config] if a.config else CONFIGS[2]
+    for k, v in preset.items():
+        if getattr(a, k, None) is None:
+            setattr(a, k, v)
+    if a.scaling is None:
+        a.scaling = "weak"
+    if a.gpus is None:
+        a.gpus = 1
+    a.kv8 = bool(a.kv8)
+    return a
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: re-execute under torch.distributed.run with
+    one rank per GPU (the form the driver uses explicitly) and relay its output."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def gemm_bytes(M, N, K, group):
@@ -89,7 +136,16 @@ def time_kernel(fn, reps, torch):
     return e0.elapsed_time(e1) * 1e3 / (4 * reps)
 
 
-def kernel_bench(eng, torch):
+def time_steps(eng, n, torch):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        eng.run()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def kernel_bench(eng, args, torch, contexts):
     """Per-kernel timing of the hot-path kernels at the step's own shapes and data (rotating over the layers so the
     256 MiB Infinity Cache cannot serve the 109 MB of weights per layer)."""
     import qserve_backend.fused_attention as fa
@@ -102,80 +158,120 @@ def kernel_bench(eng, torch):
         lin0 = eng.layers[0][name]
         us = time_kernel(lambda i: eng.layers[i % nl][name](x, eng.q_scale, eng.q_sum, out), 4 * nl, torch)
         by = gemm_bytes(B, lin0.n, lin0.k, eng.group_size)
-        res.append(dict(kernel=f"w4a8_gemm[{name} M={B} N={lin0.n} K={lin0.k}]", us=us, bytes=by,
+        res.append(dict(kernel=f"w4a8_gemm[{name} M={B} N={lin0.n} K={lin0.k}]", family="w4a8_gemm", us=us, bytes=by,
                         gbs=by / us / 1e3, tops=2.0 * B * lin0.n * lin0.k / us / 1e6, per_step=nl))
-    L = int(eng.lengths.max().item())
     q, k, v = eng.qkv_buf.split([eng.H * 128, eng.Hkv * 128, eng.Hkv * 128], dim=-1)
     q, k, v = q.reshape(B, eng.H, 128), k.reshape(B, eng.Hkv, 128), v.reshape(B, eng.Hkv, 128)
     eng.qkv_buf.normal_()
+    saved = eng.lengths.clone()
 
     def attn(i):
         fa.single_query_attention(q, k, v, eng.tables[i % nl], eng.lengths, None, 8192, 64, eng.size_per_token,
                                   eng.max_len, 128, eng.cfg["rope_theta"], True, eng.int4, True)
-    us = time_kernel(attn, 4 * nl, torch)
-    by = attn_bytes(B, eng.H, eng.Hkv, L - 1, eng.int4)
-    res.append(dict(kernel=f"decode_attention[B={B} H={eng.H} Hkv={eng.Hkv} L={L}]", us=us, bytes=by,
-                    gbs=by / us / 1e3, per_step=nl))
+    for j, L in enumerate(contexts):           # context INCLUDING the new token; first entry = the timed step's context
+        eng.lengths.fill_(L)
+        us = time_kernel(attn, 4 * nl, torch)
+        by = attn_bytes(B, eng.H, eng.Hkv, L - 1, eng.int4)
+        res.append(dict(kernel=f"decode_attention[B={B} H={eng.H} Hkv={eng.Hkv} L={L}]", family="decode_attention",
+                        us=us, bytes=by, gbs=by / us / 1e3, frac_of_hbm_peak=by / us / 1e3 / HBM_PEAK_GBS,
+                        per_step=nl if j == 0 else 0))
+    eng.lengths.copy_(saved)
     return res
 
 
-def cpu_baseline(args, cfg):
-    """The numpy oracle ("port" of the reference algorithm) on the host cores, on a bounded sample of the step: the
-    four per-channel GEMMs of a layer at M = batch, repeated over fresh weights for about 10 s, plus decode attention
-    for 16 sequences of the batch; extrapolated to tokens/s of a whole step (layers x (GEMMs + batch sequences))."""
-    import numpy as np
-    from oracle import kvattn, synth, w4a8
+def gemm_config1_bench(torch, dev):
+    """BASELINE.json configs[0] on the GPU: 4096 x 4096 x 4096 W4A8 GEMM, per-channel and per-group, compute-bound;
+    TOPS against the dense INT8 MFMA peak (north_star: >= 70 %)."""
+    import qserve_backend.qgemm_w4a8_per_chn as gc
+    import qserve_backend.qgemm_w4a8_per_group as gg
+    M = N = K = 4096
+    g = torch.Generator(device=dev).manual_seed(4096)
+    nset = 4
+    A = [torch.randint(-127, 128, (M, K), dtype=torch.int8, device=dev, generator=g) for _ in range(nset)]
+    W = [torch.randint(-128, 128, (N, K // 2), dtype=torch.int8, device=dev, generator=g) for _ in range(nset)]
+    ws = (torch.rand((N,), device=dev, generator=g) * 0.01 + 0.002).half()
+    sa = (torch.rand((M,), device=dev, generator=g) * 0.04 + 0.005).half()
+    s2 = torch.randint(1, 9, (K // 128, N), dtype=torch.int8, device=dev, generator=g)
+    z2 = (-(torch.randint(0, 16, (K // 128, N), device=dev, generator=g).to(torch.int16) * s2.to(torch.int16))).to(torch.int8)
+    out = torch.empty((M, N), dtype=torch.float16, device=dev)
+    res = []
+    ops = 2.0 * M * N * K
+    for name, fn, grp in (("per_channel", lambda i: gc.gemm_forward_cuda(A[i % nset], W[i % nset], ws, sa, ws, sa, out), -1),
+                          ("per_group", lambda i: gg.gemm_forward_cuda(A[i % nset], W[i % nset], z2, s2, ws, sa, out), 128)):
+        us = time_kernel(fn, 8, torch)
+        res.append(dict(kernel=f"w4a8_gemm[config1 {name} M={M} N={N} K={K}]", family="w4a8_gemm_compute_bound", us=us,
+                        bytes=gemm_bytes(M, N, K, grp), tops=ops / us / 1e6, frac_of_int8_mfma_peak=ops / us / 1e6 / INT8_PEAK_TOPS,
+                        peak_tops=INT8_PEAK_TOPS, per_step=0))
+    return res
+
+
+def cpu_baseline(args, cfg, torch):
+    """The reference's PyTorch-CPU linear / attention path (oracle/torch_cpu.py: unpack + de-quantise + fp32 matmul; page
+    gather + de-quantise + fp32 softmax attention) on the host cores, on a bounded sample of the step: the four GEMMs of a
+    layer at M = batch over fresh weights for ~10 s, decode attention for 8 sequences; extrapolated to tokens/s of a whole
+    step (layers x (GEMMs + batch sequences))."""
+    from oracle import torch_cpu as T
     B = args.batch
     H, Hkv, hid, inter = cfg["heads"], cfg["kv_heads"], cfg["hidden"], cfg["inter"]
     shapes = [((H + 2 * Hkv) * 128, hid), (hid, hid), (2 * inter, hid), (hid, inter)]
-    rng = np.random.default_rng(0)
+    g = torch.Generator().manual_seed(0)
     t_gemm, reps = 0.0, 0
-    while reps < 2 or (t_gemm < 10.0 and reps < 64):
+    while reps < 2 or (t_gemm < 10.0 and reps < 32):
         for N, K in shapes:
-            A = rng.integers(-127, 128, (B, K), dtype=np.int8)
-            qw = rng.integers(-128, 128, (N, K // 2), dtype=np.int8)
-            ws = rng.uniform(0.002, 0.02, N).astype(np.float16)
-            sa = rng.uniform(0.005, 0.05, B).astype(np.float16)
+            A = torch.randint(-127, 128, (B, K), dtype=torch.int8, generator=g)
+            qw = torch.randint(-128, 128, (N, K // 2), dtype=torch.int8, generator=g)
+            ws = (torch.rand((N,), generator=g) * 0.018 + 0.002).half()
+            sa = (torch.rand((B,), generator=g) * 0.045 + 0.005).half()
             t0 = time.perf_counter()
-            w4a8.gemm_per_chn(A, qw, ws, sa, ws, sa)
-            t_gemm += time.perf_counter() - t0
+            if args.group_size == -1:
+                T.linear_per_channel(A, qw, ws, sa, ws)
+            else:
+                s2 = torch.randint(1, 9, (K // 128, N), dtype=torch.int8, generator=g)
+                T.linear_per_group(A, qw, s2, s2, ws, sa)
+            if reps:                     # first pass = warm-up (thread pool, allocator)
+                t_gemm += time.perf_counter() - t0
         reps += 1
-    t_layer = t_gemm / reps
-    nseq, L = 16, args.prompt_len + 1
-    pr = synth.attention_problem(nseq, H, Hkv, [L] * nseq, seed=1)
-    pool = kvattn.PagePool(pr["nblocks"], Hkv, 128, not args.kv8)
-    pool.k[:] = rng.integers(0, 256, pool.k.shape, dtype=np.uint8)
-    pool.v[:] = rng.integers(0, 256, pool.v.shape, dtype=np.uint8)
-    for p in (pool.k, pool.v):   # sane fp16 scales / zeros
-        meta = p[:, pool.scale_off:].view(np.float16)
-        meta[:] = np.float16(0.25)
+    t_layer = t_gemm / (reps - 1)
+    nseq, L = 8, args.prompt_len
+    int4 = not args.kv8
+    mb = (L + 63) // 64
+    pb = Hkv * 64 * (64 if int4 else 128) + Hkv * 256
+    kp = torch.randint(0, 256, (nseq * mb, pb), dtype=torch.uint8, generator=g)
+    vp = torch.randint(0, 256, (nseq * mb, pb), dtype=torch.uint8, generator=g)
+    nd = Hkv * 64 * (64 if int4 else 128)
+    for p in (kp, vp):                   # sane fp16 scales / zeros
+        p[:, nd:].view(torch.float16).fill_(0.25)
+    tables = torch.stack([torch.randperm(nseq * mb, generator=g).reshape(nseq, mb),
+                          torch.randperm(nseq * mb, generator=g).reshape(nseq, mb)], dim=1)
+    qr = torch.randn((nseq, H, 128), generator=g)
+    T.decode_attention(qr, kp, vp, tables, L, Hkv, int4)
     t0 = time.perf_counter()
-    kvattn.decode_attention(pr["q"], pr["k"], pr["v"], pr["tables"], pr["lengths"], pool, cfg["rope_theta"], "fp32")
-    t_attn_all = time.perf_counter() - t0
-    t_attn = t_attn_all / nseq
+    n_att = 0
+    while n_att < 2 or time.perf_counter() - t0 < 4.0:
+        T.decode_attention(qr, kp, vp, tables, L, Hkv, int4)
+        n_att += 1
+    t_attn = (time.perf_counter() - t0) / n_att / nseq
     step_s = cfg["layers"] * (t_layer + B * t_attn)
-    threads = os.cpu_count()
-    try:                                   # threads numpy's BLAS actually uses for the GEMM slices (the rest is 1 thread)
-        from threadpoolctl import threadpool_info
-        blas = [p["num_threads"] for p in threadpool_info() if p.get("user_api") == "blas"]
-        if blas:
-            threads = max(blas)
-    except Exception:
-        pass
-    return dict(value=B / step_s, unit="tokens/s", cores=threads, kind="port",
-                sample=f"numpy oracle (GEMM slices on numpy's BLAS threads = `cores`, everything else single-threaded), "
-                       f"{t_gemm + t_attn_all:.1f} s of CPU work: one layer's per-channel GEMMs (M={B}) "
-                       f"x {reps} weight sets = {t_layer:.2f} s per layer; decode attention {t_attn:.3f} s/sequence at "
-                       f"L={L} ({nseq} sequences timed); step = {cfg['layers']} layers x (GEMMs + {B} sequences)")
+    return dict(value=B / step_s, unit="tokens/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"PyTorch-CPU path of BASELINE.md section 3 (oracle/torch_cpu.py: unpack + de-quantise + fp32 "
+                       f"torch.matmul; page gather + de-quantise + fp32 softmax attention), torch threads = `cores` of "
+                       f"{os.cpu_count()} logical CPUs, {t_gemm + n_att * t_attn * nseq:.1f} s of CPU work: one layer's "
+                       f"{'per-channel' if args.group_size == -1 else 'g128'} GEMMs (M={B}) x {reps - 1} weight sets = "
+                       f"{t_layer:.3f} s per layer; decode attention {t_attn * 1e3:.2f} ms/sequence at L={L} ({nseq} "
+                       f"sequences x {n_att} runs); step = {cfg['layers']} layers x (GEMMs + {B} sequences)")
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): running tp{world}", file=sys.stderr)
     per_gpu_batch = args.batch
     if world > 1 and args.scaling == "weak":
         args.batch *= world          # global batch; the TP shards (heads / N / K splits) divide the work back
@@ -197,16 +293,23 @@ def main():
         build.build(verbose=False)
     if world > 1:
         dist.barrier()
+    from qserve_amd import _lib
     from qserve_amd import decode as D
     if args.gemm_variant != -1:
-        from qserve_amd import _lib
         _lib.lib.qs_set_gemm_variant(args.gemm_variant)
+    if args.attn_variant != 0:
+        _lib.lib.qs_set_attention_variant(args.attn_variant)
     cfg = {"llama3-8b": D.LLAMA3_8B, "llama2-7b": D.LLAMA2_7B, "llama2-70b": D.LLAMA2_70B, "qwen1.5-72b": D.QWEN15_72B,
            "tiny": D.TINY}[args.model]
     eng = D.DecodeEngine(cfg, args.batch, args.prompt_len, args.max_new, group_size=args.group_size,
                          int4_kv=not args.kv8, device=dev, tp_rank=rank, tp_world=world,
                          fuse_pairs=not args.op_by_op)
-    eng.prefill_cache(args.prompt_len)
+    # the whole cache of the generation (prompt + max_new - 1 positions) is written by the prefill writer up front, so
+    # that any context of the run (start / mid / end) reads real quantised pages; `lengths` selects the context
+    full_ctx = args.prompt_len + args.max_new - 1
+    eng.prefill_cache(full_ctx)
+    start_len = args.prompt_len + 1
+    eng.lengths.fill_(start_len)
     graphed = False
     if not args.no_graph:
         try:
@@ -223,14 +326,15 @@ def main():
             for _ in range(4):
                 try:
                     torch.cuda.synchronize()
-                    eng.lengths.fill_(args.prompt_len + 1)
+                    eng.lengths.fill_(start_len)
                     torch.cuda.synchronize()
                     break
                 except Exception:
                     continue
-    steps2 = 0 if args.op_by_op else min(args.steps, 32)      # secondary timing of the op-by-op sequence
-    assert args.warmup + args.steps + steps2 + 8 <= args.max_new, "steps exceed the page budget (prompt_len + max_new)"
+    eng.lengths.fill_(start_len)
+    assert args.warmup + args.steps + 1 <= args.max_new, "steps exceed the page budget (prompt_len + max_new)"
 
+    # ---- the contract's timed region: W warm-up steps, then exactly K steps between barriers + synchronize ----------
     for _ in range(args.warmup):
         eng.run()
     torch.cuda.synchronize()
@@ -250,28 +354,42 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = dt / args.steps * 1e3
+    extra = {}
 
-    # the same model with every reference op issued on its own (fused pairs off): reported next to the headline value
-    ms_op = None
-    if steps2 and graphed and world == 1:
-        eng.fuse_pairs = False
-        eng.capture()
-        for _ in range(2):
+    # ---- secondary timings (single GPU): other contexts of the generation, eager launches, op-by-op sequence ---------
+    sweep = {}
+    n2 = min(args.steps, 24)
+    mid_len, end_len = args.prompt_len + args.max_new // 2, args.prompt_len + args.max_new - n2 - 3
+    if world == 1 and not args.no_extras:
+        for L in (mid_len, end_len):
+            eng.lengths.fill_(L)
             eng.run()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps2):
-            eng.run()
-        torch.cuda.synchronize()
-        ms_op = (time.perf_counter() - t0) / steps2 * 1e3
-        eng.fuse_pairs = True
+            sweep[L + 1] = round(args.batch / (time_steps(eng, n2, torch) / 1e3), 1)
+        extra["decode_tokens_per_s_by_context"] = {str(start_len + args.warmup): round(args.batch / (ms / 1e3), 1),
+                                                  **{str(k): v for k, v in sweep.items()}}
+        extra["decode_tokens_per_s_mid"] = sweep[mid_len + 1]
+        if graphed:
+            g_saved, p_saved = eng.graph, eng.pieces
+            eng.graph, eng.pieces = None, None
+            eng.lengths.fill_(start_len)
+            for _ in range(2):
+                eng.run()
+            extra["eager_tokens_per_s"] = round(args.batch / (time_steps(eng, n2, torch) / 1e3), 1)
+            eng.graph, eng.pieces = g_saved, p_saved
+            if not args.op_by_op:
+                eng.fuse_pairs = False
+                eng.lengths.fill_(start_len)
+                eng.capture()
+                eng.lengths.fill_(start_len)
+                for _ in range(2):
+                    eng.run()
+                extra["op_by_op_tokens_per_s"] = round(args.batch / (time_steps(eng, n2, torch) / 1e3), 1)
+                eng.fuse_pairs = True
+                eng.graph, eng.pieces = g_saved, p_saved
 
-    # the prompt phase through the same library (W4A8 GEMMs at M = batch*prompt_len, prefill KV writer, causal flash
-    # attention): prompt tokens/s, and the reference's end-to-end protocol (qserve_benchmark.py:48-67,108: generated
-    # tokens / (prefill + decode wall time)) composed from the two measured phases
-    prefill_ms = None
+    # ---- the reference's end-to-end protocol, measured: prompt phase + (max_new - 1) decode steps ---------------------
+    # (qserve_benchmark.py:48-67,108: the prompt step yields the first of `max_new` tokens; tokens / total wall time)
     if not args.no_prefill and world == 1:
-        saved_len = eng.lengths.clone()
         try:
             eng.prefill(args.prompt_len)
             torch.cuda.synchronize()
@@ -279,54 +397,96 @@ def main():
             eng.prefill(args.prompt_len)
             torch.cuda.synchronize()
             prefill_ms = (time.perf_counter() - t0) * 1e3
-            eng.lengths.copy_(saved_len)               # the per-kernel timing below uses the step's context length
+            t1 = time.perf_counter()
+            for _ in range(args.max_new - 1):
+                eng.run()
+            torch.cuda.synchronize()
+            decode_ms = (time.perf_counter() - t1) * 1e3
+            extra.update(prefill_ms=round(prefill_ms, 2),
+                         prefill_tokens_per_s=round(args.batch * args.prompt_len / (prefill_ms / 1e3), 1),
+                         e2e_decode_ms=round(decode_ms, 2),
+                         e2e_tokens_per_s=round(args.batch * args.max_new / ((prefill_ms + decode_ms) / 1e3), 1),
+                         e2e_decode_only_tokens_per_s=round(args.batch * (args.max_new - 1) / (decode_ms / 1e3), 1),
+                         e2e_note="reference protocol (qserve_benchmark.py:48-67,108) MEASURED in this run: one prompt "
+                                  f"phase of {args.batch} x {args.prompt_len} tokens (W4A8 GEMMs, prefill KV writer, causal "
+                                  f"flash attention) + {args.max_new - 1} decode steps; tokens = batch x {args.max_new}")
         except RuntimeError as e:                      # e.g. out of memory for the [tokens, 2*inter] buffer
-            print(f"[bench] prefill phase skipped: {e}", file=sys.stderr)
+            print(f"[bench] end-to-end protocol skipped: {e}", file=sys.stderr)
+        eng.lengths.fill_(start_len + args.warmup)
 
-    roof, kernels = None, None
+    # ---- collective cost (N > 1): one fp16 all-reduce of the row-parallel partial [batch, hidden] ---------------------
+    if world > 1:
+        buf = torch.zeros_like(eng.proj_out)
+        for _ in range(5):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        extra.update(all_reduce_us=round(e0.elapsed_time(e1) * 1e3 / 50, 2), all_reduce_bytes=buf.numel() * 2,
+                     all_reduces_per_step=2 * cfg["layers"], collective_backend=f"{backend} ({world} ranks)")
+
+    # ---- per-kernel timing + roofline ---------------------------------------------------------------------------------
+    roof, roof_family, kernels = None, None, None
     if not args.no_kernel_bench:
         try:
-            kernels = kernel_bench(eng, torch)      # every rank times its own shard's kernels; rank 0 reports
+            ctxs = [start_len + args.warmup]
+            if world == 1 and not args.no_extras:
+                ctxs += [args.prompt_len + args.max_new // 2, args.prompt_len + args.max_new - 1]
+            kernels = kernel_bench(eng, args, torch, ctxs)      # every rank times its own shard's kernels; rank 0 reports
+            if world == 1 and not args.no_extras and args.model == "llama3-8b":
+                kernels += gemm_config1_bench(torch, dev)
         except Exception as e:
             if world == 1:
                 raise
             print(f"[bench] rank {rank}: per-kernel timing skipped ({type(e).__name__}: {e})", file=sys.stderr)
     if kernels is not None:
-        tot = {}
-        for r in kernels:
-            key = "w4a8_gemm" if r["kernel"].startswith("w4a8") else "decode_attention"
-            tot[key] = tot.get(key, 0.0) + r["us"] * r["per_step"]
-        dom_kind = max(tot, key=tot.get)
-        dom = max((r for r in kernels if r["kernel"].startswith(dom_kind)), key=lambda r: r["us"] * r["per_step"])
+        step_k = [r for r in kernels if r["per_step"]]
+        dom = max(step_k, key=lambda r: r["us"] * r["per_step"])          # the single kernel with the largest step share
         # HBM bytes per launch of that kernel from the L2 memory-side PMC counters: they need their own rocprofv3
         # passes (scripts/gpu_pmc.sh), so the committed measurement of the same kernel + shape is quoted here
         traffic, traffic_src = None, None
         try:
             import glob
-            pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            newest = sorted(glob.glob(os.path.join(pdir, "r*_pmc_traffic.json")))[-1]   # named per round
-            ent = json.load(open(newest))["kernels"].get(dom["kernel"])
-            if ent:
-                traffic = ent["hbm_bytes"]
-                traffic_src = f"profiles/{os.path.basename(newest)} ({ent['kernel_symbol']}, rocprofv3 --pmc, offline pass)"
+            pdir = os.path.join(ROOT, "profiles")
+            for cand in sorted(glob.glob(os.path.join(pdir, "*_pmc_traffic.json")), key=os.path.getmtime, reverse=True):
+                ents = json.load(open(cand))["kernels"]
+                ent = ents.get(dom["kernel"]) or next((v for k, v in ents.items() if k.split(" L=")[0] == dom["kernel"].split(" L=")[0]), None)
+                if ent:
+                    traffic = ent["hbm_bytes"]
+                    traffic_src = (f"profiles/{os.path.basename(cand)} ({ent['kernel_symbol']}, rocprofv3 --pmc, offline "
+                                   f"pass{'' if dom['kernel'] in ents else ' at a neighbouring context length'})")
+                    break
         except (OSError, ValueError, KeyError, IndexError):
             pass
         roof = dict(bound="hbm", kernel=dom["kernel"], achieved=round(dom["gbs"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(dom["gbs"] / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
-                    us_per_launch=round(dom["us"], 2), algorithmic_bytes=dom["bytes"])
+                    us_per_launch=round(dom["us"], 2), algorithmic_bytes=dom["bytes"],
+                    step_share=round(dom["us"] * dom["per_step"] / (ms * 1e3), 3))
+        fam = [r for r in step_k if r["family"] == "w4a8_gemm"]
+        fb, fu = sum(r["bytes"] for r in fam), sum(r["us"] for r in fam)
+        roof_family = dict(bound="hbm", family="w4a8_gemm (the four decode GEMMs of a layer)", achieved=round(fb / fu / 1e3, 1),
+                           peak=HBM_PEAK_GBS, unit="GB/s", frac=round(fb / fu / 1e3 / HBM_PEAK_GBS, 4), us_per_layer=round(fu, 2),
+                           algorithmic_bytes=fb, step_share=round(fu * len(eng.layers) / (ms * 1e3), 3))
         for r in kernels:
-            r["us"], r["gbs"] = round(r["us"], 2), round(r["gbs"], 1)
-            if "tops" in r:
-                r["tops"] = round(r["tops"], 1)
+            for k2, nd in (("us", 2), ("gbs", 1), ("tops", 1), ("frac_of_hbm_peak", 4), ("frac_of_int8_mfma_peak", 4)):
+                if k2 in r:
+                    r[k2] = round(r[k2], nd)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, cfg)
+        cpu = cpu_baseline(args, cfg, torch)
         cpu["value"] = round(cpu["value"], 3)
 
     if rank == 0:
+        headline = (args.model == "llama3-8b" and per_gpu_batch == 64 and args.group_size == -1 and not args.kv8
+                    and args.prompt_len == 1024 and args.max_new == 512)
+        cfg_idx = next((i for i, c in CONFIGS.items() if all(getattr(args, k) == v for k, v in c.items()
+                                                              if k not in ("gpus", "scaling", "batch")) and c["batch"] == per_gpu_batch), None)
         out = {
-            "metric": "decode tokens/sec/GPU Llama-3-8B W4A8KV4 bs=64" if args.model == "llama3-8b" and per_gpu_batch == 64
-            else f"decode tokens/sec {cfg['name']} bs={args.batch}",
+            "metric": "decode tokens/sec/GPU Llama-3-8B W4A8KV4 bs=64" if headline else f"decode tokens/sec {cfg['name']} bs={args.batch}",
             "value": round(args.batch / (ms / 1e3), 1),
             "unit": "tokens/s",
             "n_gpus": world,
@@ -340,25 +500,19 @@ def main():
             "data": "synthetic random-quantised weights/activations, KV cache written by the prefill writer",
             "config": {"workload": f"{cfg['name']} W4A8{'g128' if args.group_size == 128 else ' per-channel'} "
                                    f"KV{'8' if args.kv8 else '4'} decode step, bs={args.batch}"
-                                   f"{f' ({per_gpu_batch} per GPU x tp{world})' if world > 1 else ''}, context "
-                                   f"{args.prompt_len}->+{args.max_new} (BASELINE.json configs[1])",
-                       "global_batch": args.batch, "context_start": args.prompt_len + 1 + args.warmup,
+                                   f"{f' ({per_gpu_batch} per GPU x tp{world})' if world > 1 and args.scaling == 'weak' else ''}"
+                                   f", context {args.prompt_len}->+{args.max_new}"
+                                   f"{f' (BASELINE.json configs[{cfg_idx - 1}])' if cfg_idx else ''}",
+                       "global_batch": args.batch, "context_start": start_len + args.warmup,
                        "parallelism": f"tp{world}",
                        "hipgraph": ("piecewise (collectives issued eagerly between the pieces)"
                                     if graphed and world > 1 and not args.tp_full_graph else graphed), "layers": cfg["layers"],
                        "op_sequence": "reference ops one by one" if args.op_by_op else
                        "reference ops; (residual add, layer norm) and (silu_and_mul, quant) issued as bit-identical "
                        "fused pairs (qserve_amd/fused.py)",
-                       "op_by_op_tokens_per_s": round(args.batch / (ms_op / 1e3), 1) if ms_op else None,
-                       "prefill_tokens_per_s": round(args.batch * args.prompt_len / (prefill_ms / 1e3), 1)
-                       if prefill_ms else None,
-                       "prefill_ms": round(prefill_ms, 2) if prefill_ms else None,
-                       "e2e_tokens_per_s": round(args.batch * args.max_new / ((prefill_ms + args.max_new * ms) / 1e3), 1)
-                       if prefill_ms else None,
-                       "e2e_note": "reference protocol (qserve_benchmark.py: generated tokens / (prefill + decode) wall "
-                                   f"time) for {args.max_new} generated tokens per sequence, composed from the measured "
-                                   "prefill time and the measured decode step time"},
+                       **extra},
             "roofline": roof,
+            "roofline_family": roof_family,
             "cpu_baseline": cpu,
             "kernels": kernels,
         }

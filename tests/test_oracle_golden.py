@@ -234,3 +234,46 @@ def test_silu_and_rms_norm_shapes():
     x = np.random.default_rng(5).standard_normal((3, 64)).astype(np.float16)
     assert fused.silu_and_mul(x).shape == (3, 32)
     assert fused.rms_norm(x, np.ones(64, np.float16), 1e-5).shape == (3, 64)
+
+
+def test_torch_cpu_baseline_matches_exact_oracle():
+    """bench.py's cpu_baseline (oracle/torch_cpu.py, the PyTorch-CPU dequant + matmul / attention path of BASELINE.md 3)
+    computes the same GEMM and the same attention as the exact oracle, up to fp32 rounding."""
+    import torch
+    from oracle import torch_cpu as T
+    t = torch.from_numpy
+    pc = synth.per_channel_problem(5, 64, 256, seed=1)
+    out = T.linear_per_channel(t(pc["A"]), t(pc["qweight"]), t(pc["wscales"]), t(pc["ascales"]), t(pc["w_szs"])).numpy()
+    Wd = pc["q"].astype(np.float64) * pc["wscales"].astype(np.float64)[:, None] - pc["w_szs"].astype(np.float64)[:, None]
+    assert np.abs(out - (pc["A"].astype(np.float64) * pc["ascales"].astype(np.float64)[:, None]) @ Wd.T).max() < 1e-4
+    pg = synth.per_group_problem(5, 64, 256, seed=2)
+    out = T.linear_per_group(t(pg["A"]), t(pg["qweight"]), t(pg["s2_zeros"]), t(pg["s2_scales"]), t(pg["wscales"]),
+                             t(pg["ascales"])).numpy()
+    w8 = w4a8.dequant_per_group_w8(pg["qweight"], pg["s2_zeros"], pg["s2_scales"]).astype(np.float64)
+    ref = (pg["A"].astype(np.float64) * pg["ascales"].astype(np.float64)[:, None]) @ (w8 * pg["wscales"].astype(np.float64)[:, None]).T
+    assert np.abs(out - ref).max() < 1e-4
+    for int4 in (True, False):
+        r = np.random.default_rng(3)
+        B, H, Hkv, L = 2, 4, 2, 100
+        pool = kvattn.PagePool(6, Hkv, 128, int4)
+        tables = np.stack([r.permutation(6)[:4].reshape(2, 2), r.permutation(6)[:4].reshape(2, 2)], 1)
+        for b in range(B):
+            for pos in range(L):
+                for which in ("k", "v"):
+                    x = r.standard_normal((Hkv, 128)).astype(np.float16)
+                    qb, sc, zr = kvattn.kv_quantize(x, int4)
+                    for h in range(Hkv):
+                        pool.write_token(which, int(tables[b, 0 if which == "k" else 1, pos // 64]), pos % 64, h, qb[h], sc[h], zr[h])
+        q = r.standard_normal((B, H, 128)).astype(np.float32)
+        got = T.decode_attention(t(q), t(pool.k), t(pool.v), t(tables.astype(np.int64)), L, Hkv, int4).numpy()
+        for b in range(B):
+            for hk in range(Hkv):
+                kq, ks, kz = pool.read_tokens("k", tables[b, 0], hk, L)
+                vq, vs, vz = pool.read_tokens("v", tables[b, 1], hk, L)
+                Kd = kvattn.kv_dequantize(kq, ks, kz, int4, "exact").astype(np.float64)
+                Vd = kvattn.kv_dequantize(vq, vs, vz, int4, "exact").astype(np.float64)
+                for g in range(H // Hkv):
+                    s = Kd @ q[b, hk * 2 + g].astype(np.float64) / np.sqrt(128.0)
+                    p = np.exp(s - s.max())
+                    ref = (p / p.sum()) @ Vd
+                    assert np.abs(got[b, hk * 2 + g] - ref).max() < 1e-4
