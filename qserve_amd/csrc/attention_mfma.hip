@@ -68,17 +68,23 @@ __device__ __forceinline__ QParams make_qparams(float mn, float mx) {
     p.inv = 1.0f / (float)p.scale;
     return p;
 }
-__device__ __forceinline__ void wave_quant_store4(_Float16 v0, _Float16 v1, uint8_t* dst, __half* scale_p,
-                                                  __half* zero_p, int lane) {
-    const float mx = wave_max(fmaxf((float)v0, (float)v1));
-    const float mn = wave_min(fminf((float)v0, (float)v1));
+// (explicit global address space: a generic pointer would make these FLAT stores, and a flat access may alias LDS, so
+// the compiler drains the LDS-DMA queue - vmcnt(0) - in front of it)
+typedef __attribute__((address_space(1))) uint8_t* g_u8;
+typedef __attribute__((address_space(1))) uint16_t* g_u16;
+__device__ __forceinline__ void wave_quant_store4(_Float16 v0, _Float16 v1, uint8_t* dst_, __half* scale_p_,
+                                                  __half* zero_p_, int lane) {
+    g_u8 dst = (g_u8)dst_;
+    g_u16 scale_p = (g_u16)reinterpret_cast<uint16_t*>(scale_p_), zero_p = (g_u16)reinterpret_cast<uint16_t*>(zero_p_);
+    const float mx = wave_max_dpp(fmaxf((float)v0, (float)v1));   // (max / min are order-independent: bit-exact)
+    const float mn = wave_min_dpp(fminf((float)v0, (float)v1));
     const QParams p = make_qparams(mn, mx);
     const unsigned u0 = rni_sat_u8(fmaf((float)v0, p.inv, (float)p.zero));
     const unsigned u1 = rni_sat_u8(fmaf((float)v1, p.inv, (float)p.zero));
     dst[lane] = (uint8_t)((u0 & 0xFu) | (u1 << 4));
     if (lane == 0) {
-        *scale_p = __builtin_bit_cast(__half, p.scale);
-        *zero_p = __builtin_bit_cast(__half, p.zero);
+        *scale_p = __builtin_bit_cast(uint16_t, p.scale);
+        *zero_p = __builtin_bit_cast(uint16_t, p.zero);
     }
 }
 
@@ -94,7 +100,10 @@ __device__ __forceinline__ u32 and_or(u32 x, u32 m, u32 c) {
 
 typedef __attribute__((address_space(3))) const uint8_t* lds_u8;   // 32-bit LDS address (keeps ds_read, not flat_load)
 
-template <int G>
+// EXP: timing / ablation switches (qs_set_attention_variant(200 + EXP), G = 4 only; default 0 = the product kernel):
+//   1 = non-temporal LDS-DMA (aux nt), 2 = no compute (DMA + waits only: results are wrong by design),
+//   4 = skip phase A (RoPE / new token: wrong by design), 8 = partial load of the last page
+template <int G, int EXP = 0>
 __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
     const int64_t* __restrict__ kv_pointers, const int* __restrict__ lengths, _Float16* __restrict__ out,
@@ -112,6 +121,15 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hkv = blockIdx.x, b = blockIdx.y;
+    // EXP & 32: timeline trace (s_memtime stamps of lane 0 of every wave into the split workspace; timing tool only)
+    auto stamp = [&](int i) {
+        if constexpr (EXP & 32) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0)
+                reinterpret_cast<unsigned long long*>(ws)[(((size_t)b * gridDim.x + hkv) * NW + wave) * 16 + i] = t;
+        }
+    };
+    stamp(0);
     const int64_t* ktab = kv_pointers + (size_t)b * 2 * max_blocks;
     const int64_t* vtab = ktab + max_blocks;
     // first-round page addresses are requested together with the length (they do not depend on it when this workgroup
@@ -124,6 +142,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     }
     const int tl = lengths ? lengths[b] - 1 : timestep;   // tlength, Template.hpp:901
     if (tl < 0) return;
+    stamp(1);
     const float inv_sqrt = 0.08838834764831845f;
     const float qk_scale = inv_sqrt * 1.4426950408889634f;   // scores live in the log2 domain: exp2 everywhere
     constexpr int GP = G <= 1 ? 1 : G <= 2 ? 2 : G <= 4 ? 4 : 8;   // group size padded to a power of two (lane mapping)
@@ -146,76 +165,156 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     auto page_addr = [&](int which, int p) -> int64_t {      // in-loop lookup (the dispatcher guarantees p < MAXP)
         return s_ptab[which][p];
     };
-    auto dma_k = [&](int64_t page) {     // 4 x 1 KiB data + 256 B (scales | zeros): 5 VMEM instructions
+    // LDS-DMA issued from inline asm (recipe: cdna_hip_programming.md 5.7 - M0 carries the wave-uniform LDS base and is
+    // written in the statement that reads it).  Deliberately NOT the builtin: the compiler's waitcnt pass models every
+    // builtin LDS-DMA as a pending LDS write and puts a vmcnt(0) in front of the next ds_read of the page loop as soon
+    // as pages are in flight at loop entry - which serialises fetch and compute and makes the counted waits below
+    // meaningless.  With asm the compiler sees no DMA at all; every wait on this queue is explicit (vmcnt(10) / (5) / (0)).
+    auto dma16 = [&](const uint8_t* g, uint8_t* l) {
+        u32 keep;
+        const u32 ldst = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)(lptr_t)l);   // provably wave-uniform for the "s" operand
+        if constexpr (EXP & 1)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(ldst) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(ldst) : "memory");
+    };
+    auto dma4 = [&](const void* g, const void* l) {       // per-lane source, 4 B per lane: 256 B per wave instruction
+        u32 keep;
+        const u32 ldst = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)(lptr_t)l);   // provably wave-uniform for the "s" operand
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(ldst) : "memory");
+    };
+    auto dma_k = [&](int64_t page, int valid_tok = PAGE_TOK) {     // 4 x 1 KiB data + 256 B (scales | zeros): 5 VMEM instructions
         const uint8_t* kbase = reinterpret_cast<const uint8_t*>(page);
         const uint8_t* kd = kbase + (u32)(hkv * PAGE_TOK * DHB + lane * 16);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            __builtin_amdgcn_global_load_lds((gptr_t)(kd + e * 1024), (lptr_t)(s_kw + e * 1024), 16, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (EXP & 8) {
+                // lanes of tokens >= valid stay idle (their bytes are never read: masked scores / zero probabilities);
+                // lane 0 always loads so that the instruction issues and the vmcnt bookkeeping holds
+                if (16 * e + (lane >> 2) < valid_tok || lane == 0) dma16(kd + e * 1024, s_kw + e * 1024);
+            } else {
+                dma16(kd + e * 1024, s_kw + e * 1024);
+            }
+        }
         const uint8_t* mb = kbase + (u32)(num_kv_heads * PAGE_TOK * DHB +
                                           ((lane >> 5) * num_kv_heads + hkv) * PAGE_TOK * 2 + (lane & 31) * 4);
-        __builtin_amdgcn_global_load_lds((gptr_t)mb, (lptr_t)(&s_meta[wave][0][0]), 4, 0, 0);
+        dma4(mb, &s_meta[wave][0][0]);
     };
-    auto dma_v = [&](int64_t page) {
+    auto dma_v = [&](int64_t page, int valid_tok = PAGE_TOK) {
         const uint8_t* vbase = reinterpret_cast<const uint8_t*>(page);
         const uint8_t* vd = vbase + (u32)(hkv * PAGE_TOK * DHB + lane * 16);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            __builtin_amdgcn_global_load_lds((gptr_t)(vd + e * 1024), (lptr_t)(s_vw + e * 1024), 16, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (EXP & 8) {
+                if (16 * e + (lane >> 2) < valid_tok || lane == 0) dma16(vd + e * 1024, s_vw + e * 1024);
+            } else {
+                dma16(vd + e * 1024, s_vw + e * 1024);
+            }
+        }
         const uint8_t* mb = vbase + (u32)(num_kv_heads * PAGE_TOK * DHB +
                                           ((lane >> 5) * num_kv_heads + hkv) * PAGE_TOK * 2 + (lane & 31) * 4);
-        __builtin_amdgcn_global_load_lds((gptr_t)mb, (lptr_t)(&s_meta[wave][2][0]), 4, 0, 0);
+        dma4(mb, &s_meta[wave][2][0]);
     };
-    if (p_begin + wave < p_end) {
-        dma_k(spec ? kpage0 : ktab[p_begin + wave]);
-        dma_v(spec ? vpage0 : vtab[p_begin + wave]);
-    }
-    for (int i = tid; i < 2 * MAXP; i += NW * 64) {
-        const int pi = i >> 1;
-        if (pi < npages) s_ptab[i & 1][pi] = (i & 1) ? vtab[pi] : ktab[pi];
-    }
-
-    // ---- phase A: RoPE of the G query heads and of k; quantise + store the new token's K and V ------------------
     const _Float16* qb = q + (size_t)b * q_stride0 + (size_t)hkv * G * DH;
     const _Float16* kb = k + (size_t)b * kv_stride0 + (size_t)hkv * DH;
     const _Float16* vb = v + (size_t)b * kv_stride0 + (size_t)hkv * DH;
-    if (tid < 64) {
-        RopeCS cs;
-        if (rope_tab && tl < rope_tab_len) {
-            const float2 t = rope_tab[(size_t)tl * 64 + tid];   // same double-evaluated, float-rounded values
-            cs.c = t.x;
-            cs.s = t.y;
-        } else {
-            cs = rope_coef(tid, tl, rope_base, DH);
-        }
-#pragma unroll
-        for (int h = 0; h < G; ++h) {
-            _Float16 a, bb;
-            rope_pair((float)qb[h * DH + tid], (float)qb[h * DH + 64 + tid], cs, a, bb);
-            s_q[h][tid] = a;
-            s_q[h][64 + tid] = bb;
-        }
-        _Float16 a, bb;
-        rope_pair((float)kb[tid], (float)kb[64 + tid], cs, a, bb);
-        s_knew[tid] = a;
-        s_knew[64 + tid] = bb;
-    }
-    __syncthreads();
-    {
+    if constexpr (!(EXP & 16)) {
+        // ---- phase A overlapped with the first page fetch ---------------------------------------------------------------
+        // The vmcnt queue is in order: anything requested AFTER the LDS-DMA of the first pages can only be waited for
+        // together with those pages (2-5 us under the launch burst), and a workgroup barrier behind such a wait makes
+        // every wave wait for the slowest page.  So every global input of phase A (the G query rows, k, v, the RoPE
+        // coefficients of position tl, the page table) is itself fetched by LDS-DMA, ISSUED BEFORE the page DMA and
+        // waited for with a counted vmcnt(10) that leaves the ten page operations in flight (no VGPR destination: the
+        // compiler inserts no wait of its own); the page DMA is issued unconditionally (a wave without a page in the
+        // first round fetches the new token's page - always a valid address - so that "10 younger operations" holds
+        // on every path), and the two phase-A barriers are raw s_barrier + lgkmcnt(0) (no vmcnt drain).  RoPE, the new
+        // token's quantisation and the operand build all run while the first pages are in flight.
+        // Staging area = the not-yet-built Q.K^T operand s_qp: rows 0..G-1 raw q, row 8 raw k, row 9 raw v, rows 10-11
+        // the 64 (cos, sin) pairs.
         const int blk = tl >> 6, slot = tl & 63;
-        if (wave == 0 && z == 0) {
-            uint8_t* pg = reinterpret_cast<uint8_t*>(ktab[blk]);
-            __half* sc = reinterpret_cast<__half*>(pg + (size_t)num_kv_heads * PAGE_TOK * DHB);
-            wave_quant_store4(s_knew[2 * lane], s_knew[2 * lane + 1], pg + ((size_t)hkv * PAGE_TOK + slot) * DHB,
-                              sc + hkv * PAGE_TOK + slot, sc + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
-        } else if (wave == 1 && z == 0) {
-            uint8_t* pg = reinterpret_cast<uint8_t*>(vtab[blk]);
-            __half* sc = reinterpret_cast<__half*>(pg + (size_t)num_kv_heads * PAGE_TOK * DHB);
-            wave_quant_store4(vb[2 * lane], vb[2 * lane + 1], pg + ((size_t)hkv * PAGE_TOK + slot) * DHB,
-                              sc + hkv * PAGE_TOK + slot, sc + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
-        } else if (wave == 2) {
-            // B operand of Q.K^T for lane (head li, kg = tg), MFMA w: dims 32tg + 8w + {0,4,1,5,2,6,3,7}; the positions
-            // that meet hi-nibble operands (1024 + 16 n) carry q/16
+        // every page-table entry phase A needs is loaded HERE, before the first asm statement: behind an asm with a
+        // "memory" clobber the compiler may no longer use scalar loads for kv_pointers (possible aliasing write) and a
+        // vector load would sit in the vmcnt queue behind the page DMA
+        const int64_t knew_page = ktab[blk], vnew_page = vtab[blk];
+        const bool has_page = p_begin + wave < p_end;
+        int64_t kfirst = kpage0, vfirst = vpage0;
+        if (has_page && !spec) {
+            kfirst = ktab[p_begin + wave];
+            vfirst = vtab[p_begin + wave];
+        }
+        uint8_t* const raw = reinterpret_cast<uint8_t*>(&s_qp[0][0]);
+        const bool have_tab = rope_tab && tl < rope_tab_len;
+        auto dmaA = [&](const void* g, uint8_t* l) {      // 256 B per wave instruction, lane-linear
+            dma4(reinterpret_cast<const uint8_t*>(g) + lane * 4, l);
+        };
+        auto issue = [&](int64_t kp, int64_t vp, int vt0) {
+            if constexpr (!(EXP & 4)) {
+                if (wave == 0) {
+#pragma unroll
+                    for (int h = 0; h < G; ++h) dmaA(qb + h * DH, raw + h * 256);
+                    dmaA(kb, raw + 8 * 256);
+                    if (have_tab) {
+                        dmaA(rope_tab + (size_t)tl * 64, raw + 10 * 256);
+                        dmaA(rope_tab + (size_t)tl * 64 + 32, raw + 11 * 256);
+                    }
+                } else if (wave == 1) {
+                    dmaA(vb, raw + 9 * 256);
+                }
+            }
+            if (wave == 0) {                                   // page table -> LDS: 32 entries (256 B) per instruction
+                for (int c = 0; c * 32 < npages; ++c) {
+                    if (c * 64 + lane < 2 * npages) {
+                        dma4(reinterpret_cast<const uint8_t*>(ktab + c * 32) + lane * 4, &s_ptab[0][c * 32]);
+                        dma4(reinterpret_cast<const uint8_t*>(vtab + c * 32) + lane * 4, &s_ptab[1][c * 32]);
+                    }
+                }
+            }
+            dma_k(kp, vt0);
+            dma_v(vp, vt0);
+        };
+        // first-round page of this wave: its address was requested together with the length; only a wave WITHOUT a page
+        // (short contexts, split tails) has to fetch the fall-back address first - a wave-uniform branch, so that the
+        // common path issues its DMA without waiting for that extra dependent load
+        if (has_page) issue(kfirst, vfirst, min(PAGE_TOK, tl - (p_begin + wave) * PAGE_TOK));
+        else issue(knew_page, vnew_page, PAGE_TOK);
+        stamp(2);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // everything older than this wave's ten page operations
+        stamp(3);
+        u32 vpair = 0;
+        if constexpr (!(EXP & 4)) {
+            if (wave == 0) {
+                RopeCS cs;
+                if (have_tab) {
+                    const float2 t = reinterpret_cast<const float2*>(raw + 10 * 256)[lane];
+                    cs.c = t.x;
+                    cs.s = t.y;
+                } else {
+                    cs = rope_coef(lane, tl, rope_base, DH);
+                }
+                const _Float16* rq = reinterpret_cast<const _Float16*>(raw);
+                _Float16 ra[G + 1], rb[G + 1];
+#pragma unroll
+                for (int h = 0; h < G; ++h) rope_pair((float)rq[h * DH + lane], (float)rq[h * DH + 64 + lane], cs, ra[h], rb[h]);
+                rope_pair((float)rq[8 * DH + lane], (float)rq[8 * DH + 64 + lane], cs, ra[G], rb[G]);
+#pragma unroll
+                for (int h = 0; h < G; ++h) {
+                    s_q[h][lane] = ra[h];
+                    s_q[h][64 + lane] = rb[h];
+                }
+                s_knew[lane] = ra[G];
+                s_knew[64 + lane] = rb[G];
+            } else if (wave == 1) {
+                vpair = reinterpret_cast<const u32*>(raw + 9 * 256)[lane];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ONLY phase-A barrier: rotated q / k visible
+        if constexpr (!(EXP & 4)) {
+            // B operand of Q.K^T for lane (head li, kg = tg), MFMA w: dims 32tg + 8w + {0,4,1,5,2,6,3,7}; the positions that
+            // meet hi-nibble operands (1024 + 16 n) carry q/16.  EVERY wave writes the whole (identical) operand image, so
+            // each wave only depends on its own LDS writes and no second barrier stands between RoPE and the first Q.K^T.
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 h8 x = {0, 0, 0, 0, 0, 0, 0, 0};                       // heads >= G: zero rows of the operand
@@ -224,15 +323,96 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
                 *reinterpret_cast<h8*>(&s_qp[li][32 * tg + 8 * w]) =
                     (h8){x[0], x[4], x[1] * s16, x[5] * s16, x[2], x[6], x[3] * s16, x[7] * s16};
             }
-        } else {
-            for (int h = wave - 3; h < G; h += NW - 3) {
-                float d = (float)s_q[h][lane] * (float)s_knew[lane] + (float)s_q[h][64 + lane] * (float)s_knew[64 + lane];
-                d = wave_sum(d);
-                if (lane == 0) s_cur[h] = d * qk_scale;
+            // the rest of phase A has no consumer before the final merge: the new token's cache write (waves 0 / 1,
+            // split 0) and its own score (waves 3..)
+            if (wave == 0 && z == 0) {
+                uint8_t* pg = reinterpret_cast<uint8_t*>(knew_page);
+                __half* sc = reinterpret_cast<__half*>(pg + (size_t)num_kv_heads * PAGE_TOK * DHB);
+                wave_quant_store4(s_knew[2 * lane], s_knew[2 * lane + 1], pg + ((size_t)hkv * PAGE_TOK + slot) * DHB,
+                                  sc + hkv * PAGE_TOK + slot, sc + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
+            } else if (wave == 1 && z == 0) {
+                uint8_t* pg = reinterpret_cast<uint8_t*>(vnew_page);
+                __half* sc = reinterpret_cast<__half*>(pg + (size_t)num_kv_heads * PAGE_TOK * DHB);
+                const h2 vv = __builtin_bit_cast(h2, vpair);
+                wave_quant_store4(vv[0], vv[1], pg + ((size_t)hkv * PAGE_TOK + slot) * DHB, sc + hkv * PAGE_TOK + slot,
+                                  sc + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
+            } else if (wave >= 3) {
+                for (int h = wave - 3; h < G; h += NW - 3) {
+                    float d = (float)s_q[h][lane] * (float)s_knew[lane] + (float)s_q[h][64 + lane] * (float)s_knew[64 + lane];
+                    d = wave_sum_dpp(d);
+                    if (lane == 0) s_cur[h] = d * qk_scale;
+                }
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(4);
+    } else {
+        if (p_begin + wave < p_end) {
+            const int vt0 = min(PAGE_TOK, tl - (p_begin + wave) * PAGE_TOK);
+            dma_k(spec ? kpage0 : ktab[p_begin + wave], vt0);
+            dma_v(spec ? vpage0 : vtab[p_begin + wave], vt0);
+        }
+        for (int i = tid; i < 2 * MAXP; i += NW * 64) {
+            const int pi = i >> 1;
+            if (pi < npages) s_ptab[i & 1][pi] = (i & 1) ? vtab[pi] : ktab[pi];
+        }
+
+        // ---- phase A (round-1 form, kept for in-run A/B): RoPE of the G query heads and of k; quantise + store ---------
+        if (!(EXP & 4) && tid < 64) {
+            RopeCS cs;
+            if (rope_tab && tl < rope_tab_len) {
+                const float2 t = rope_tab[(size_t)tl * 64 + tid];   // same double-evaluated, float-rounded values
+                cs.c = t.x;
+                cs.s = t.y;
+            } else {
+                cs = rope_coef(tid, tl, rope_base, DH);
+            }
+    #pragma unroll
+            for (int h = 0; h < G; ++h) {
+                _Float16 a, bb;
+                rope_pair((float)qb[h * DH + tid], (float)qb[h * DH + 64 + tid], cs, a, bb);
+                s_q[h][tid] = a;
+                s_q[h][64 + tid] = bb;
+            }
+            _Float16 a, bb;
+            rope_pair((float)kb[tid], (float)kb[64 + tid], cs, a, bb);
+            s_knew[tid] = a;
+            s_knew[64 + tid] = bb;
+        }
+        __syncthreads();
+        if (!(EXP & 4)) {
+            const int blk = tl >> 6, slot = tl & 63;
+            if (wave == 0 && z == 0) {
+                uint8_t* pg = reinterpret_cast<uint8_t*>(ktab[blk]);
+                __half* sc = reinterpret_cast<__half*>(pg + (size_t)num_kv_heads * PAGE_TOK * DHB);
+                wave_quant_store4(s_knew[2 * lane], s_knew[2 * lane + 1], pg + ((size_t)hkv * PAGE_TOK + slot) * DHB,
+                                  sc + hkv * PAGE_TOK + slot, sc + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
+            } else if (wave == 1 && z == 0) {
+                uint8_t* pg = reinterpret_cast<uint8_t*>(vtab[blk]);
+                __half* sc = reinterpret_cast<__half*>(pg + (size_t)num_kv_heads * PAGE_TOK * DHB);
+                wave_quant_store4(vb[2 * lane], vb[2 * lane + 1], pg + ((size_t)hkv * PAGE_TOK + slot) * DHB,
+                                  sc + hkv * PAGE_TOK + slot, sc + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
+            } else if (wave == 2) {
+                // B operand of Q.K^T for lane (head li, kg = tg), MFMA w: dims 32tg + 8w + {0,4,1,5,2,6,3,7}; the positions
+                // that meet hi-nibble operands (1024 + 16 n) carry q/16
+    #pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    h8 x = {0, 0, 0, 0, 0, 0, 0, 0};                       // heads >= G: zero rows of the operand
+                    if (li < G) x = *reinterpret_cast<const h8*>(&s_q[li][32 * tg + 8 * w]);
+                    const _Float16 s16 = (_Float16)0.0625f;
+                    *reinterpret_cast<h8*>(&s_qp[li][32 * tg + 8 * w]) =
+                        (h8){x[0], x[4], x[1] * s16, x[5] * s16, x[2], x[6], x[3] * s16, x[7] * s16};
+                }
+            } else {
+                for (int h = wave - 3; h < G; h += NW - 3) {
+                    float d = (float)s_q[h][lane] * (float)s_knew[lane] + (float)s_q[h][64 + lane] * (float)s_knew[64 + lane];
+                    d = wave_sum(d);
+                    if (lane == 0) s_cur[h] = d * qk_scale;
+                }
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     // per-lane constants of head li: qsum = sum_d q_eff_d and Qoff = sum over the operand of 1024 * q' (the offset that
     // the 1024+n / 1024+16n operand form adds to the raw dot product); q_eff = what the MFMA effectively multiplies n by
@@ -266,9 +446,17 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     for (int p = p_begin + wave; p < p_end; p += NW) {
         // K(p) landed?  Outstanding younger VMEM ops at this point: the 5 of V(p).
         asm volatile("s_waitcnt vmcnt(5) ; QS_LOOP_BEGIN" ::: "memory");
+        stamp(5 + 2 * min(2, (p - p_begin) / NW));
         const bool more = p + NW < p_end;
         const int valid = min(PAGE_TOK, tl - p * PAGE_TOK);
         const bool full = valid == PAGE_TOK;   // wave-uniform: only the last page needs masking
+        if constexpr (EXP & 2) {               // timing experiment: memory side only
+            if (more) dma_k(page_addr(0, p + NW), min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
+            if (more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (more) dma_v(page_addr(1, p + NW), min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
+            continue;
+        }
 
         // one opaque per-lane base per buffer: every operand read below is base + immediate (without this the compiler
         // hoists a dozen loop-invariant address registers out of the loop and spills them)
@@ -341,7 +529,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             }
             // K buffer consumed -> request K(p+NW)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (more) dma_k(page_addr(0, p + NW));
+            if (more) dma_k(page_addr(0, p + NW), min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
             float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
             if constexpr (GP == 4) {
                 mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx),
@@ -391,7 +579,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             }
             // K buffer consumed -> request K(p+NW)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (more) dma_k(page_addr(0, p + NW));
+            if (more) dma_k(page_addr(0, p + NW), min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
             float mx = sc8[0];
 #pragma unroll
             for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc8[j]);
@@ -510,7 +698,8 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0) ; QS_LOOP_END" ::: "memory");
-        if (more) dma_v(page_addr(1, p + NW));
+        stamp(6 + 2 * min(2, (p - p_begin) / NW));
+        if (more) dma_v(page_addr(1, p + NW), min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
     }
 
     // ---- per-wave partials -> LDS.  Lane (head li, tg) holds out dims 8*(4tg + r) + e in acc[e][r] ---------------
@@ -536,7 +725,12 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     corr += xor_lane(corr, lid2, 32);
     psum += xor_lane(psum, lid2, 16);
     psum += xor_lane(psum, lid2, 32);
+    // every LDS-DMA of this wave has landed (a wave without pages never waited for its first-round fetch, and the merge
+    // area below aliases the page buffers)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(12);
     __syncthreads();   // every wave is done with its page buffers: reuse s_k as the [NW][G][DH+4] fp32 merge area
+    stamp(13);
     constexpr int OS = DH + 4;
     float (*s_o)[G][OS] = reinterpret_cast<float (*)[G][OS]>(&s_kv[0]);
     static_assert(sizeof(float) * NW * G * OS <= sizeof(s_kv), "merge area must fit the page buffers");
@@ -552,6 +746,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         }
     }
     __syncthreads();
+    stamp(14);
     for (int o = tid2; o < G * DH; o += NW * 64) {
         const int h = o / DH, d = o % DH;
         float M = z == 0 ? s_cur[h] : -3.0e38f;
@@ -576,6 +771,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             }
         }
     }
+    stamp(15);
 }
 
 // second phase of split-KV: one workgroup per (sequence, query head) combines the nsplit partials
@@ -687,6 +883,12 @@ float* qs_split_workspace(size_t bytes, hipStream_t st) {
     return w.p;
 }
 size_t qs_split_workspace_capacity() { return SPLIT_WS_BYTES; }
+// timing tool (scripts/trace_attn.py): copy the first `bytes` of the split workspace (the EXP & 32 timeline stamps) to dst
+extern "C" int qs_debug_copy_split_workspace(void* dst, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !g_ws[dev].p || bytes > SPLIT_WS_BYTES) return QS_EINVAL;
+    return (int)hipMemcpy(dst, g_ws[dev].p, bytes, hipMemcpyDeviceToDevice);
+}
 
 // called from attention.hip's dispatcher for KV4.  force_split: 0 = heuristic, n > 0 = exactly n splits (tests)
 int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
@@ -695,6 +897,11 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
     if (G < 1 || G > 8) {
         qs_set_error("single_query_attention: num_heads/num_kv_heads = %d not in 1..8", G);
         return QS_ENOSUP;
+    }
+    int exp_flags = 0;                      // qs_set_attention_variant(200 + EXP): ablation builds of the G = 4 kernel
+    if (force_split >= 100) {
+        exp_flags = force_split - 100;
+        force_split = 0;
     }
     int tab_len = 0;
     const float2* tab = g_qs_attn_plan.active ? nullptr : qs_rope_table(base, max_pos, st, &tab_len);
@@ -724,6 +931,32 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
 #define QS_LAUNCH_G(GG)                                                                                             \
     hipLaunchKernelGGL((decode_attention_mfma_kernel<GG>), grid, dim3(NW * 64), 0, st, q, k, v, kvp, len, out, H, Hkv, \
                        qs, kvs, mb, timestep, base, tab, tab_len, nsplit, ws)
+#define QS_LAUNCH_EXP(E)                                                                                              \
+    case E:                                                                                                            \
+        hipLaunchKernelGGL((decode_attention_mfma_kernel<4, E>), grid, dim3(NW * 64), 0, st, q, k, v, kvp, len, out, H,   \
+                           Hkv, qs, kvs, mb, timestep, base, tab, tab_len, nsplit, ws);                                \
+        return qs_launch_status("single_query_attention")
+    if (exp_flags & 32) {                     // timeline trace: stamps go to the (otherwise unused) split workspace
+        ws = qs_split_workspace((size_t)blocks * NW * 16 * 8, st);
+        if (!ws) exp_flags = 0;
+    }
+    if (G == 4 && exp_flags > 0 && nsplit == 1) {
+        switch (exp_flags) {
+            QS_LAUNCH_EXP(1);
+            QS_LAUNCH_EXP(2);
+            QS_LAUNCH_EXP(3);
+            QS_LAUNCH_EXP(4);
+            QS_LAUNCH_EXP(8);
+            QS_LAUNCH_EXP(9);
+            QS_LAUNCH_EXP(6);
+            QS_LAUNCH_EXP(16);
+            QS_LAUNCH_EXP(17);
+            QS_LAUNCH_EXP(25);
+            QS_LAUNCH_EXP(32);
+            QS_LAUNCH_EXP(41);
+            default: break;
+        }
+    }
     switch (G) {
         case 1: QS_LAUNCH_G(1); break;
         case 2: QS_LAUNCH_G(2); break;

@@ -60,6 +60,34 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// wave64 all-reduce on the DPP crossbar (no LDS traffic, ~10 short instructions instead of six dependent ds_bpermute
+// round trips): xor-1 / xor-2 inside the quads, row_half_mirror and row_mirror inside each 16-lane row, then the four row
+// results through v_readlane.  Every lane receives the result.
+template <class Op>
+__device__ __forceinline__ float wave_allreduce_dpp(float v, Op op) {
+#define QS_DPP(ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+    v = op(v, QS_DPP(0xB1));    // quad_perm [1,0,3,2]
+    v = op(v, QS_DPP(0x4E));    // quad_perm [2,3,0,1]
+    v = op(v, QS_DPP(0x141));   // row_half_mirror
+    v = op(v, QS_DPP(0x140));   // row_mirror
+#undef QS_DPP
+    const int x = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 48));
+    return op(op(r0, r1), op(r2, r3));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    return wave_allreduce_dpp(v, [](float a, float b) { return fmaxf(a, b); });
+}
+__device__ __forceinline__ float wave_min_dpp(float v) {
+    return wave_allreduce_dpp(v, [](float a, float b) { return fminf(a, b); });
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    return wave_allreduce_dpp(v, [](float a, float b) { return a + b; });
+}
+
 // cvt.rni.sat.{s8,u8}.f32 equivalents: round-to-nearest-even then saturate (NaN -> 0)
 // Plan-only mode of the GEMM dispatcher (qs_w4a8_gemm_plan): the launchers record which kernel family / geometry they
 // were asked for and return without touching the device - the selection heuristics become testable on a CPU-only box.

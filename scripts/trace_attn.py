@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Timeline of the KV4 decode attention kernel (EXP & 32 build: s_memtime stamps per wave).  env: B, L, VAR (232 / 241)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import qserve_backend.fused_attention as fa
+from qserve_amd._lib import lib
+dev = torch.device("cuda:0")
+B, H, Hkv, L = int(os.environ.get("B", "64")), 32, 8, int(os.environ.get("L", "1033"))
+VAR = int(os.environ.get("VAR", "232"))
+mb = (L + 63) // 64 + 1
+pb = Hkv * 64 * 64 + 64 * Hkv * 4
+NL = 8
+pools, tables = [], []
+for _ in range(NL):
+    kp = torch.randint(0, 255, (B * mb, pb), dtype=torch.uint8, device=dev)
+    vp = torch.randint(0, 255, (B * mb, pb), dtype=torch.uint8, device=dev)
+    kp[:, Hkv * 64 * 64:] = torch.tensor([0x00, 0x34], dtype=torch.uint8, device=dev).repeat((pb - Hkv * 64 * 64) // 2)
+    vp[:, Hkv * 64 * 64:] = torch.tensor([0x00, 0x34], dtype=torch.uint8, device=dev).repeat((pb - Hkv * 64 * 64) // 2)
+    perm = torch.randperm(B * mb).reshape(B, mb)
+    t = torch.empty((B, 2, mb), dtype=torch.int64)
+    t[:, 0] = kp.data_ptr() + perm * pb
+    t[:, 1] = vp.data_ptr() + perm * pb
+    pools.append((kp, vp)); tables.append(t.to(dev))
+qkv = torch.randn((B, (H + 2 * Hkv) * 128), dtype=torch.float16, device=dev)
+q, k, v = qkv.split([H * 128, Hkv * 128, Hkv * 128], dim=-1)
+q, k, v = q.reshape(B, H, 128), k.reshape(B, Hkv, 128), v.reshape(B, Hkv, 128)
+lens = torch.full((B,), L, dtype=torch.int32, device=dev)
+lib.qs_debug_copy_split_workspace.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+lib.qs_set_attention_variant(VAR)
+for i in range(6):   # the last launch's stamps survive; earlier launches make the caches / pools "cold" like the step
+    fa.single_query_attention(q, k, v, tables[i % NL], lens, None, 8192, 64, Hkv * 64, L, 128, 5e5, True, True, True)
+torch.cuda.synchronize()
+n = B * Hkv * 8 * 16
+out = torch.zeros((n,), dtype=torch.int64, device=dev)
+assert lib.qs_debug_copy_split_workspace(out.data_ptr(), n * 8) == 0
+st = out.cpu().numpy().reshape(B * Hkv, 8, 16).astype(np.float64)
+t0 = st[:, :, 0].min()
+st = np.where(st > 0, st - t0, np.nan)
+names = ["entry", "tl", "dma issued", "phaseA in", "phaseA done", "K0 in", "pg0 done", "K1 in", "pg1 done", "K2 in", "pg2 done", "", "loop done", "sync1", "merged", "end"]
+print(f"L={L} VAR={VAR}: stamps in s_memtime ticks relative to the first wave's entry (mean / min / max over all waves)")
+for i, nm in enumerate(names):
+    if not nm: continue
+    x = st[:, :, i]
+    if np.all(np.isnan(x)): continue
+    print(f"  {i:2d} {nm:12s} mean {np.nanmean(x):9.0f}  min {np.nanmin(x):9.0f}  max {np.nanmax(x):9.0f}   wave0 mean {np.nanmean(st[:, 0, i]):9.0f}  wave7 mean {np.nanmean(st[:, 7, i]):9.0f}")
+print("  per-workgroup end: mean", np.nanmean(np.nanmax(st[:, :, 15], axis=1)), "max", np.nanmax(st[:, :, 15]))
+lib.qs_set_attention_variant(0)
