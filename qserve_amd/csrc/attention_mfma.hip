@@ -33,7 +33,9 @@ namespace {
 constexpr int PAGE_TOK = 64;
 constexpr int DH = 128;
 constexpr int DHB = 64;        // KV4 bytes per token per head
-constexpr int NW = 8;          // waves per workgroup
+constexpr int NW = 8;          // waves per workgroup; all of them own pages
+constexpr int NWT = NW;
+constexpr int SVC = NW - 1;    // the service wave (RoPE, operand build, new token) - the wave that owns the fewest pages
 constexpr int MAXP = 192;      // page-table entries cached in LDS per sequence (dispatcher: max_blocks <= MAXP)
 
 struct RopeCS {
@@ -101,10 +103,12 @@ __device__ __forceinline__ u32 and_or(u32 x, u32 m, u32 c) {
 typedef __attribute__((address_space(3))) const uint8_t* lds_u8;   // 32-bit LDS address (keeps ds_read, not flat_load)
 
 // EXP: timing / ablation switches (qs_set_attention_variant(200 + EXP), G = 4 only; default 0 = the product kernel):
-//   1 = non-temporal LDS-DMA (aux nt), 2 = no compute (DMA + waits only: results are wrong by design),
-//   4 = skip phase A (RoPE / new token: wrong by design), 8 = partial load of the last page
+//   1 = page DMA WITHOUT the non-temporal hint (default: nt - every KV byte is read once per step; measured -4 % at
+//       L = 1033 ... -12 % at L = 4096), 2 = no compute (DMA + waits only: results are wrong by design),
+//   4 = skip phase A (RoPE / new token: wrong by design), 8 = fetch the last page in full (default: only the rows of
+//       valid tokens), 32 = timeline trace (s_memtime stamps into the split workspace, scripts/trace_attn.py)
 template <int G, int EXP = 0>
-__global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
+__global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
     const int64_t* __restrict__ kv_pointers, const int* __restrict__ lengths, _Float16* __restrict__ out,
     int num_heads, int num_kv_heads, int64_t q_stride0, int64_t kv_stride0, int max_blocks, int timestep,
@@ -112,11 +116,11 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     __shared__ __attribute__((aligned(16))) uint8_t s_kv[2 * NW * PAGE_TOK * DHB];   // [K | V][wave][4 KiB]
     __shared__ __attribute__((aligned(16))) _Float16 s_meta[NW][4][PAGE_TOK];   // k scale, k zero, v scale, v zero
     __shared__ __attribute__((aligned(16))) _Float16 s_q[G][DH];                // rotated q of the G heads
-    __shared__ int64_t s_ptab[2][MAXP];                                         // page addresses of this sequence
     __shared__ __attribute__((aligned(16))) _Float16 s_qp[16][DH];              // Q.K^T B operand (see below)
     __shared__ __attribute__((aligned(16))) _Float16 s_knew[DH];
     __shared__ float s_cur[16];
     __shared__ float s_m[NW][G], s_l[NW][G];
+    __shared__ int s_flag;                                                      // service wave -> page waves: operands ready
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         if constexpr (EXP & 32) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             if (lane == 0)
-                reinterpret_cast<unsigned long long*>(ws)[(((size_t)b * gridDim.x + hkv) * NW + wave) * 16 + i] = t;
+                reinterpret_cast<unsigned long long*>(ws)[(((size_t)b * gridDim.x + hkv) * NWT + wave) * 16 + i] = t;
         }
     };
     stamp(0);
@@ -140,7 +144,33 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         kpage0 = ktab[wave];
         vpage0 = vtab[wave];
     }
+    // (the length and the first-round page addresses are requested FIRST, as scalar loads: anything the compiler cannot
+    // prove store-free in front of them - volatile asm, the loads of the service wave - would make them vector loads)
     const int tl = lengths ? lengths[b] - 1 : timestep;   // tlength, Template.hpp:901
+    // service wave: q / k / v of the new token do not depend on the context length - requested at kernel entry, ahead of
+    // every page DMA of this CU in the memory pipeline (which serves requests in order: loads issued after the burst of
+    // the first round would come back ~4 us later); raised issue priority until the operands are published
+    const _Float16* qb = q + (size_t)b * q_stride0 + (size_t)hkv * G * DH;
+    const _Float16* kb = k + (size_t)b * kv_stride0 + (size_t)hkv * DH;
+    const _Float16* vb = v + (size_t)b * kv_stride0 + (size_t)hkv * DH;
+    _Float16 qlo[G], qhi[G], klo = 0, khi = 0;
+    h2 vnew_pair = {0, 0};                 // the new token's raw v (two elements per lane)
+#pragma unroll
+    for (int h = 0; h < G; ++h) qlo[h] = qhi[h] = 0;
+    if (wave == SVC) {
+        asm volatile("s_setprio 3");       // (asm without a memory clobber: the builtin counts as a possible store and
+                                           //  turns every later page-table lookup into a vector load)
+        if constexpr (!(EXP & 4)) {
+#pragma unroll
+            for (int h = 0; h < G; ++h) {
+                qlo[h] = qb[h * DH + lane];
+                qhi[h] = qb[h * DH + 64 + lane];
+            }
+            klo = kb[lane];
+            khi = kb[64 + lane];
+            vnew_pair = *reinterpret_cast<const h2*>(vb + 2 * lane);
+        }
+    }
     if (tl < 0) return;
     stamp(1);
     const float inv_sqrt = 0.08838834764831845f;
@@ -160,10 +190,18 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     const int p_begin = z * pps, p_end = min(npages, p_begin + pps);
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    // Page addresses inside the loop come from the LDS copy (s_ptab, filled in phase A): a global load there would sit
-    // in the same in-order vmcnt queue as the LDS-DMA and make K(p+NW) wait for V(p) to land.
-    auto page_addr = [&](int which, int p) -> int64_t {      // in-loop lookup (the dispatcher guarantees p < MAXP)
-        return s_ptab[which][p];
+    // Page addresses of the later rounds: SCALAR loads (scalar cache / lgkmcnt - they never enter the in-order vmcnt queue
+    // of the page DMA; the table rows were touched by the first-round lookups).  From inline asm, because behind the DMA
+    // statements' "memory" clobber the compiler itself would fall back to vector loads for kv_pointers.
+    auto next_pages = [&](int p, int64_t& kn, int64_t& vn) {
+        const uint64_t ka = (uint64_t)(uintptr_t)(ktab + p), va = (uint64_t)(uintptr_t)(vtab + p);
+        // (readfirstlane returns a signed int: without the u32 casts the low half would be sign-extended into the high one)
+        const uint64_t ks = ((uint64_t)(u32)__builtin_amdgcn_readfirstlane((u32)(ka >> 32)) << 32) |
+                            (uint64_t)(u32)__builtin_amdgcn_readfirstlane((u32)ka);
+        const uint64_t vs = ((uint64_t)(u32)__builtin_amdgcn_readfirstlane((u32)(va >> 32)) << 32) |
+                            (uint64_t)(u32)__builtin_amdgcn_readfirstlane((u32)va);
+        asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(kn), "=&s"(vn) : "s"(ks), "s"(vs) : "memory");
     };
     // LDS-DMA issued from inline asm (recipe: cdna_hip_programming.md 5.7 - M0 carries the wave-uniform LDS base and is
     // written in the statement that reads it).  Deliberately NOT the builtin: the compiler's waitcnt pass models every
@@ -173,7 +211,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     auto dma16 = [&](const uint8_t* g, uint8_t* l) {
         u32 keep;
         const u32 ldst = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)(lptr_t)l);   // provably wave-uniform for the "s" operand
-        if constexpr (EXP & 1)
+        if constexpr (!(EXP & 1))
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(g), "s"(ldst) : "memory");
         else
@@ -191,7 +229,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         const uint8_t* kd = kbase + (u32)(hkv * PAGE_TOK * DHB + lane * 16);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if constexpr (EXP & 8) {
+            if constexpr (!(EXP & 8)) {
                 // lanes of tokens >= valid stay idle (their bytes are never read: masked scores / zero probabilities);
                 // lane 0 always loads so that the instruction issues and the vmcnt bookkeeping holds
                 if (16 * e + (lane >> 2) < valid_tok || lane == 0) dma16(kd + e * 1024, s_kw + e * 1024);
@@ -208,7 +246,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         const uint8_t* vd = vbase + (u32)(hkv * PAGE_TOK * DHB + lane * 16);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if constexpr (EXP & 8) {
+            if constexpr (!(EXP & 8)) {
                 if (16 * e + (lane >> 2) < valid_tok || lane == 0) dma16(vd + e * 1024, s_vw + e * 1024);
             } else {
                 dma16(vd + e * 1024, s_vw + e * 1024);
@@ -218,103 +256,65 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
                                           ((lane >> 5) * num_kv_heads + hkv) * PAGE_TOK * 2 + (lane & 31) * 4);
         dma4(mb, &s_meta[wave][2][0]);
     };
-    const _Float16* qb = q + (size_t)b * q_stride0 + (size_t)hkv * G * DH;
-    const _Float16* kb = k + (size_t)b * kv_stride0 + (size_t)hkv * DH;
-    const _Float16* vb = v + (size_t)b * kv_stride0 + (size_t)hkv * DH;
-    if constexpr (!(EXP & 16)) {
-        // ---- phase A overlapped with the first page fetch ---------------------------------------------------------------
-        // The vmcnt queue is in order: anything requested AFTER the LDS-DMA of the first pages can only be waited for
-        // together with those pages (2-5 us under the launch burst), and a workgroup barrier behind such a wait makes
-        // every wave wait for the slowest page.  So every global input of phase A (the G query rows, k, v, the RoPE
-        // coefficients of position tl, the page table) is itself fetched by LDS-DMA, ISSUED BEFORE the page DMA and
-        // waited for with a counted vmcnt(10) that leaves the ten page operations in flight (no VGPR destination: the
-        // compiler inserts no wait of its own); the page DMA is issued unconditionally (a wave without a page in the
-        // first round fetches the new token's page - always a valid address - so that "10 younger operations" holds
-        // on every path), and the two phase-A barriers are raw s_barrier + lgkmcnt(0) (no vmcnt drain).  RoPE, the new
-        // token's quantisation and the operand build all run while the first pages are in flight.
-        // Staging area = the not-yet-built Q.K^T operand s_qp: rows 0..G-1 raw q, row 8 raw k, row 9 raw v, rows 10-11
-        // the 64 (cos, sin) pairs.
-        const int blk = tl >> 6, slot = tl & 63;
-        // every page-table entry phase A needs is loaded HERE, before the first asm statement: behind an asm with a
-        // "memory" clobber the compiler may no longer use scalar loads for kv_pointers (possible aliasing write) and a
-        // vector load would sit in the vmcnt queue behind the page DMA
-        const int64_t knew_page = ktab[blk], vnew_page = vtab[blk];
-        const bool has_page = p_begin + wave < p_end;
-        int64_t kfirst = kpage0, vfirst = vpage0;
-        if (has_page && !spec) {
-            kfirst = ktab[p_begin + wave];
-            vfirst = vtab[p_begin + wave];
+    // ---- phase A on the SERVICE wave, concurrent with the first page fetch ---------------------------------------------
+    // What the timeline trace (EXP & 32) showed for the one-barrier-after-DMA form: issuing the first-round page DMA
+    // takes a wave 2-4 us (the memory pipeline back-pressures the burst), so any phase-A work that sits behind that issue
+    // in program order, and any barrier all waves must reach after it, completes at ~10 us - the first Q.K^T of a 20 us
+    // kernel started at 11 us.  Now: seven waves do nothing but issue their DMA; the last wave (it owns the fewest
+    // pages) first loads q / k / v / the RoPE coefficients / the page table with ordinary loads - its vmcnt queue is
+    // still empty, the compiler's own counted waits are right - rotates, builds the Q.K^T operand image, raises an LDS
+    // flag (~2 us after launch) and only then issues its own page DMA; the other waves poll that flag after their issue
+    // (no barrier couples the waves to each other) and start on whichever page has landed.  The new token's cache write
+    // and its own score follow on the service wave after its pages, off everybody's critical path.
+    // (A ninth, page-less wave was tried first: 576-thread workgroups no longer fit twice on a CU - 26 vs 20 us.)
+    const int blk = tl >> 6, slot = tl & 63;
+    const bool has_page = p_begin + wave < p_end;
+    if (tid == SVC * 64) s_flag = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // start-of-kernel barrier (raw: the service wave's loads stay in flight)
+    auto first_round = [&]() {
+        if (has_page) {
+            // page addresses: requested together with the length for split 0 (scalar loads, before any asm statement:
+            // behind an asm "memory" clobber the compiler falls back to vector loads for kv_pointers)
+            int64_t kfirst = kpage0, vfirst = vpage0;
+            if (!spec) {
+                kfirst = ktab[p_begin + wave];
+                vfirst = vtab[p_begin + wave];
+            }
+            const int vt0 = min(PAGE_TOK, tl - (p_begin + wave) * PAGE_TOK);
+            dma_k(kfirst, vt0);
+            dma_v(vfirst, vt0);
         }
-        uint8_t* const raw = reinterpret_cast<uint8_t*>(&s_qp[0][0]);
-        const bool have_tab = rope_tab && tl < rope_tab_len;
-        auto dmaA = [&](const void* g, uint8_t* l) {      // 256 B per wave instruction, lane-linear
-            dma4(reinterpret_cast<const uint8_t*>(g) + lane * 4, l);
-        };
-        auto issue = [&](int64_t kp, int64_t vp, int vt0) {
-            if constexpr (!(EXP & 4)) {
-                if (wave == 0) {
-#pragma unroll
-                    for (int h = 0; h < G; ++h) dmaA(qb + h * DH, raw + h * 256);
-                    dmaA(kb, raw + 8 * 256);
-                    if (have_tab) {
-                        dmaA(rope_tab + (size_t)tl * 64, raw + 10 * 256);
-                        dmaA(rope_tab + (size_t)tl * 64 + 32, raw + 11 * 256);
-                    }
-                } else if (wave == 1) {
-                    dmaA(vb, raw + 9 * 256);
-                }
-            }
-            if (wave == 0) {                                   // page table -> LDS: 32 entries (256 B) per instruction
-                for (int c = 0; c * 32 < npages; ++c) {
-                    if (c * 64 + lane < 2 * npages) {
-                        dma4(reinterpret_cast<const uint8_t*>(ktab + c * 32) + lane * 4, &s_ptab[0][c * 32]);
-                        dma4(reinterpret_cast<const uint8_t*>(vtab + c * 32) + lane * 4, &s_ptab[1][c * 32]);
-                    }
-                }
-            }
-            dma_k(kp, vt0);
-            dma_v(vp, vt0);
-        };
-        // first-round page of this wave: its address was requested together with the length; only a wave WITHOUT a page
-        // (short contexts, split tails) has to fetch the fall-back address first - a wave-uniform branch, so that the
-        // common path issues its DMA without waiting for that extra dependent load
-        if (has_page) issue(kfirst, vfirst, min(PAGE_TOK, tl - (p_begin + wave) * PAGE_TOK));
-        else issue(knew_page, vnew_page, PAGE_TOK);
         stamp(2);
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // everything older than this wave's ten page operations
-        stamp(3);
-        u32 vpair = 0;
+    };
+    if (wave != SVC) {
+        first_round();
+        while (*(volatile __attribute__((address_space(3))) int*)(&s_flag) == 0) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        stamp(4);
+    } else {
         if constexpr (!(EXP & 4)) {
-            if (wave == 0) {
-                RopeCS cs;
-                if (have_tab) {
-                    const float2 t = reinterpret_cast<const float2*>(raw + 10 * 256)[lane];
-                    cs.c = t.x;
-                    cs.s = t.y;
-                } else {
-                    cs = rope_coef(lane, tl, rope_base, DH);
-                }
-                const _Float16* rq = reinterpret_cast<const _Float16*>(raw);
-                _Float16 ra[G + 1], rb[G + 1];
-#pragma unroll
-                for (int h = 0; h < G; ++h) rope_pair((float)rq[h * DH + lane], (float)rq[h * DH + 64 + lane], cs, ra[h], rb[h]);
-                rope_pair((float)rq[8 * DH + lane], (float)rq[8 * DH + 64 + lane], cs, ra[G], rb[G]);
-#pragma unroll
-                for (int h = 0; h < G; ++h) {
-                    s_q[h][lane] = ra[h];
-                    s_q[h][64 + lane] = rb[h];
-                }
-                s_knew[lane] = ra[G];
-                s_knew[64 + lane] = rb[G];
-            } else if (wave == 1) {
-                vpair = reinterpret_cast<const u32*>(raw + 9 * 256)[lane];
+            // ordinary loads: this wave's queue carries nothing else, the compiler's own counted waits are right here
+            RopeCS cs;
+            if (rope_tab && tl < rope_tab_len) {
+                const float2 t = rope_tab[(size_t)tl * 64 + lane];   // same double-evaluated, float-rounded values
+                cs.c = t.x;
+                cs.s = t.y;
+            } else {
+                cs = rope_coef(lane, tl, rope_base, DH);
             }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ONLY phase-A barrier: rotated q / k visible
-        if constexpr (!(EXP & 4)) {
+#pragma unroll
+            for (int h = 0; h < G; ++h) {
+                _Float16 a, bb;
+                rope_pair((float)qlo[h], (float)qhi[h], cs, a, bb);
+                s_q[h][lane] = a;
+                s_q[h][64 + lane] = bb;
+            }
+            _Float16 ka, kbb;
+            rope_pair((float)klo, (float)khi, cs, ka, kbb);
+            s_knew[lane] = ka;
+            s_knew[64 + lane] = kbb;
             // B operand of Q.K^T for lane (head li, kg = tg), MFMA w: dims 32tg + 8w + {0,4,1,5,2,6,3,7}; the positions that
-            // meet hi-nibble operands (1024 + 16 n) carry q/16.  EVERY wave writes the whole (identical) operand image, so
-            // each wave only depends on its own LDS writes and no second barrier stands between RoPE and the first Q.K^T.
+            // meet hi-nibble operands (1024 + 16 n) carry q/16 (same wave wrote s_q: LDS keeps a wave's accesses in order)
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 h8 x = {0, 0, 0, 0, 0, 0, 0, 0};                       // heads >= G: zero rows of the operand
@@ -323,95 +323,21 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
                 *reinterpret_cast<h8*>(&s_qp[li][32 * tg + 8 * w]) =
                     (h8){x[0], x[4], x[1] * s16, x[5] * s16, x[2], x[6], x[3] * s16, x[7] * s16};
             }
-            // the rest of phase A has no consumer before the final merge: the new token's cache write (waves 0 / 1,
-            // split 0) and its own score (waves 3..)
-            if (wave == 0 && z == 0) {
-                uint8_t* pg = reinterpret_cast<uint8_t*>(knew_page);
-                __half* sc = reinterpret_cast<__half*>(pg + (size_t)num_kv_heads * PAGE_TOK * DHB);
-                wave_quant_store4(s_knew[2 * lane], s_knew[2 * lane + 1], pg + ((size_t)hkv * PAGE_TOK + slot) * DHB,
-                                  sc + hkv * PAGE_TOK + slot, sc + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
-            } else if (wave == 1 && z == 0) {
-                uint8_t* pg = reinterpret_cast<uint8_t*>(vnew_page);
-                __half* sc = reinterpret_cast<__half*>(pg + (size_t)num_kv_heads * PAGE_TOK * DHB);
-                const h2 vv = __builtin_bit_cast(h2, vpair);
-                wave_quant_store4(vv[0], vv[1], pg + ((size_t)hkv * PAGE_TOK + slot) * DHB, sc + hkv * PAGE_TOK + slot,
-                                  sc + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
-            } else if (wave >= 3) {
-                for (int h = wave - 3; h < G; h += NW - 3) {
-                    float d = (float)s_q[h][lane] * (float)s_knew[lane] + (float)s_q[h][64 + lane] * (float)s_knew[64 + lane];
-                    d = wave_sum_dpp(d);
-                    if (lane == 0) s_cur[h] = d * qk_scale;
-                }
+            {   // v is consumed much later (after the code shared with the page waves): pin its load as complete HERE, or
+                // the compiler carries "load pending" into the shared code and drains the page waves' DMA queue there
+                u32 bits = __builtin_bit_cast(u32, vnew_pair);
+                asm volatile("" : "+v"(bits));
+                vnew_pair = __builtin_bit_cast(h2, bits);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) *(volatile __attribute__((address_space(3))) int*)(&s_flag) = 1;
+            asm volatile("s_setprio 0");
+            stamp(4);
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) *(volatile __attribute__((address_space(3))) int*)(&s_flag) = 1;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        stamp(4);
-    } else {
-        if (p_begin + wave < p_end) {
-            const int vt0 = min(PAGE_TOK, tl - (p_begin + wave) * PAGE_TOK);
-            dma_k(spec ? kpage0 : ktab[p_begin + wave], vt0);
-            dma_v(spec ? vpage0 : vtab[p_begin + wave], vt0);
-        }
-        for (int i = tid; i < 2 * MAXP; i += NW * 64) {
-            const int pi = i >> 1;
-            if (pi < npages) s_ptab[i & 1][pi] = (i & 1) ? vtab[pi] : ktab[pi];
-        }
-
-        // ---- phase A (round-1 form, kept for in-run A/B): RoPE of the G query heads and of k; quantise + store ---------
-        if (!(EXP & 4) && tid < 64) {
-            RopeCS cs;
-            if (rope_tab && tl < rope_tab_len) {
-                const float2 t = rope_tab[(size_t)tl * 64 + tid];   // same double-evaluated, float-rounded values
-                cs.c = t.x;
-                cs.s = t.y;
-            } else {
-                cs = rope_coef(tid, tl, rope_base, DH);
-            }
-    #pragma unroll
-            for (int h = 0; h < G; ++h) {
-                _Float16 a, bb;
-                rope_pair((float)qb[h * DH + tid], (float)qb[h * DH + 64 + tid], cs, a, bb);
-                s_q[h][tid] = a;
-                s_q[h][64 + tid] = bb;
-            }
-            _Float16 a, bb;
-            rope_pair((float)kb[tid], (float)kb[64 + tid], cs, a, bb);
-            s_knew[tid] = a;
-            s_knew[64 + tid] = bb;
-        }
-        __syncthreads();
-        if (!(EXP & 4)) {
-            const int blk = tl >> 6, slot = tl & 63;
-            if (wave == 0 && z == 0) {
-                uint8_t* pg = reinterpret_cast<uint8_t*>(ktab[blk]);
-                __half* sc = reinterpret_cast<__half*>(pg + (size_t)num_kv_heads * PAGE_TOK * DHB);
-                wave_quant_store4(s_knew[2 * lane], s_knew[2 * lane + 1], pg + ((size_t)hkv * PAGE_TOK + slot) * DHB,
-                                  sc + hkv * PAGE_TOK + slot, sc + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
-            } else if (wave == 1 && z == 0) {
-                uint8_t* pg = reinterpret_cast<uint8_t*>(vtab[blk]);
-                __half* sc = reinterpret_cast<__half*>(pg + (size_t)num_kv_heads * PAGE_TOK * DHB);
-                wave_quant_store4(vb[2 * lane], vb[2 * lane + 1], pg + ((size_t)hkv * PAGE_TOK + slot) * DHB,
-                                  sc + hkv * PAGE_TOK + slot, sc + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
-            } else if (wave == 2) {
-                // B operand of Q.K^T for lane (head li, kg = tg), MFMA w: dims 32tg + 8w + {0,4,1,5,2,6,3,7}; the positions
-                // that meet hi-nibble operands (1024 + 16 n) carry q/16
-    #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    h8 x = {0, 0, 0, 0, 0, 0, 0, 0};                       // heads >= G: zero rows of the operand
-                    if (li < G) x = *reinterpret_cast<const h8*>(&s_q[li][32 * tg + 8 * w]);
-                    const _Float16 s16 = (_Float16)0.0625f;
-                    *reinterpret_cast<h8*>(&s_qp[li][32 * tg + 8 * w]) =
-                        (h8){x[0], x[4], x[1] * s16, x[5] * s16, x[2], x[6], x[3] * s16, x[7] * s16};
-                }
-            } else {
-                for (int h = wave - 3; h < G; h += NW - 3) {
-                    float d = (float)s_q[h][lane] * (float)s_knew[lane] + (float)s_q[h][64 + lane] * (float)s_knew[64 + lane];
-                    d = wave_sum(d);
-                    if (lane == 0) s_cur[h] = d * qk_scale;
-                }
-            }
-        }
-        __syncthreads();
+        first_round();                     // the service wave's own pages: requested only now (its queue was kept clean)
     }
 
     // per-lane constants of head li: qsum = sum_d q_eff_d and Qoff = sum over the operand of 1024 * q' (the offset that
@@ -450,11 +376,13 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         const bool more = p + NW < p_end;
         const int valid = min(PAGE_TOK, tl - p * PAGE_TOK);
         const bool full = valid == PAGE_TOK;   // wave-uniform: only the last page needs masking
+        int64_t kpage_next = 0, vpage_next = 0;
+        if (more) next_pages(p + NW, kpage_next, vpage_next);
         if constexpr (EXP & 2) {               // timing experiment: memory side only
-            if (more) dma_k(page_addr(0, p + NW), min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
+            if (more) dma_k(kpage_next, min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
             if (more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (more) dma_v(page_addr(1, p + NW), min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
+            if (more) dma_v(vpage_next, min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
             continue;
         }
 
@@ -529,7 +457,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             }
             // K buffer consumed -> request K(p+NW)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (more) dma_k(page_addr(0, p + NW), min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
+            if (more) dma_k(kpage_next, min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
             float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
             if constexpr (GP == 4) {
                 mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx),
@@ -579,7 +507,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
             }
             // K buffer consumed -> request K(p+NW)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (more) dma_k(page_addr(0, p + NW), min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
+            if (more) dma_k(kpage_next, min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
             float mx = sc8[0];
 #pragma unroll
             for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc8[j]);
@@ -699,7 +627,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
         }
         asm volatile("s_waitcnt lgkmcnt(0) ; QS_LOOP_END" ::: "memory");
         stamp(6 + 2 * min(2, (p - p_begin) / NW));
-        if (more) dma_v(page_addr(1, p + NW), min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
+        if (more) dma_v(vpage_next, min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
     }
 
     // ---- per-wave partials -> LDS.  Lane (head li, tg) holds out dims 8*(4tg + r) + e in acc[e][r] ---------------
@@ -725,6 +653,29 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     corr += xor_lane(corr, lid2, 32);
     psum += xor_lane(psum, lid2, 16);
     psum += xor_lane(psum, lid2, 32);
+    // ---- service wave, off every critical path: the new token's cache write (split 0) and its own score -------------------
+    // (placed here, after the code the page waves share with it: pending stores of the service wave at a control-flow
+    // merge in front of the page loop would make the compiler put a vmcnt(0) there - which drains the page waves' DMA)
+    if constexpr (!(EXP & 4)) {
+        if (wave == SVC) {
+            if (z == 0) {
+                uint8_t* pgk = reinterpret_cast<uint8_t*>(ktab[blk]);
+                __half* sck = reinterpret_cast<__half*>(pgk + (size_t)num_kv_heads * PAGE_TOK * DHB);
+                wave_quant_store4(s_knew[2 * lane], s_knew[2 * lane + 1], pgk + ((size_t)hkv * PAGE_TOK + slot) * DHB,
+                                  sck + hkv * PAGE_TOK + slot, sck + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
+                uint8_t* pgv = reinterpret_cast<uint8_t*>(vtab[blk]);
+                __half* scv = reinterpret_cast<__half*>(pgv + (size_t)num_kv_heads * PAGE_TOK * DHB);
+                wave_quant_store4(vnew_pair[0], vnew_pair[1], pgv + ((size_t)hkv * PAGE_TOK + slot) * DHB,
+                                  scv + hkv * PAGE_TOK + slot, scv + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
+            }
+#pragma unroll
+            for (int h = 0; h < G; ++h) {
+                float d = (float)s_q[h][lane] * (float)s_knew[lane] + (float)s_q[h][64 + lane] * (float)s_knew[64 + lane];
+                d = wave_sum_dpp(d);
+                if (lane == 0) s_cur[h] = d * qk_scale;
+            }
+        }
+    }
     // every LDS-DMA of this wave has landed (a wave without pages never waited for its first-round fetch, and the merge
     // area below aliases the page buffers)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -747,7 +698,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attention_mfma_kernel(
     }
     __syncthreads();
     stamp(14);
-    for (int o = tid2; o < G * DH; o += NW * 64) {
+    for (int o = tid2; o < G * DH; o += NWT * 64) {
         const int h = o / DH, d = o % DH;
         float M = z == 0 ? s_cur[h] : -3.0e38f;
 #pragma unroll
@@ -929,31 +880,25 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
     }
     grid.z = nsplit;
 #define QS_LAUNCH_G(GG)                                                                                             \
-    hipLaunchKernelGGL((decode_attention_mfma_kernel<GG>), grid, dim3(NW * 64), 0, st, q, k, v, kvp, len, out, H, Hkv, \
+    hipLaunchKernelGGL((decode_attention_mfma_kernel<GG>), grid, dim3(NWT * 64), 0, st, q, k, v, kvp, len, out, H, Hkv, \
                        qs, kvs, mb, timestep, base, tab, tab_len, nsplit, ws)
 #define QS_LAUNCH_EXP(E)                                                                                              \
     case E:                                                                                                            \
-        hipLaunchKernelGGL((decode_attention_mfma_kernel<4, E>), grid, dim3(NW * 64), 0, st, q, k, v, kvp, len, out, H,   \
+        hipLaunchKernelGGL((decode_attention_mfma_kernel<4, E>), grid, dim3(NWT * 64), 0, st, q, k, v, kvp, len, out, H,  \
                            Hkv, qs, kvs, mb, timestep, base, tab, tab_len, nsplit, ws);                                \
         return qs_launch_status("single_query_attention")
     if (exp_flags & 32) {                     // timeline trace: stamps go to the (otherwise unused) split workspace
-        ws = qs_split_workspace((size_t)blocks * NW * 16 * 8, st);
+        ws = qs_split_workspace((size_t)blocks * NWT * 16 * 8, st);
         if (!ws) exp_flags = 0;
     }
     if (G == 4 && exp_flags > 0 && nsplit == 1) {
         switch (exp_flags) {
             QS_LAUNCH_EXP(1);
             QS_LAUNCH_EXP(2);
-            QS_LAUNCH_EXP(3);
-            QS_LAUNCH_EXP(4);
+            QS_LAUNCH_EXP(6);
             QS_LAUNCH_EXP(8);
             QS_LAUNCH_EXP(9);
-            QS_LAUNCH_EXP(6);
-            QS_LAUNCH_EXP(16);
-            QS_LAUNCH_EXP(17);
-            QS_LAUNCH_EXP(25);
             QS_LAUNCH_EXP(32);
-            QS_LAUNCH_EXP(41);
             default: break;
         }
     }

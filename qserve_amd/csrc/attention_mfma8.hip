@@ -66,6 +66,12 @@ __device__ __forceinline__ u32 pack_h2(float a, float b) {
     return __builtin_bit_cast(u32, v);
 }
 
+// cache policy of the page DMA: non-temporal (aux bit 1) - every KV byte is read exactly once per step (measured on the
+// KV4 twin: -4 % at L = 1033 ... -12 % at L = 4096); QS_KV8_NT=0 at build time restores the default policy for A/B
+#ifndef QS_KV8_NT
+#define QS_KV8_NT 1
+#endif
+constexpr int NT_AUX = QS_KV8_NT ? 2 : 0;
 typedef __attribute__((address_space(3))) const uint8_t* lds_u8;   // 32-bit LDS address (keeps ds_read, not flat_load)
 typedef u32 v2u __attribute__((ext_vector_type(2)));
 #define LDS_AT(T, p) (*(const __attribute__((address_space(3))) T*)(p))
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
         for (int e = 0; e < 8; ++e) {
             const int row = 8 * e + r8;
             const u32 off = row * DHB + ((p8 ^ ((row >> 1) & 7)) * 16);              // chunk swizzle on the source side
-            __builtin_amdgcn_global_load_lds((gptr_t)(kd + off), (lptr_t)(s_kw + e * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(kd + off), (lptr_t)(s_kw + e * 1024), 16, 0, NT_AUX);
         }
         const uint8_t* mb = kbase + (u32)(num_kv_heads * PAGE_TOK * DHB +
                                           ((lane >> 5) * num_kv_heads + hkv) * PAGE_TOK * 2 + (lane & 31) * 4);
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
             const int slot = 8 * e + r8;
             const int tok = slot ^ ((slot >> 2) & 1);                                 // row permutation on the source side
             const u32 off = tok * DHB + p8 * 16;
-            __builtin_amdgcn_global_load_lds((gptr_t)(vd + off), (lptr_t)(s_vw + e * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(vd + off), (lptr_t)(s_vw + e * 1024), 16, 0, NT_AUX);
         }
         const uint8_t* mb = vbase + (u32)(num_kv_heads * PAGE_TOK * DHB +
                                           ((lane >> 5) * num_kv_heads + hkv) * PAGE_TOK * 2 + (lane & 31) * 4);
