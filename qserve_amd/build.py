@@ -49,6 +49,7 @@ def _compile(src, force, extra):
 
 def build(force=False, verbose=True, extra=()):
     os.makedirs(BUILD, exist_ok=True)
+    extra = list(extra) + os.environ.get("QS_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DQS_RING_TRACE (timing tools)
     with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         res = list(ex.map(lambda s: _compile(s, force, list(extra)), SOURCES))
     objs = [o for o, _ in res]

@@ -19,6 +19,10 @@
 #include "common.h"
 #include <type_traits>
 
+// A/B switches (qs_set_gemm_variant(5000 + bits); every setting computes the same results):
+//   1 = weight DMA with the default cache policy instead of non-temporal, 2 = epilogue on the first K-group only
+int g_ring_flags = 0;
+
 namespace {
 
 __device__ __forceinline__ u32 vadd4(u32 a, u32 b) {
@@ -52,6 +56,21 @@ __device__ __forceinline__ float epi_per_group(int acc, float ws, float sa) {
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef u32 v2u __attribute__((ext_vector_type(2)));
 
+// QS_RING_TRACE builds (scripts/trace_gemm.py; never the shipped library): per-wave timeline into a caller buffer
+#ifdef QS_RING_TRACE
+__device__ unsigned long long* g_ring_trace = nullptr;
+#define QS_STAMP(i)                                                                          \
+    do {                                                                                     \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                          \
+        if (g_ring_trace && lane == 0) g_ring_trace[((size_t)blockIdx.x * 8 + wave) * 16 + (i)] = t_; \
+    } while (0)
+#define QS_ACC(var, t0_) var += (unsigned)(__builtin_amdgcn_s_memtime() - (t0_))
+#else
+#define QS_STAMP(i) \
+    do {            \
+    } while (0)
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -73,7 +92,8 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
                                                          const __half* __restrict__ wszs,
                                                          const __half* __restrict__ assums, void* __restrict__ out,
                                                          int M, int N, int K, int mblocks, int ns, int ksplit_arg,
-                                                         int* __restrict__ slabs, unsigned* __restrict__ counters) {
+                                                         int* __restrict__ slabs, unsigned* __restrict__ counters,
+                                                         int flags) {
     const int ksplit = KSPLIT ? ksplit_arg : 1;
     constexpr int KG = 8 / WN;
     constexpr int ASTAGE = 16 * MT * 64;              // activation bytes per stage (64 k)
@@ -88,6 +108,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = wave / WN, wn = wave % WN;
+    QS_STAMP(0);
     const int li = lane & 15, g = lane >> 4;
     const int tsel = li >> 3, c = li & 7;
     // workgroup -> (channel block, token block); token blocks of one channel block sit on ONE XCD (b % 8) so that the
@@ -151,6 +172,12 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
                      : "memory");
     };
+    // weights are read exactly once per launch by exactly one workgroup: non-temporal (MI355X_MICROARCH.md "nt-weights":
+    // issued -> landed -18 %); the activation tile is re-read by every workgroup from L2 and keeps the default policy
+    auto dma16_nt = [&](u32 voff, const void* sbase, u32 lds_addr) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(lds_addr)
+                     : "memory");
+    };
     auto issue = [&](int i, int slot) {               // group-local stage i -> global stage u = i*KG + kg
         const int u = u0 + i * KG + kg;
         const u32 dst = ring_lds + slot * GSTAGE;
@@ -158,7 +185,9 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
         for (int j = 0; j < NPIECE / WN; ++j) {
             const void* sb = p_isw[j] ? static_cast<const void*>(W + (size_t)u * 1024)
                                       : static_cast<const void*>(A + (size_t)u * 64);
-            dma16(p_off[j], sb, dst + p_lds[j]);
+            static_assert(MT % WN == 0, "piece kind must be a compile-time function of j");
+            if (j >= MT / WN && !(flags & 1)) dma16_nt(p_off[j], sb, dst + p_lds[j]);   // (p = wn + j*WN >= MT: a weight piece)
+            else dma16(p_off[j], sb, dst + p_lds[j]);
         }
         if (MODE == 1) {
             const int8_t* src = m_base + (size_t)(u >> 1) * N;
@@ -219,6 +248,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
     // ---- prologue: stages 0..ns-2 in flight, operands of stage 0 in registers ---------------------------------------
     for (int j = 0; j < ns - 1; ++j)
         if (j < nloc) issue(j, j);
+    QS_STAMP(1);
     // wait for stage 0: younger stages outstanding = min(ns-1, nloc) - 1
     {
         const int young = (nloc < ns - 1 ? nloc : ns - 1) - 1;
@@ -228,6 +258,10 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
         else wait_vm<0>();
     }
     raw_barrier();
+    QS_STAMP(2);
+#ifdef QS_RING_TRACE
+    unsigned t_wait = 0, t_round = 0;
+#endif
     Ops o0, o1;
     {
         const Raw q0 = read_raw(0);
@@ -268,20 +302,129 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
     };
     int slot = 0;
     for (int i = 0; i < nloc; i += 2) {               // two rounds per trip (operand registers ping-pong); nloc may be odd
+#ifdef QS_RING_TRACE
+        unsigned long long ta = __builtin_amdgcn_s_memtime();
+#endif
         wait_next(i);
         raw_barrier();
+#ifdef QS_RING_TRACE
+        QS_ACC(t_wait, ta);
+        ta = __builtin_amdgcn_s_memtime();
+#endif
         round(i, slot, o0, o1);
+#ifdef QS_RING_TRACE
+        QS_ACC(t_round, ta);
+        ta = __builtin_amdgcn_s_memtime();
+#endif
         slot = slot + 1 == ns ? 0 : slot + 1;
         if (i + 1 < nloc) {
             wait_next(i + 1);
             raw_barrier();
+#ifdef QS_RING_TRACE
+            QS_ACC(t_wait, ta);
+            ta = __builtin_amdgcn_s_memtime();
+#endif
             round(i + 1, slot, o1, o0);
+#ifdef QS_RING_TRACE
+            QS_ACC(t_round, ta);
+#endif
             slot = slot + 1 == ns ? 0 : slot + 1;
         }
     }
+    QS_STAMP(3);
+#ifdef QS_RING_TRACE
+    if (g_ring_trace && lane == 0) {
+        g_ring_trace[((size_t)blockIdx.x * 8 + wave) * 16 + 8] = t_wait;
+        g_ring_trace[((size_t)blockIdx.x * 8 + wave) * 16 + 9] = t_round;
+    }
+#endif
 
     // ---- reduce the KG partial tiles through LDS, fused epilogue -----------------------------------------------------
     const int ncol0 = (unit0 + wn) * 64 + 32 * (g >> 1) + 4 * (g & 1);
+    constexpr int NP = MT * 4;                         // 16 x 16 result pieces per wave: piece pc = mt*4 + cl
+    // DISTRIBUTED form (no K slices): piece pc is finished by K-group pc % KG - every group sums, scales and converts a
+    // 1/KG share of the tile instead of groups 1..KG-1 handing everything to group 0 and leaving (timeline trace,
+    // scripts/trace_gemm.py: reduction + epilogue on two of eight waves = 3 us of a 19 us launch at gate_up size).
+    const bool dist = !(KSPLIT && ksplit > 1) && !(flags & 2);
+    if (dist) {
+        constexpr int PPG = (NP + KG - 1) / KG;        // pieces per owning group
+        h4 ws4[PPG], wz4[PPG];
+        _Float16 sa_h[PPG], ss_h[PPG];
+        if (OUTK == 0) {                               // scale operands of the OWN pieces, requested ahead of the barriers
+#pragma unroll
+            for (int q = 0; q < PPG; ++q) {
+                const int pc = q * KG + kg;
+                if (pc < NP) {
+                    const int mt = pc >> 2, cl = pc & 3;
+                    ws4[q] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wscales) + ncol0 + 8 * cl);
+                    if (MODE == 0) wz4[q] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wszs) + ncol0 + 8 * cl);
+                    int m = m0 + 16 * mt + li;
+                    m = m < M ? m : M - 1;
+                    sa_h[q] = reinterpret_cast<const _Float16*>(ascales)[m];
+                    if (MODE == 0) ss_h[q] = reinterpret_cast<const _Float16*>(assums)[m];
+                }
+            }
+        }
+        __syncthreads();                               // rings are dead (every wave drained its DMA queue)
+        QS_STAMP(4);
+        // partial of piece pc from group kg -> slot [owner][wn][source index among the other groups][pc / KG][lane]
+        v4i* const red4 = reinterpret_cast<v4i*>(smem);
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) {
+            const int own = pc % KG;
+            if (own != kg) {
+                const int src = kg < own ? kg : kg - 1;
+                red4[((((own * WN + wn) * (KG - 1) + src) * PPG + pc / KG) << 6) + lane] = acc[pc >> 2][pc & 3];
+            }
+        }
+        __syncthreads();
+        constexpr int RS = 144;                        // staged fp16 row: 128 B + 16 (keeps 16-byte alignment)
+        uint8_t* const st = smem + (size_t)KG * WN * (KG - 1) * PPG * 1024 + wn * (16 * MT * RS);
+#pragma unroll
+        for (int q = 0; q < PPG; ++q) {
+#pragma unroll
+            for (int kk = 0; kk < KG; ++kk) {          // (static piece index under a wave-uniform branch)
+                const int pc = q * KG + kk;
+                if (pc < NP && kk == kg) {
+                    const int mt = pc >> 2, cl = pc & 3;
+                    v4i sum = acc[mt][cl];
+#pragma unroll
+                    for (int sidx = 0; sidx < KG - 1; ++sidx)
+                        sum += red4[((((kg * WN + wn) * (KG - 1) + sidx) * PPG + q) << 6) + lane];
+                    if (OUTK == 1) {
+                        const int m = m0 + 16 * mt + li;
+                        if (m < M) *reinterpret_cast<v4i*>(reinterpret_cast<int*>(out) + (size_t)m * N + ncol0 + 8 * cl) = sum;
+                    } else {
+                        const float sa = (float)sa_h[q];
+                        const float ss = MODE == 0 ? (float)ss_h[q] : 0.f;
+                        h4 o;
+                        if (MODE == 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(sum[r], (float)ws4[q][r], sa, (float)wz4[q][r], ss);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(sum[r], (float)ws4[q][r], sa);
+                        }
+                        *reinterpret_cast<h4*>(st + (16 * mt + li) * RS + (32 * (g >> 1) + 8 * cl + 4 * (g & 1)) * 2) = o;
+                    }
+                }
+            }
+        }
+        if (OUTK == 1) return;
+        __syncthreads();                               // the fp16 tile of every unit is staged
+        QS_STAMP(5);
+        _Float16* const orow = reinterpret_cast<_Float16*>(out) + (unit0 + wn) * 64 + (lane & 7) * 8;
+#pragma unroll
+        for (int i = 0; i < 2 * MT; ++i) {
+            if (i % KG != kg) continue;                    // the rows of unit wn are shared by its KG waves
+            const int r = i * 8 + (lane >> 3);
+            const int m = m0 + r;
+            const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane & 7) * 16);
+            if (m < M) *reinterpret_cast<v4u*>(orow + (size_t)m * N) = v;
+        }
+        QS_STAMP(6);
+        return;
+    }
     h4 ws4[4], wz4[4];
     _Float16 sa_h[MT], ss_h[MT];
     if (OUTK == 0 && kg == 0) {                        // requested now: their latency overlaps the reduction
@@ -299,7 +442,6 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
         }
     }
     __syncthreads();                                   // rings are dead (every wave drained its DMA queue)
-    constexpr int NP = MT * 4;
     int* const red = reinterpret_cast<int*>(smem);     // [KG-1][WN][NP*4][64]
     if (kg > 0) {
 #pragma unroll
@@ -311,6 +453,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
                     red[((((kg - 1) * WN + wn) * NP + mt * 4 + cl) * 4 + r) * 64 + lane] = acc[mt][cl][r];
     }
     __syncthreads();
+    QS_STAMP(4);
     if (kg > 0) return;
 #pragma unroll
     for (int k2 = 0; k2 < KG - 1; ++k2)
@@ -408,6 +551,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
             *reinterpret_cast<h4*>(st + (16 * mt + li) * RS + (32 * (g >> 1) + 8 * cl + 4 * (g & 1)) * 2) = o;
         }
     }
+    QS_STAMP(5);
     _Float16* const orow = reinterpret_cast<_Float16*>(out) + (unit0 + wn) * 64 + (lane & 7) * 8;
 #pragma unroll
     for (int i = 0; i < 2 * MT; ++i) {
@@ -416,6 +560,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
         const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane & 7) * 16);
         if (m < M) *reinterpret_cast<v4u*>(orow + (size_t)m * N) = v;
     }
+    QS_STAMP(6);
 }
 
 template <int MT, int WN, int MODE, int OUTK, bool KSPLIT>
@@ -432,7 +577,12 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
     if (ns > nloc + 1) ns = nloc + 1;
     if (ns < 3) ns = 3;                                // the slot read ahead and the slot refilled must differ
     size_t smem = (size_t)KG * ns * GSTAGE;
-    const size_t tail = (size_t)(KG - 1) * WN * MT * 4 * 4 * 64 * 4 + (size_t)WN * 16 * MT * 144;   // reduction + staging
+    size_t tail = (size_t)(KG - 1) * WN * MT * 4 * 4 * 64 * 4 + (size_t)WN * 16 * MT * 144;   // reduction + staging
+    {   // distributed form: [owner KG][WN][KG-1 sources][pieces per group] x 1 KiB + the same staging area
+        const size_t ppg = (MT * 4 + KG - 1) / KG;
+        const size_t t2 = (size_t)KG * WN * (KG - 1) * ppg * 1024 + (size_t)WN * 16 * MT * 144;
+        if (tail < t2) tail = t2;
+    }
     if (smem < tail) smem = tail;
     static size_t configured_dev[QS_MAX_DEVICES] = {};   // per instantiation and device
     size_t& configured = configured_dev[qs_device_slot()];
@@ -449,11 +599,18 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, A, W, zeros, scales8,
                        reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
                        reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K,
-                       mblocks, ns, ksplit, slabs, counters);
+                       mblocks, ns, ksplit, slabs, counters, g_ring_flags);
     return qs_launch_status("w4a8 gemm (ring)");
 }
 
 }  // namespace
+
+#ifdef QS_RING_TRACE
+extern "C" int qs_debug_ring_trace(void* buf) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ring_trace), &p, sizeof(p));
+}
+#endif
 
 // Entry used by the dispatcher in gemm_w4a8.hip.  mt = m-tiles per workgroup (1, 2, 4), wn = units per workgroup
 // (1, 2); ksplit = K slices (1 = none; > 1 needs the slab / counter workspace: (N/64) * mblocks * ksplit * mt KiB * 4 and
