@@ -122,6 +122,20 @@ int qs_single_query_attention(const void* q, const void* k, const void* v, const
                               int timestep, int rotary_embedding_dim, float rotary_base, int neox_rotary_style,
                               int int4_kv_cache, int kv_cache_with_zeros, qs_stream_t stream);
 
+/* Pair fusion for the decode loop (no reference counterpart): single_query_attention followed by
+ * invoke_quant(_fuse_sum) of its output (llama_w4a8_unpad.py:253-282) as ONE call.  `out` receives the fp16 attention
+ * output exactly as above; quant_out int8 [B, H*Dh], quant_scale half [B], quant_sum half [B] (may be NULL) receive what
+ * qs_invoke_quant(quant_out, out, quant_sum, quant_scale, B, H*Dh) would write - BIT-IDENTICAL.  Where the chosen
+ * attention kernel can finish the row itself (matrix-core KV4 kernel, no KV split, H*Dh <= 4096) this is one launch,
+ * otherwise the two launches are issued here.  Uses the per-device arrival-counter scratch (same stream rule as above). */
+int qs_single_query_attention_quant(const void* q, const void* k, const void* v, const int64_t* kv_pointers,
+                                    const int32_t* length_per_sample, void* out, int8_t* quant_out, void* quant_sum,
+                                    void* quant_scale, int batch, int num_heads, int num_kv_heads, int head_dim,
+                                    int64_t q_stride0, int64_t kv_stride0, int max_blocks, int memory_max_seqlen,
+                                    int tokens_per_block, int size_per_token, int timestep, int rotary_embedding_dim,
+                                    float rotary_base, int neox_rotary_style, int int4_kv_cache, int kv_cache_with_zeros,
+                                    qs_stream_t stream);
+
 /* Kernel selection for A/B tests: 0 = matrix-core kernels (KV4 and KV8) with the split-KV heuristic [default],
  * 1 = VALU kernels, 100 + n = matrix-core kernels with exactly n KV splits. */
 void qs_set_attention_variant(int variant);

@@ -571,6 +571,31 @@ extern "C" int qs_single_query_attention(const void* q, const void* k, const voi
 }
 
 thread_local QsAttnPlan g_qs_attn_plan = {0, 0, 0, 0};
+thread_local QsAttnQuant g_qs_attn_quant = {nullptr, nullptr, nullptr, 0};
+
+// single_query_attention followed by invoke_quant(_fuse_sum) of its output, as ONE call (decode loop of
+// llama_w4a8_unpad.py:253-282: attention, reshape, self.invoke_quant).  Results are bit-identical to the two calls; where
+// the chosen attention kernel can finish the row itself (matrix-core KV4 kernel, no KV split, rows <= 4096) the row
+// kernel and a kernel boundary disappear, otherwise the two launches are issued here.
+extern "C" int qs_single_query_attention_quant(const void* q, const void* k, const void* v, const int64_t* kv_pointers,
+                                               const int32_t* length_per_sample, void* out, int8_t* quant_out,
+                                               void* quant_sum, void* quant_scale, int batch, int num_heads,
+                                               int num_kv_heads, int head_dim, int64_t q_stride0, int64_t kv_stride0,
+                                               int max_blocks, int memory_max_seqlen, int tokens_per_block,
+                                               int size_per_token, int timestep, int rotary_embedding_dim,
+                                               float rotary_base, int neox_rotary_style, int int4_kv_cache,
+                                               int kv_cache_with_zeros, qs_stream_t stream) {
+    QS_REQUIRE(quant_out && quant_scale, "single_query_attention_quant: null pointer");
+    g_qs_attn_quant = {quant_out, quant_scale, quant_sum, 0};
+    const int rc = qs_single_query_attention(q, k, v, kv_pointers, length_per_sample, out, batch, num_heads, num_kv_heads,
+                                             head_dim, q_stride0, kv_stride0, max_blocks, memory_max_seqlen,
+                                             tokens_per_block, size_per_token, timestep, rotary_embedding_dim, rotary_base,
+                                             neox_rotary_style, int4_kv_cache, kv_cache_with_zeros, stream);
+    const int done = g_qs_attn_quant.done;
+    g_qs_attn_quant = {nullptr, nullptr, nullptr, 0};
+    if (rc != QS_OK || done || batch == 0) return rc;
+    return qs_invoke_quant(quant_out, out, quant_sum, quant_scale, batch, num_heads * head_dim, stream);
+}
 extern "C" int qs_attention_plan(int batch, int num_heads, int num_kv_heads, int max_blocks, int timestep,
                                  int int4_kv_cache, int* plan3) {
     QS_REQUIRE(plan3, "attention plan: null output");

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
     const int64_t* __restrict__ kv_pointers, const int* __restrict__ lengths, _Float16* __restrict__ out,
     int num_heads, int num_kv_heads, int64_t q_stride0, int64_t kv_stride0, int max_blocks, int timestep,
-    float rope_base, const float2* __restrict__ rope_tab, int rope_tab_len, int nsplit, float* __restrict__ ws) {
+    float rope_base, const float2* __restrict__ rope_tab, int rope_tab_len, int nsplit, float* __restrict__ ws,
+    int8_t* __restrict__ qout, __half* __restrict__ qscale, __half* __restrict__ qrowsum, unsigned* __restrict__ qcounters) {
     __shared__ __attribute__((aligned(16))) uint8_t s_kv[2 * NW * PAGE_TOK * DHB];   // [K | V][wave][4 KiB]
     __shared__ __attribute__((aligned(16))) _Float16 s_meta[NW][4][PAGE_TOK];   // k scale, k zero, v scale, v zero
     __shared__ __attribute__((aligned(16))) _Float16 s_q[G][DH];                // rotated q of the G heads
@@ -712,13 +713,102 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
             den += f * s_l[w][h];
         }
         if (nsplit == 1) {
-            out[((size_t)b * num_heads + (size_t)hkv * G + h) * DH + d] = (_Float16)(num / (den + 1.e-6f));   // Template.hpp:1819
+            const _Float16 res = (_Float16)(num / (den + 1.e-6f));   // Template.hpp:1819
+            if (qout) reinterpret_cast<_Float16*>(&s_meta[0][0][0])[o] = res;   // (page metadata is dead: staging area)
+            else out[((size_t)b * num_heads + (size_t)hkv * G + h) * DH + d] = res;
         } else {                                                    // un-normalised partial: [O(128) | M | L]
             float* pw = ws + ((((size_t)b * num_kv_heads + hkv) * nsplit + z) * G + h) * (DH + 2);
             pw[d] = num;
             if (d == 0) {
                 pw[DH] = M * 0.6931471805599453f;   // the merge kernel works in natural-log units
                 pw[DH + 1] = den;
+            }
+        }
+    }
+    // ---- fused invoke_quant(_fuse_sum) of the attention output (qs_single_query_attention_quant) -----------------------
+    // The per-token statistics span all KV heads = all workgroups of the sequence, so the LAST of them to finish does
+    // the row: every workgroup publishes its G x 128 fp16 outputs with write-through (sc0 sc1) 16-byte stores, waits for
+    // their acknowledgement, draws a ticket from a per-sequence counter (device-scope atomic; reset by the last
+    // arriver); the last one re-reads the whole row with cache-missing (sc0 sc1) loads and runs quant_kernel's exact
+    // arithmetic on its first 256 threads - same thread -> element mapping, same shuffle trees, same combination order
+    // over the four waves - so qout / qscale / qsum are BIT-IDENTICAL to invoke_quant(_fuse_sum)(out).  The seam is the
+    // fence-free form of the K-sliced GEMM (gemm_w4a8_ring.hip); it replaces a ~5 us row kernel and a kernel boundary.
+    if (nsplit == 1 && qout) {
+        __syncthreads();
+        const int hidden = num_heads * DH;
+        if (tid2 < G * 16) {
+            const v4u x = reinterpret_cast<const v4u*>(&s_meta[0][0][0])[tid2];
+            _Float16* dst = out + ((size_t)b * num_heads + (size_t)hkv * G) * DH + tid2 * 8;
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(x) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid2 == 0) {
+            const unsigned t = __hip_atomic_fetch_add(qcounters + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = t == (unsigned)(num_kv_heads - 1);
+            if (last) __hip_atomic_store(qcounters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *(volatile __attribute__((address_space(3))) int*)(&s_flag) = last;
+        }
+        __syncthreads();
+        if (*(volatile __attribute__((address_space(3))) int*)(&s_flag)) {      // workgroup-uniform
+            float* const sm = reinterpret_cast<float*>(&s_kv[0]);                // 2 x 4 floats
+            const _Float16* row = out + (size_t)b * hidden;
+            v4u raw[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+            float amax = 0.f, sum = 0.f;
+            if (tid2 < 256) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int i = (c * 256 + tid2) * 8;
+                    if (i < hidden) {
+                        const _Float16* src = row + i;
+                        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(raw[c]) : "v"(src) : "memory");
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1])::"memory");
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int i = (c * 256 + tid2) * 8;
+                    if (i < hidden) {
+                        const h8 vv = __builtin_bit_cast(h8, raw[c]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float f = (float)vv[j];
+                            sum += f;
+                            amax = fmaxf(amax, fabsf(f));
+                        }
+                    }
+                }
+                amax = wave_max(amax);
+                if (qrowsum) sum = wave_sum(sum);
+                if ((tid2 & 63) == 0) {
+                    sm[tid2 >> 6] = amax;
+                    sm[4 + (tid2 >> 6)] = sum;
+                }
+            }
+            __syncthreads();
+            if (tid2 < 256) {
+                float r = sm[0], s2 = qrowsum ? sm[4] : 0.f;
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    r = fmaxf(r, sm[w]);
+                    if (qrowsum) s2 = s2 + sm[4 + w];
+                }
+                if (tid2 == 0) {
+                    qscale[b] = __float2half_rn(r / 127.0f);                     // fused_kernels.cu:72
+                    if (qrowsum) qrowsum[b] = __float2half_rn(s2);                     // :121
+                }
+                const float mul = 127.0f / r;                                     // :78 (unrounded fp32 amax)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int i = (c * 256 + tid2) * 8;
+                    if (i < hidden) {
+                        const h8 vv = __builtin_bit_cast(h8, raw[c]);
+                        float f[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) f[j] = (float)vv[j];
+                        qs_store_q8(qout + (size_t)b * hidden + i, f, mul);
+                    }
+                }
             }
         }
     }
@@ -841,6 +931,30 @@ extern "C" int qs_debug_copy_split_workspace(void* dst, size_t bytes) {
     return (int)hipMemcpy(dst, g_ws[dev].p, bytes, hipMemcpyDeviceToDevice);
 }
 
+// per-sequence arrival counters of the attention + quant fusion: one fixed allocation per device (65536 sequences),
+// zeroed once, self-resetting (the last arriver of every sequence writes 0), never freed; nullptr while it cannot be
+// allocated (first use inside a stream capture): the caller then runs the un-fused pair
+namespace {
+unsigned* g_qcounters[16];
+}
+unsigned* qs_attn_quant_counters(hipStream_t st, int batch) {
+    int dev = 0;
+    if (batch > 65536 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (g_qcounters[dev]) return g_qcounters[dev];
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, 65536 * sizeof(unsigned)) != hipSuccess || hipMemset(p, 0, 65536 * sizeof(unsigned)) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    g_qcounters[dev] = reinterpret_cast<unsigned*>(p);
+    return g_qcounters[dev];
+}
+
 // called from attention.hip's dispatcher for KV4.  force_split: 0 = heuristic, n > 0 = exactly n splits (tests)
 int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
                           const int64_t* kvp, const int* len, _Float16* out, int H, int Hkv, int64_t qs, int64_t kvs,
@@ -879,13 +993,24 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
         if (!ws) nsplit = 1;
     }
     grid.z = nsplit;
+    // attention + invoke_quant fusion (qs_single_query_attention_quant): un-split launches over rows of <= 4096 values
+    // (quant_kernel's 256-thread mapping is what the last arriver reproduces bit for bit)
+    int8_t* qout = nullptr;
+    __half *qscale = nullptr, *qsum = nullptr;
+    unsigned* qcnt = nullptr;
+    if (g_qs_attn_quant.qout && nsplit == 1 && H * DH <= 4096 && (qcnt = qs_attn_quant_counters(st, (int)grid.y))) {
+        qout = g_qs_attn_quant.qout;
+        qscale = reinterpret_cast<__half*>(g_qs_attn_quant.qscale);
+        qsum = reinterpret_cast<__half*>(g_qs_attn_quant.qsum);
+        g_qs_attn_quant.done = 1;
+    }
 #define QS_LAUNCH_G(GG)                                                                                             \
     hipLaunchKernelGGL((decode_attention_mfma_kernel<GG>), grid, dim3(NWT * 64), 0, st, q, k, v, kvp, len, out, H, Hkv, \
-                       qs, kvs, mb, timestep, base, tab, tab_len, nsplit, ws)
+                       qs, kvs, mb, timestep, base, tab, tab_len, nsplit, ws, qout, qscale, qsum, qcnt)
 #define QS_LAUNCH_EXP(E)                                                                                              \
     case E:                                                                                                            \
         hipLaunchKernelGGL((decode_attention_mfma_kernel<4, E>), grid, dim3(NWT * 64), 0, st, q, k, v, kvp, len, out, H,  \
-                           Hkv, qs, kvs, mb, timestep, base, tab, tab_len, nsplit, ws);                                \
+                           Hkv, qs, kvs, mb, timestep, base, tab, tab_len, nsplit, ws, qout, qscale, qsum, qcnt);      \
         return qs_launch_status("single_query_attention")
     if (exp_flags & 32) {                     // timeline trace: stamps go to the (otherwise unused) split workspace
         ws = qs_split_workspace((size_t)blocks * NWT * 16 * 8, st);

@@ -104,6 +104,15 @@ struct QsAttnPlan {
     int active, family, nsplit, waves;
 };
 extern thread_local QsAttnPlan g_qs_attn_plan;
+// request of qs_single_query_attention_quant to the attention launchers: fuse invoke_quant(_fuse_sum) of the output
+// into the kernel when the chosen kernel can (sets `done`); otherwise the entry point runs the row kernel itself
+struct QsAttnQuant {
+    int8_t* qout;
+    void* qscale;
+    void* qsum;     // may be null (invoke_quant without the row sum)
+    int done;
+};
+extern thread_local QsAttnQuant g_qs_attn_quant;
 
 // butterfly exchange with an explicitly supplied lane id: __shfl_xor derives its own (loop-invariant) lane id, which the
 // register allocator then keeps alive - or spills - across a long loop
@@ -125,4 +134,15 @@ __device__ __forceinline__ unsigned rni_sat_u8(float x) {
     float r = rintf(x);
     r = fminf(fmaxf(r, 0.f), 255.f);
     return (x != x) ? 0u : (unsigned)r;
+}
+// 8 values x mul -> 8 int8 (cvt.rni.sat.s8.f32), one 8-byte store: the quantising store of the per-token row kernels
+// (fused_kernels.cu:78-82), shared by fused_small.hip and the attention + quant fusion
+__device__ __forceinline__ void qs_store_q8(int8_t* p, const float (&v)[8], float mul) {
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        lo |= ((unsigned)rni_sat_s8(v[j] * mul) & 0xFFu) << (8 * j);
+        hi |= ((unsigned)rni_sat_s8(v[4 + j] * mul) & 0xFFu) << (8 * j);
+    }
+    *reinterpret_cast<uint2*>(p) = make_uint2(lo, hi);
 }

@@ -66,15 +66,7 @@ constexpr int WIDE_ROW = 4096;
 
 __device__ __forceinline__ h8 load8(const _Float16* p) { return *reinterpret_cast<const h8*>(p); }
 
-__device__ __forceinline__ void store_q8(int8_t* p, const float (&v)[8], float mul) {
-    unsigned lo = 0, hi = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        lo |= ((unsigned)rni_sat_s8(v[j] * mul) & 0xFFu) << (8 * j);
-        hi |= ((unsigned)rni_sat_s8(v[4 + j] * mul) & 0xFFu) << (8 * j);
-    }
-    *reinterpret_cast<uint2*>(p) = make_uint2(lo, hi);
-}
+__device__ __forceinline__ void store_q8(int8_t* p, const float (&v)[8], float mul) { qs_store_q8(p, v, mul); }
 
 // ---------------------------------------------------------------------------------------------------------
 // Row kernels keep the whole token row in registers (NC chunks of 8 fp16 per thread, hidden <= NC*2048): ONE global

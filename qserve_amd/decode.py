@@ -7,8 +7,8 @@ It issues exactly the op sequence of the reference's model code for `is_prompt=F
     -> residual add -> rms_norm_general_fuse_sum -> gate_up GEMM -> silu_and_mul -> invoke_quant_fuse_sum
     -> down GEMM -> residual add;   then rms_norm, fp16 lm_head, greedy sampling.
 
-With `fuse_pairs=True` (default) the adjacent pairs (residual add, layer norm) and (silu_and_mul, quant) are issued as
-one launch each (qserve_amd/fused.py) - same arithmetic, same intermediate fp16 roundings, bit-identical tensors
+With `fuse_pairs=True` (default) the adjacent pairs (attention, quant of its output), (residual add, layer norm) and
+(silu_and_mul, quant) are issued as one launch each (qserve_amd/fused.py) - same arithmetic, same intermediate fp16 roundings, bit-identical tensors
 (tests/test_fused_gpu.py, tests/test_decode_gpu.py); `fuse_pairs=False` issues the reference's ops one by one.
 
 Weights are synthetic (random packed nibbles / scales of the right shapes, distinct per layer so nothing is
@@ -313,15 +313,21 @@ class DecodeEngine:
                 norm_quant(h, L["ln1"])
             L["qkv"](qa, self.q_scale, self.q_sum, self.qkv_buf)
             q, k, v = self.qkv_buf.split([self.H * 128, self.Hkv * 128, self.Hkv * 128], dim=-1)
-            attn = fused_attention.single_query_attention(
-                q.reshape(B, self.H, 128), k.reshape(B, self.Hkv, 128), v.reshape(B, self.Hkv, 128), self.tables[li],
-                self.lengths, None, 8192, 64, self.size_per_token, self.max_len, 128, cfg["rope_theta"], True,
-                self.int4, True)
-            attn = attn.reshape(B, -1)
-            if fuse_sum:
-                fused_kernels.invoke_quant_fuse_sum(qo, attn, self.q_sum, self.q_scale)
+            if fuse:         # attention + invoke_quant(_fuse_sum) of its output in one call (bit-identical pair fusion)
+                fusedmod.single_query_attention_quant(
+                    q.reshape(B, self.H, 128), k.reshape(B, self.Hkv, 128), v.reshape(B, self.Hkv, 128), self.tables[li],
+                    self.lengths, qo, self.q_scale, 8192, 64, self.size_per_token, self.max_len, 128, cfg["rope_theta"],
+                    True, self.int4, True, quant_sum=sums)
             else:
-                fused_kernels.invoke_quant(qo, attn, self.q_scale)
+                attn = fused_attention.single_query_attention(
+                    q.reshape(B, self.H, 128), k.reshape(B, self.Hkv, 128), v.reshape(B, self.Hkv, 128), self.tables[li],
+                    self.lengths, None, 8192, 64, self.size_per_token, self.max_len, 128, cfg["rope_theta"], True,
+                    self.int4, True)
+                attn = attn.reshape(B, -1)
+                if fuse_sum:
+                    fused_kernels.invoke_quant_fuse_sum(qo, attn, self.q_sum, self.q_scale)
+                else:
+                    fused_kernels.invoke_quant(qo, attn, self.q_scale)
             L["o"](qo, self.q_scale, self.q_sum, self.proj_out)
             if self.tp_world > 1:
                 yield self.proj_out

@@ -5,6 +5,7 @@ they exist because at decode batch sizes each row kernel is a fixed ~5 us latenc
 
     add_residual_rms_norm_general(_fuse_sum)  ==  hidden += delta ; layernorm_ops.rms_norm_general(_fuse_sum)(hidden)
     silu_and_mul_quant(_fuse_sum)             ==  activation_ops.silu_and_mul ; fused_kernels.invoke_quant(_fuse_sum)
+    single_query_attention_quant(_fuse_sum)   ==  fused_attention.single_query_attention ; fused_kernels.invoke_quant(_fuse_sum)
 """
 import torch
 
@@ -43,3 +44,38 @@ def silu_and_mul_quant(out, input, scale, input_sum=None):
     with guard(out):
         check(lib.qs_silu_and_mul_quant(ptr(out), ptr(input), ptr(input_sum) if input_sum is not None else 0, ptr(scale),
                                         input.numel() // (2 * d), d, stream()), "fused.silu_and_mul_quant")
+
+
+def single_query_attention_quant(q, k, v, kv_pointers, length_per_sample, quant_out, quant_scale, memory_max_seqlen,
+                                 tokens_per_block, size_per_token, timestep, rotary_embedding_dim, rotary_base,
+                                 neox_rotary_style, int4_kv_cache, kv_cache_with_zeros, quant_sum=None):
+    """attn = single_query_attention(q, k, v, ...) (fp16 [B, H, Dh], returned) and, in the same call,
+    quant_out / quant_scale (/ quant_sum) = invoke_quant(_fuse_sum)(attn.reshape(B, -1)) - bit-identical to the pair
+    (llama_w4a8_unpad.py:253-282); one launch where the attention kernel can finish the row itself."""
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        expect(t, torch.float16, n, contiguous=False)
+    expect(kv_pointers, torch.int64, "kv_pointers")
+    expect(quant_out, torch.int8, "quant_out")
+    expect(quant_scale, torch.float16, "quant_scale")
+    if quant_sum is not None:
+        expect(quant_sum, torch.float16, "quant_sum")
+    batch = kv_pointers.size(0)
+    nheads, nheads_kv, headdim = q.size(1), k.size(1), k.size(-1)
+    if not (k.stride(2) == 1 and k.stride(1) == headdim and v.stride(2) == 1 and v.stride(1) == headdim):
+        raise RuntimeError("k and v must have stride(2) == 1 and stride(1) == head_dim")
+    if not (q.stride(2) == 1 and q.stride(1) == headdim):
+        raise RuntimeError("q must have stride(2) == 1 and stride(1) == head_dim")
+    if length_per_sample is not None:
+        expect(length_per_sample, torch.int32, "length_per_sample")
+    if quant_out.numel() != q.size(0) * nheads * headdim:
+        raise RuntimeError("quant_out must hold batch x heads x head_dim int8 values")
+    out = torch.empty((q.size(0), nheads, headdim), dtype=q.dtype, device=q.device)
+    with guard(q):
+        check(lib.qs_single_query_attention_quant(
+            ptr(q), ptr(k), ptr(v), ptr(kv_pointers), ptr(length_per_sample), ptr(out), ptr(quant_out),
+            ptr(quant_sum) if quant_sum is not None else 0, ptr(quant_scale), batch, nheads, nheads_kv, headdim,
+            q.stride(0), k.stride(0), kv_pointers.size(-1), int(memory_max_seqlen), int(tokens_per_block),
+            int(size_per_token), int(timestep), int(rotary_embedding_dim), float(rotary_base),
+            int(bool(neox_rotary_style)), int(bool(int4_kv_cache)), int(bool(kv_cache_with_zeros)), stream()),
+            "fused.single_query_attention_quant")
+    return out

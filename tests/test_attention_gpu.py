@@ -267,3 +267,62 @@ def test_decode_valu_kernel_still_correct(gpu, int4):
     finally:
         _lib.lib.qs_set_attention_variant(0)
 
+
+
+@pytest.mark.parametrize("int4", [True, False], ids=["kv4", "kv8"])
+@pytest.mark.parametrize("with_sum", [True, False])
+@pytest.mark.parametrize("B,H,Hkv,L", [(64, 32, 8, 1033), (5, 8, 2, 300), (3, 8, 8, 130), (2, 16, 2, 70), (8, 32, 8, 4000)])
+def test_attention_quant_fusion_is_bit_identical_to_the_pair(gpu, B, H, Hkv, L, with_sum, int4):
+    """qserve_amd.fused.single_query_attention_quant == single_query_attention ; invoke_quant(_fuse_sum): the fp16
+    output, the int8 row, the fp16 scale (and row sum) and every cache byte, bit for bit - in-kernel fusion (KV4, no KV
+    split: the last-arriving workgroup of a sequence finishes the row), split-KV launches (B=8, L=4000) and the KV8 /
+    other fall-back paths alike."""
+    import qserve_backend.fused_attention as fa
+    import qserve_backend.fused_kernels as fk
+    from qserve_amd import fused
+    g = torch.Generator(device=gpu).manual_seed(B + H + L)
+    mb = (L + 63) // 64 + 1
+    dhb = 64 if int4 else 128
+    nblocks = B * mb
+
+    def fresh():
+        pools = DevPools(nblocks, Hkv, int4, gpu, fill=0)
+        g2 = torch.Generator(device=gpu).manual_seed(7)
+        nd = Hkv * 64 * dhb
+        for p in (pools.k, pools.v):
+            p[:, :nd] = torch.randint(0, 256, (nblocks, nd), dtype=torch.uint8, device=gpu, generator=g2)
+            p[:, nd:].view(torch.float16).copy_((torch.rand((nblocks, (pools.pb - nd) // 2), device=gpu, generator=g2) * 0.5 + 0.05).half())
+        return pools
+    tables = torch.stack([torch.randperm(nblocks, generator=torch.Generator().manual_seed(1)).reshape(B, mb),
+                          torch.randperm(nblocks, generator=torch.Generator().manual_seed(2)).reshape(B, mb)], dim=1).numpy()
+    new = torch.randn((B, (H + 2 * Hkv) * 128), generator=g, device=gpu, dtype=torch.float16)
+    q, k, v = new.split([H * 128, Hkv * 128, Hkv * 128], dim=-1)
+    q, k, v = q.reshape(B, H, 128), k.reshape(B, Hkv, 128), v.reshape(B, Hkv, 128)
+    lens = torch.randint(max(1, L - 200), L + 1, (B,), generator=torch.Generator().manual_seed(3)).to(torch.int32).to(gpu)
+    lens[0] = L
+    args = (None, 8192, 64, Hkv * dhb, L, 128, ROPE, True, int4, True)
+    # the pair
+    p1 = fresh()
+    ptr1 = p1.pointers(tables)
+    out1 = fa.single_query_attention(q, k, v, ptr1, lens, *args)
+    q1 = torch.full((B, H * 128), 77, dtype=torch.int8, device=gpu)
+    s1 = torch.full((B,), 7.0, dtype=torch.float16, device=gpu)
+    m1 = torch.full((B,), 7.0, dtype=torch.float16, device=gpu)
+    if with_sum:
+        fk.invoke_quant_fuse_sum(q1, out1.reshape(B, -1), m1, s1)
+    else:
+        fk.invoke_quant(q1, out1.reshape(B, -1), s1)
+    # the fused call, twice (the arrival counters must have reset themselves)
+    for rep in range(2):
+        p2 = fresh()
+        ptr2 = p2.pointers(tables)
+        q2 = torch.full((B, H * 128), 55, dtype=torch.int8, device=gpu)
+        s2 = torch.full((B,), 5.0, dtype=torch.float16, device=gpu)
+        m2 = torch.full((B,), 7.0, dtype=torch.float16, device=gpu)
+        out2 = fused.single_query_attention_quant(q, k, v, ptr2, lens, q2, s2, *args[1:], quant_sum=m2 if with_sum else None)
+        torch.cuda.synchronize()
+        assert torch.equal(out2.view(torch.int16), out1.view(torch.int16)), "fp16 attention output differs"
+        assert torch.equal(s2.view(torch.int16), s1.view(torch.int16)), "scale differs"
+        assert torch.equal(q2, q1), "int8 row differs"
+        assert torch.equal(m2.view(torch.int16), m1.view(torch.int16)), "row sum differs (or was touched without being asked for)"
+        assert torch.equal(p2.k, p1.k) and torch.equal(p2.v, p1.v), "cache pages differ"
