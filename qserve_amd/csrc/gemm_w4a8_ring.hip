@@ -20,7 +20,7 @@
 #include <type_traits>
 
 // A/B switches (qs_set_gemm_variant(5000 + bits); every setting computes the same results):
-//   1 = weight DMA with the default cache policy instead of non-temporal, 2 = epilogue on the first K-group only
+//   1 = weight DMA with the default cache policy instead of non-temporal
 int g_ring_flags = 0;
 
 namespace {
@@ -345,12 +345,17 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
     // DISTRIBUTED form (no K slices): piece pc is finished by K-group pc % KG - every group sums, scales and converts a
     // 1/KG share of the tile instead of groups 1..KG-1 handing everything to group 0 and leaving (timeline trace,
     // scripts/trace_gemm.py: reduction + epilogue on two of eight waves = 3 us of a 19 us launch at gate_up size).
-    const bool dist = !(KSPLIT && ksplit > 1) && !(flags & 2);
+    // (in-run A/B against the group-0 form, qs_set_gemm_variant(5002) in the r2 builds: qkv 9.8 -> 8.7, o 7.5 -> 7.2,
+    //  gate_up 19.5 -> 18.1 us; the switch was removed because keeping both forms alive made the kernel spill)
+    const bool dist = !(KSPLIT && ksplit > 1);
     if (dist) {
         constexpr int PPG = (NP + KG - 1) / KG;        // pieces per owning group
         h4 ws4[PPG], wz4[PPG];
         _Float16 sa_h[PPG], ss_h[PPG];
-        if (OUTK == 0) {                               // scale operands of the OWN pieces, requested ahead of the barriers
+        __syncthreads();                               // rings are dead (every wave drained its DMA queue)
+        QS_STAMP(4);
+        if (OUTK == 0) {                               // scale operands of the OWN pieces, requested here: their latency hides under the exchange below (before the
+                                                       // barrier the k loop's operand buffers are still live and the compiler spills)
 #pragma unroll
             for (int q = 0; q < PPG; ++q) {
                 const int pc = q * KG + kg;
@@ -365,8 +370,6 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
                 }
             }
         }
-        __syncthreads();                               // rings are dead (every wave drained its DMA queue)
-        QS_STAMP(4);
         // partial of piece pc from group kg -> slot [owner][wn][source index among the other groups][pc / KG][lane]
         v4i* const red4 = reinterpret_cast<v4i*>(smem);
 #pragma unroll

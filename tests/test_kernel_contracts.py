@@ -1,0 +1,97 @@
+"""Code-generation contracts of the hand-scheduled kernels, checked on the gfx950 assembly hipcc produces (CPU-only:
+hipcc cross-compiles; ~1 minute).  These are the properties the measured performance rests on and that a harmless-looking
+source edit silently destroys (each one was found the hard way):
+
+* the page loop of the KV4 / KV8 decode attention kernels waits on the vector-memory queue ONLY through the three
+  hand-placed counted waits - as soon as the compiler's own waitcnt pass sees an LDS-DMA in flight at loop entry it puts
+  `s_waitcnt vmcnt(0)` in front of every LDS read, which serialises page fetch and compute;
+* no kernel of the decode / prefill hot path uses scratch memory (register spills);
+* the occupancy the launch geometry assumes (two 512-thread workgroups per CU for decode attention) is reachable.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "qserve_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    out = {}
+    d = tmp_path_factory.mktemp("asm")
+    for name in ("attention_mfma", "attention_mfma8", "gemm_w4a8_ring", "gemm_w4a8_tiled"):
+        dst = d / (name + ".s")
+        r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(dst),
+                            os.path.join(CSRC, name + ".hip")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[name] = open(dst).read()
+    return out
+
+
+def kernels(text):
+    """{mangled name: body} of every kernel in an assembly file."""
+    res = {}
+    for m in re.finditer(r"^(_Z\w+):\s*; @\1\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
+        res[m.group(1)] = m.group(2)
+    return res
+
+
+def meta(text, name, key):
+    m = re.search(re.escape(name) + r".*?;\s*" + key + r":\s*(\d+)", text, re.S)
+    return int(m.group(1))
+
+
+def test_kv4_attention_page_loop_has_only_the_hand_placed_vmcnt_waits(asm):
+    ks = {n: b for n, b in kernels(asm["attention_mfma"]).items() if "decode_attention_mfma_kernel" in n}
+    product = {n: b for n, b in ks.items() if re.search(r"kernelILi\dELi0E", n)}       # EXP = 0 instantiations, G = 1..8
+    assert len(product) == 8
+    for name, body in product.items():
+        i0, i1 = body.index("s_waitcnt vmcnt(5) ; QS_LOOP_BEGIN"), body.index("QS_LOOP_END")
+        loop = body[i0:i1]
+        waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop)
+        # loop top vmcnt(5) [K landed], then the V wait: vmcnt(0) on the last page / vmcnt(5) otherwise
+        assert waits == ["5", "0", "5"], f"{name}: vector-memory waits inside the page loop: {waits}"
+        # between the flag poll and the loop nothing may drain the queue either
+        pre = body[body.index("s_sleep"):i0]
+        assert "vmcnt(0)" not in pre.split("global_load_lds")[-1], f"{name}: vmcnt(0) between the page DMA issue and the loop"
+        assert "global_load_lds_dwordx4" in body and " nt" in body, "page DMA must be issued from asm with the nt hint"
+
+
+def test_kv8_attention_page_loop_has_only_the_hand_placed_vmcnt_waits(asm):
+    ks = {n: b for n, b in kernels(asm["attention_mfma8"]).items() if "decode_attention_mfma8_kernel" in n}
+    assert len(ks) == 8
+    for name, body in ks.items():
+        head = body.index("s_waitcnt vmcnt(9)")
+        loop = body[head:]
+        loop = loop[:loop.index("s_barrier")]
+        waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop)
+        # loop top vmcnt(9) [K landed], V wait vmcnt(0) (last page) / vmcnt(9); then the drain in front of the merge barrier
+        assert waits == ["9", "0", "9", "0"], f"{name}: {waits}"
+
+
+@pytest.mark.parametrize("unit", ["attention_mfma", "attention_mfma8", "gemm_w4a8_ring", "gemm_w4a8_tiled"])
+def test_hot_path_kernels_do_not_spill(asm, unit):
+    text = asm[unit]
+    names = re.findall(r"^\s*\.amdhsa_kernel (\S+)", text, re.M)
+    scratch = [int(x) for x in re.findall(r"; ScratchSize: (\d+)", text)]
+    assert len(names) == len(scratch) and names
+    bad = [(n, s) for n, s in zip(names, scratch) if s]
+    assert not bad, f"kernels with scratch (spills): {bad}"
+
+
+def test_decode_attention_fits_two_workgroups_per_cu(asm):
+    text = asm["attention_mfma"]
+    for name in kernels(text):
+        if "decode_attention_mfma_kernel" not in name or not re.search(r"kernelILi\dELi0E", name):
+            continue
+        vg = meta(text, name, "NumVgprs")
+        lds = meta(text, name, "LDSByteSize")
+        alloc = (vg + 7) // 8 * 8
+        assert 512 // alloc >= 4, f"{name}: {vg} VGPRs -> fewer than 4 waves per SIMD (two 8-wave workgroups per CU)"
+        assert 2 * lds <= 160 * 1024, f"{name}: {lds} B of LDS per workgroup"
