@@ -195,6 +195,16 @@ def qs_single_query_attention(q, k, v, kv_pointers, length_per_sample, out, batc
     return 0
 
 
+def qs_single_query_attention_quant(q, k, v, kv_pointers, length_per_sample, out, quant_out, quant_sum, quant_scale, batch, H,
+                                    Hkv, head_dim, q_stride0, kv_stride0, max_blocks, memory_max_seqlen, tokens_per_block,
+                                    size_per_token, timestep, rot_dim, base, neox, int4, with_zeros, stream):
+    """The pair it is defined as (include/qserve_amd.h): attention, then invoke_quant(_fuse_sum) of its output."""
+    rc = qs_single_query_attention(q, k, v, kv_pointers, length_per_sample, out, batch, H, Hkv, head_dim, q_stride0,
+                                   kv_stride0, max_blocks, memory_max_seqlen, tokens_per_block, size_per_token, timestep,
+                                   rot_dim, base, neox, int4, with_zeros, stream)
+    return rc or qs_invoke_quant(quant_out, out, quant_sum, quant_scale, batch, H * head_dim, stream)
+
+
 def qs_flash_attn_varlen_fwd(q, k, v, out, cu_q, cu_k, batch, H, Hkv, head_dim, qs0, ks0, vs0, os0, max_q, max_k, scale,
                              causal, stream):
     CALLS.append(("qs_flash_attn_varlen_fwd", batch, H, Hkv, max_q, max_k, causal))
@@ -212,7 +222,8 @@ def qs_flash_attn_varlen_fwd(q, k, v, out, cu_q, cu_k, batch, H, Hkv, head_dim, 
 SYMBOLS = {f.__name__: f for f in (
     qs_w4a8_per_chn_gemm, qs_w4a8_per_group_gemm, qs_invoke_quant, qs_rms_norm_general, qs_rms_norm, qs_silu_and_mul,
     qs_residual_add, qs_add_residual_rms_norm_general, qs_silu_and_mul_quant, qs_compute_padding_offsets,
-    qs_apply_bias_rope_update_kv_cache, qs_single_query_attention, qs_flash_attn_varlen_fwd)}
+    qs_apply_bias_rope_update_kv_cache, qs_single_query_attention, qs_single_query_attention_quant,
+    qs_flash_attn_varlen_fwd)}
 
 
 class _NoGuard:
