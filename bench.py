@@ -452,7 +452,10 @@ def main():
         try:
             import glob
             pdir = os.path.join(ROOT, "profiles")
-            for cand in sorted(glob.glob(os.path.join(pdir, "*_pmc_traffic.json")), key=os.path.getmtime, reverse=True):
+            def _rank(path):     # newest round first: round2_c > round2_b > ... > r05 > r04 (file names, not mtimes: a
+                b = os.path.basename(path)          # snapshot copy gives every file the same timestamp)
+                return (1, b) if b.startswith("round") else (0, b)
+            for cand in sorted(glob.glob(os.path.join(pdir, "*_pmc_traffic.json")), key=_rank, reverse=True):
                 ents = json.load(open(cand))["kernels"]
                 ent = ents.get(dom["kernel"]) or next((v for k, v in ents.items() if k.split(" L=")[0] == dom["kernel"].split(" L=")[0]), None)
                 if ent:

@@ -9,7 +9,7 @@ import qserve_backend.fused_attention as fa
 
 eng = D.DecodeEngine(D.LLAMA3_8B, 64, 1024, 512, with_lm_head=False)
 eng.prefill_cache(1024)
-eng.lengths.fill_(1100)
+eng.lengths.fill_(1033)      # bench.py default: context_start = prompt 1024 + 1 + 8 warm-up steps
 B, nl = eng.B, len(eng.layers)
 q, k, v = eng.qkv_buf.split([eng.H * 128, eng.Hkv * 128, eng.Hkv * 128], dim=-1)
 q, k, v = q.reshape(B, eng.H, 128), k.reshape(B, eng.Hkv, 128), v.reshape(B, eng.Hkv, 128)
