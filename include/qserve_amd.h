@@ -206,6 +206,11 @@ int qs_flash_attn_varlen_fwd(const void* q, const void* k, const void* v, void* 
                              int64_t q_stride0, int64_t k_stride0, int64_t v_stride0, int64_t o_stride0,
                              int max_seqlen_q, int max_seqlen_k, float softmax_scale, int causal, qs_stream_t stream);
 
+/* Device self-test (tests/test_fused_gpu.py): the DPP / permlane wave reductions every row kernel uses round exactly like
+ * the shuffle butterfly they replace.  in: float [n] (n % 64 == 0); out: float [n/64][4] = {sum, sum by shuffles, max, max
+ * by shuffles} per 64-value block. */
+int qs_debug_wave_reduce_selftest(const float* in, float* out, int n, qs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,19 +44,55 @@ static inline int qs_device_slot() {
 }
 
 // wave64 reductions -------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+// The classic xor butterfly (offsets 32, 16, 8, 4, 2, 1; every lane ends with the result) with the SAME pairing and the
+// same order of operations as a __shfl_xor loop - so fp32 sums round identically, bit for bit - but without its six
+// dependent ds_bpermute round trips through the LDS crossbar (~100+ cycles each; these reductions sit on the latency
+// chain of every row kernel):
+//   xor 32 / 16 ... v_permlane32_swap / v_permlane16_swap of the value with itself: the two results are (lower | lower)
+//                   and (upper | upper) halves (resp. even / odd rows), whose op() is "own op partner" in every lane;
+//   xor 8 ......... DPP row_ror:8 (a rotation by 8 inside a 16-lane row IS xor 8);
+//   xor 4 ......... DPP row_ror:4: after the xor-8 step the row is 8-periodic, so lane (i +- 4) mod 16 holds exactly the
+//                   value of lane i ^ 4;
+//   xor 2 / 1 ..... DPP quad_perm [2,3,0,1] / [1,0,3,2].
+// All 64 lanes must be active (every call site is wave-uniform).
+template <class Op>
+__device__ __forceinline__ float wave_butterfly(float v, Op op) {
+    {
+        const int x = __builtin_bit_cast(int, v);
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        v = op(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
+    }
+    {
+        const int x = __builtin_bit_cast(int, v);
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        v = op(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
+    }
+#define QS_DPP(ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+    v = op(v, QS_DPP(0x128));   // row_ror:8
+    v = op(v, QS_DPP(0x124));   // row_ror:4
+    v = op(v, QS_DPP(0x4E));    // quad_perm [2,3,0,1]
+    v = op(v, QS_DPP(0xB1));    // quad_perm [1,0,3,2]
+#undef QS_DPP
     return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    return wave_butterfly(v, [](float a, float b) { return fmaxf(a, b); });
 }
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+    return wave_butterfly(v, [](float a, float b) { return fminf(a, b); });
 }
 __device__ __forceinline__ float wave_sum(float v) {
+    return wave_butterfly(v, [](float a, float b) { return a + b; });
+}
+// the same three through __shfl_xor (ds_bpermute): reference form, kept for the device self-test of the equivalence
+__device__ __forceinline__ float wave_sum_shfl(float v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max_shfl(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
 

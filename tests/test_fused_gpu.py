@@ -243,3 +243,21 @@ def test_other_model_shapes_run_and_fuse_identically(gpu, name, gs):
         assert torch.isfinite(eng.hidden.float()).all()
         outs.append((eng.hidden.clone(), eng.tokens.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_wave_reductions_round_like_the_shuffle_butterfly(gpu):
+    """common.h wave_sum / wave_max (permlane swaps + DPP) == the __shfl_xor butterfly, bit for bit, in every lane: the
+    row kernels' statistics (and with them every int8 activation byte) depend on that summation order."""
+    import ctypes
+    from qserve_amd._lib import check, lib
+    g = torch.Generator(device=gpu).manual_seed(0)
+    n = 64 * 4096
+    x = (torch.randn((n,), device=gpu, generator=g) * torch.exp(torch.randn((n,), device=gpu, generator=g) * 3)).float()
+    out = torch.zeros((n // 64, 4), device=gpu)
+    check(lib.qs_debug_wave_reduce_selftest(x.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream), "selftest")
+    torch.cuda.synchronize()
+    o = out.view(torch.int32)
+    assert torch.equal(o[:, 0], o[:, 1]), "wave_sum differs from the shuffle butterfly"
+    assert torch.equal(o[:, 2], o[:, 3]), "wave_max differs from the shuffle butterfly"
+    assert torch.allclose(out[:, 0], x.view(-1, 64).double().sum(1).float(), rtol=1e-4, atol=1e-3)
+    assert torch.equal(out[:, 2], x.view(-1, 64).max(1).values)
