@@ -26,6 +26,7 @@
 #ifndef QSERVE_AMD_H
 #define QSERVE_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -210,6 +211,12 @@ int qs_flash_attn_varlen_fwd(const void* q, const void* k, const void* v, void* 
  * the shuffle butterfly they replace.  in: float [n] (n % 64 == 0); out: float [n/64][4] = {sum, sum by shuffles, max, max
  * by shuffles} per 64-value block. */
 int qs_debug_wave_reduce_selftest(const float* in, float* out, int n, qs_stream_t stream);
+
+/* Timing tool (scripts/trace_attn.py): device-to-device copy of the first `bytes` of the split-KV workspace, where the
+ * trace instantiation of the KV4 decode attention (qs_set_attention_variant(232)) leaves its s_memtime stamps.
+ * (A library built with -DQS_RING_TRACE additionally exports qs_debug_ring_trace(void* buf) for scripts/trace_gemm.py;
+ * it is not part of the shipped ABI.) */
+int qs_debug_copy_split_workspace(void* dst, size_t bytes);
 
 #ifdef __cplusplus
 }

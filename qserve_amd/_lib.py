@@ -38,6 +38,7 @@ SIGNATURES = {
     "qs_add_residual_rms_norm_general": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "qs_silu_and_mul_quant": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "qs_debug_wave_reduce_selftest": (_i, [_vp, _vp, _i, _vp]),
+    "qs_debug_copy_split_workspace": (_i, [_vp, C.c_size_t]),
     "qs_flash_attn_varlen_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _f,
                                       _i, _vp]),
 }

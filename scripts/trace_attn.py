@@ -26,7 +26,7 @@ qkv = torch.randn((B, (H + 2 * Hkv) * 128), dtype=torch.float16, device=dev)
 q, k, v = qkv.split([H * 128, Hkv * 128, Hkv * 128], dim=-1)
 q, k, v = q.reshape(B, H, 128), k.reshape(B, Hkv, 128), v.reshape(B, Hkv, 128)
 lens = torch.full((B,), L, dtype=torch.int32, device=dev)
-lib.qs_debug_copy_split_workspace.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+
 lib.qs_set_attention_variant(VAR)
 for i in range(6):   # the last launch's stamps survive; earlier launches make the caches / pools "cold" like the step
     fa.single_query_attention(q, k, v, tables[i % NL], lens, None, 8192, 64, Hkv * 64, L, 128, 5e5, True, True, True)
