@@ -14,12 +14,13 @@
 //     (rolling into the next stage), the next stage's weight nibbles + their unpacking, and its share of the DMA for
 //     the stage five ahead - pinned in that order with sched_barrier so the matrix pipe never waits at a stage edge.
 //   * LDS images are bank-conflict free by construction: the DMA writes lane-linear, so the permutation is applied to
-//     the per-lane SOURCE address (activations: 16-byte chunk ^ ((row>>2)&3); weights: [tile][chunk e][k32 ^ tile][c]).
+//     the per-lane SOURCE address (activations: 16-byte chunk ^ ((-(row>>2))&3); weights: [tile][chunk e][k32 ^ tile][c]).
 //   * per-group: level-2 dequant in registers exactly as in the decode kernels (bit-faithful to the reference).
 #include "common.h"
 #include <type_traits>
 
 int g_tiled_dbg = 0;   // qs_set_gemm_variant(3100 + bits): 1 no MFMA, 2 no DMA, 4 no operand reads, 8 no barrier
+int g_tiled_flags = 0; // qs_set_gemm_variant(3200 + bits): A/B switches, results unchanged: 1 = round-1 chunk swizzle of the activation image
 namespace {
 
 constexpr int NS = 6;                      // LDS ring depth (stages of 64 k)
@@ -79,14 +80,14 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
                                                           const __half* __restrict__ ascales,
                                                           const __half* __restrict__ wszs,
                                                           const __half* __restrict__ assums, void* __restrict__ out,
-                                                          int M, int N, int K, int nbm) {
+                                                          int M, int N, int K, int nbm, int flags) {
     constexpr int BM = 32 * MT;                       // tokens per workgroup
     constexpr int ASTAGE = BM * 64;                   // activation bytes per stage
     constexpr int NA = ASTAGE / 8192;                 // 8 KiB all-thread DMA instructions for the activation image
     constexpr int NDMA = NA + 1 + (MODE == 1 ? 1 : 0);
     static_assert(NDMA <= MT && MT % PD == 0, "pipeline slots");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* const a_ring = smem;                     // [NS][ASTAGE]  rows of 64 B, chunk position p holds chunk p^((r>>2)&3)
+    uint8_t* const a_ring = smem;                     // [NS][ASTAGE]  rows of 64 B, chunk position p holds chunk p ^ aswz(r>>2)
     uint8_t* const w_ring = smem + NS * ASTAGE;       // [NS][unit 4][tile 2][e 4][k32^tile 2][c 8][16 B]
     uint8_t* const m_ring = w_ring + NS * WSTAGE;     // [NS][512]: 256 scales | 256 zeros (storage order)
 
@@ -102,6 +103,9 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     const int KT = K >> 5;
     const int nh = K >> 6;                            // stages
 
+    // chunk swizzle of the activation image (see gemm_w4a8_ring.hip): position = chunk ^ ((-(row >> 2)) & 3) is free of
+    // bank conflicts for the lane groups of ds_read_b128; chunk ^ (row >> 2) (round 1) was two-way conflicted
+    auto aswz = [&](int j) { return (flags & 1) ? j : ((0 - j) & 3); };
     // ---- DMA sources: per-lane 32-bit byte offsets; the stage advance (64 k) goes into the scalar base ---------------
     // (inline asm rather than __builtin_amdgcn_global_load_lds: the compiler books the builtin as a FLAT access and
     // from then on degrades every counted LDS wait in the loop to lgkmcnt(0))
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
         const int r = (i * 8 + wave) * 16 + (lane >> 2);          // row this lane copies in instruction i
         int row = m0 + r;
         row = row < M ? row : M - 1;
-        a_off[i] = (u32)row * (u32)K + (((lane & 3) ^ ((r >> 2) & 3)) * 16);
+        a_off[i] = (u32)row * (u32)K + (((lane & 3) ^ aswz((r >> 2) & 3)) * 16);
     }
     u32 w_off;
     {
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     // ---- LDS operand readers ----------------------------------------------------------------------------------------
     const int w_rd = wn * 2048 + tsel * 1024 + (((g >> 1) ^ tsel)) * 128 + c * 16 + (g & 1) * 8;   // + e*256
     const int m_rd = wn * 64 + (tsel * 8 + c) * 4;
-    const int a_rd = (wm * 16 * MT + li) * 64 + ((g ^ ((li >> 2) & 3)) * 16);                      // + mt*1024
+    const int a_rd = (wm * 16 * MT + li) * 64 + ((g ^ aswz((li >> 2) & 3)) * 16);                  // + mt*1024
     auto read_b = [&](int slot, int mt) -> v4i {
         return *reinterpret_cast<const v4i*>(a_ring + slot * ASTAGE + a_rd + mt * 1024);
     };
@@ -354,7 +358,7 @@ int launch_tiled(const int8_t* A, const uint8_t* W, const int8_t* zeros, const i
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, A, W, zeros, scales8,
                        reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
                        reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K,
-                       nbm);
+                       nbm, g_tiled_flags);
     return qs_launch_status("w4a8 gemm (tiled)");
 }
 
