@@ -8,22 +8,24 @@
 //   * workgroup = 8 wave64 (512 threads) computes 256 tokens x 256 channels; wave (wm, wn) owns 128 tokens x one
 //     64-channel unit: 8 m-tiles x 4 row classes of v_mfma_i32_16x16x64_i8 accumulators (128 VGPRs).
 //   * pipeline stage = 64 k ("half-step", one MFMA k-slice): 16 KiB of activations + 8 KiB of packed weights (+512 B of
-//     per-group scales) in a 6-deep LDS ring filled by global_load_lds.  One raw s_barrier per stage; counted
-//     s_waitcnt vmcnt keeps four stages (~97 KiB per CU) in flight across it.
+//     per-group scales) in LDS rings filled by global_load_lds: the weights in a 6-deep ring of stages, the activations
+//     in a 3-deep ring of stage PAIRS - one DMA instruction copies 8 token rows x 128 B, i.e. whole 128-byte lines
+//     (a 64-k stage on its own is half a line per row: every line would be requested twice from L2, and with all 256
+//     CUs doing so the L2s deliver 12.5 TB/s instead of 25-29 TB/s - scripts/microbench_cufill.hip).  One raw
+//     s_barrier per stage; counted s_waitcnt vmcnt keeps four stages (~97 KiB per CU) in flight across it.
 //   * inside a stage every wave runs 32 MFMAs; between them it issues the LDS reads of operands needed 3 m-tiles ahead
 //     (rolling into the next stage), the next stage's weight nibbles + their unpacking, and its share of the DMA for
 //     the stage five ahead - pinned in that order with sched_barrier so the matrix pipe never waits at a stage edge.
 //   * LDS images are bank-conflict free by construction: the DMA writes lane-linear, so the permutation is applied to
-//     the per-lane SOURCE address (activations: 16-byte chunk ^ ((-(row>>2))&3); weights: [tile][chunk e][k32 ^ tile][c]).
+//     the per-lane SOURCE address (activations: see "pair image" below; weights: [tile][chunk e][k32 ^ tile][c]).
 //   * per-group: level-2 dequant in registers exactly as in the decode kernels (bit-faithful to the reference).
 #include "common.h"
 #include <type_traits>
 
 int g_tiled_dbg = 0;   // qs_set_gemm_variant(3100 + bits): 1 no MFMA, 2 no DMA, 4 no operand reads, 8 no barrier
-int g_tiled_flags = 0; // qs_set_gemm_variant(3200 + bits): A/B switches, results unchanged: 1 = round-1 chunk swizzle of the activation image
 namespace {
 
-constexpr int NS = 6;                      // LDS ring depth (stages of 64 k)
+constexpr int NS = 6;                      // weight ring depth (stages of 64 k); the activation ring holds NS/2 stage pairs
 constexpr int PD = 4;                      // operand LDS reads run this many m-tiles ahead of the MFMAs
 constexpr int BN = 256;                    // channels per workgroup (4 units)
 constexpr int WSTAGE = BN * 32;            // packed weight bytes per stage = 8 KiB
@@ -64,6 +66,16 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// counted wait with a run-time count (pipeline fill and drain only; the steady state uses constants)
+__device__ __forceinline__ void wait_vm_dyn(int n) {
+    switch (n) {
+#define QS_W(N) case N: wait_vm<N>(); break
+        QS_W(1); QS_W(2); QS_W(3); QS_W(4); QS_W(5); QS_W(6); QS_W(7); QS_W(8); QS_W(9); QS_W(10); QS_W(11); QS_W(12);
+        QS_W(13); QS_W(14); QS_W(15); QS_W(16);
+#undef QS_W
+    default: wait_vm<0>(); break;
+    }
+}
 __device__ __forceinline__ void raw_barrier() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -80,15 +92,15 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
                                                           const __half* __restrict__ ascales,
                                                           const __half* __restrict__ wszs,
                                                           const __half* __restrict__ assums, void* __restrict__ out,
-                                                          int M, int N, int K, int nbm, int flags) {
+                                                          int M, int N, int K, int nbm) {
     constexpr int BM = 32 * MT;                       // tokens per workgroup
-    constexpr int ASTAGE = BM * 64;                   // activation bytes per stage
-    constexpr int NA = ASTAGE / 8192;                 // 8 KiB all-thread DMA instructions for the activation image
-    constexpr int NDMA = NA + 1 + (MODE == 1 ? 1 : 0);
-    static_assert(NDMA <= MT && MT % PD == 0, "pipeline slots");
+    constexpr int APAIR = BM * 128;                   // activation bytes per stage pair (128 k)
+    constexpr int NA2 = APAIR / 8192;                 // 8 KiB all-thread DMA instructions per activation pair
+    constexpr int NW = 1 + (MODE == 1 ? 1 : 0);       // DMA instructions per stage for the weights (+ per-group meta)
+    static_assert(NA2 + NW <= MT && MT % PD == 0 && NS % 2 == 0, "pipeline slots");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* const a_ring = smem;                     // [NS][ASTAGE]  rows of 64 B, chunk position p holds chunk p ^ aswz(r>>2)
-    uint8_t* const w_ring = smem + NS * ASTAGE;       // [NS][unit 4][tile 2][e 4][k32^tile 2][c 8][16 B]
+    uint8_t* const a_ring = smem;                     // [NS/2][APAIR]  pair image, see below
+    uint8_t* const w_ring = smem + (NS / 2) * APAIR;  // [NS][unit 4][tile 2][e 4][k32^tile 2][c 8][16 B]
     uint8_t* const m_ring = w_ring + NS * WSTAGE;     // [NS][512]: 256 scales | 256 zeros (storage order)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -101,21 +113,29 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     const int bm = blockIdx.x % nbm, bn = blockIdx.x / nbm;
     const int m0 = bm * BM, n0 = bn * BN;
     const int KT = K >> 5;
-    const int nh = K >> 6;                            // stages
+    const int nh = K >> 6;                            // stages (even: K % 128 == 0)
 
-    // chunk swizzle of the activation image (see gemm_w4a8_ring.hip): position = chunk ^ ((-(row >> 2)) & 3) is free of
-    // bank conflicts for the lane groups of ds_read_b128; chunk ^ (row >> 2) (round 1) was two-way conflicted
-    auto aswz = [&](int j) { return (flags & 1) ? j : ((0 - j) & 3); };
-    // ---- DMA sources: per-lane 32-bit byte offsets; the stage advance (64 k) goes into the scalar base ---------------
+    // ---- activation pair image --------------------------------------------------------------------------------------
+    // One DMA instruction fills a 1 KiB piece = 8 token rows x 128 B (two stages).  Inside the piece the 16 half rows of
+    // 64 B are placed so that (i) every 16 consecutive lanes fetch two whole 128-byte lines, and (ii) the readers of ONE
+    // stage (half h) - lane (li, g) wants 16 B of token row li, k-chunk g - never meet on a bank: half h of row 2a + b
+    // sits at 64-byte position 4a + 2(h ^ (a & 1)) + b, so for a fixed h the position mod 4 (= the bank quarter) is a
+    // function of li & 3 that takes all four values; the four rows li, li+4, li+8, li+12 that share a quarter hold
+    // chunk c at 16-byte position c ^ ((-(li >> 2)) & 3), which is distinct inside each of ds_read_b128's lane groups
+    // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS; measured conflict-free).
+    auto aswz = [&](int j) { return (0 - j) & 3; };
+    // ---- DMA sources: per-lane 32-bit byte offsets; the k advance goes into the scalar base --------------------------
     // (inline asm rather than __builtin_amdgcn_global_load_lds: the compiler books the builtin as a FLAT access and
     // from then on degrades every counted LDS wait in the loop to lgkmcnt(0))
-    u32 a_off[NA];
+    u32 a_off[NA2];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int r = (i * 8 + wave) * 16 + (lane >> 2);          // row this lane copies in instruction i
+    for (int i = 0; i < NA2; ++i) {
+        const int P = lane >> 2, pa = P >> 2, q = P & 3;
+        const int half = (q >> 1) ^ (pa & 1);
+        const int r = (i * 8 + wave) * 8 + 2 * pa + (q & 1);      // tile row this lane copies in instruction i
         int row = m0 + r;
         row = row < M ? row : M - 1;
-        a_off[i] = (u32)row * (u32)K + (((lane & 3) ^ aswz((r >> 2) & 3)) * 16);
+        a_off[i] = (u32)row * (u32)K + half * 64 + (((lane & 3) ^ aswz((r >> 2) & 3)) * 16);
     }
     u32 w_off;
     {
@@ -135,21 +155,32 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
                      : "memory");
     };
-    auto issue_piece = [&](int u, int slot, int p) {
-        if (p < NA)
-            dma16(a_off[p], A + (size_t)u * 64, lds0 + slot * ASTAGE + (p * 8 + wave) * 1024);
-        else if (p == NA)
-            dma16(w_off, W + (size_t)u * 1024, lds0 + NS * ASTAGE + slot * WSTAGE + wave * 1024);
-        else if (MODE == 1)
-            dma4(m_off, m_base + (size_t)(u >> 1) * N, lds0 + NS * (ASTAGE + WSTAGE) + slot * 512 + (wave & 1) * 256);
+    auto issue_a = [&](int pr, int pslot, int i) {                 // instruction i of activation pair pr (stages 2pr, 2pr+1)
+        dma16(a_off[i], A + (size_t)pr * 128, lds0 + pslot * APAIR + (i * 8 + wave) * 1024);
+    };
+    auto issue_w = [&](int u, int slot, int i) {                   // i = 0: weights of stage u, 1: its per-group meta
+        if (i == 0) dma16(w_off, W + (size_t)u * 1024, lds0 + (NS / 2) * APAIR + slot * WSTAGE + wave * 1024);
+        else dma4(m_off, m_base + (size_t)(u >> 1) * N, lds0 + (NS / 2) * APAIR + NS * WSTAGE + slot * 512 + (wave & 1) * 256);
+    };
+    // Issue order of a wave (vmcnt retires in order): W(0), then for q = 0, 1, ...: A(q), W(2q+1), W(2q+2).  The
+    // prologue issues W(0..4), A(0), A(1); stage u issues W(u+5) and, when u is even, A(u/2 + 2) before it.  Stage v
+    // reads its own and ALREADY stage v+1's operands (rolling prefetch), so before stage v the wave needs everything up
+    // to W(v+1) (v even; A(v/2) precedes it) or up to A((v+1)/2) (v odd; W(v+1) precedes it) complete; whatever was
+    // issued later may stay in flight.  Steady state: 3 NW + NA2 instructions.
+    auto allowed = [&](int v) {
+        const int nw = v + 5 < nh ? v + 5 : nh, na = 2 + ((v + 1) >> 1) < (nh >> 1) ? 2 + ((v + 1) >> 1) : (nh >> 1);
+        const int q = v >> 1;
+        const int need = (v & 1) ? NW + (q + 1) * (NA2 + 2 * NW) + NA2 : 2 * NW + q * (NA2 + 2 * NW) + NA2;
+        return NW * nw + NA2 * na - need;          // <= 0 at the end of K: everything has to be there
     };
 
     // ---- LDS operand readers ----------------------------------------------------------------------------------------
     const int w_rd = wn * 2048 + tsel * 1024 + (((g >> 1) ^ tsel)) * 128 + c * 16 + (g & 1) * 8;   // + e*256
     const int m_rd = wn * 64 + (tsel * 8 + c) * 4;
-    const int a_rd = (wm * 16 * MT + li) * 64 + ((g ^ aswz((li >> 2) & 3)) * 16);                  // + mt*1024
-    auto read_b = [&](int slot, int mt) -> v4i {
-        return *reinterpret_cast<const v4i*>(a_ring + slot * ASTAGE + a_rd + mt * 1024);
+    const int a_rd0 = (2 * wm * MT + (li >> 3)) * 1024 + (4 * ((li & 7) >> 1) + 2 * ((li >> 1) & 1) + (li & 1)) * 64 +
+                      ((g ^ aswz(li >> 2)) * 16);                                                  // half 0; + mt*2048
+    auto read_b = [&](int pslot, int half, int mt) -> v4i {
+        return *reinterpret_cast<const v4i*>(a_ring + pslot * APAIR + (a_rd0 ^ (half * 128)) + mt * 2048);
     };
     struct Raw {
         v2u r[4];
@@ -188,43 +219,57 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
 #pragma unroll
         for (int cl = 0; cl < 4; ++cl) acc[mt][cl] = (v4i){0, 0, 0, 0};
 
-    // ---- prologue: stages 0..NS-2 in flight, operands of stage 0 in registers ---------------------------------------
+    // ---- prologue: weights of stages 0..NS-2 and two activation pairs in flight, operands of stage 0 in registers ----
+    if (!(DBG & 2)) {
 #pragma unroll
-    for (int j = 0; j < NS - 1; ++j)
-        if (j < nh) {
+        for (int i = 0; i < NW; ++i) issue_w(0, 0, i);
 #pragma unroll
-            for (int p = 0; p < NDMA; ++p) issue_piece(j, j, p);
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int i = 0; i < NA2; ++i) issue_a(q, q, i);
+#pragma unroll
+            for (int t = 1; t <= 2; ++t)
+                if (2 * q + t < nh) {
+#pragma unroll
+                    for (int i = 0; i < NW; ++i) issue_w(2 * q + t, 2 * q + t, i);
+                }
         }
-    if (nh >= NS - 1) wait_vm<(NS - 2) * NDMA>();
-    else wait_vm<0>();
+    }
+    wait_vm_dyn((DBG & 2) ? 0 : allowed(0));
     raw_barrier();
     v4i a0[4], a1[4], bq[PD];
     {
         const Raw q0 = read_w(0);
 #pragma unroll
-        for (int t = 0; t < PD; ++t) bq[t] = read_b(0, t);
+        for (int t = 0; t < PD; ++t) bq[t] = read_b(0, 0, t);
 #pragma unroll
         for (int cl = 0; cl < 4; ++cl) a0[cl] = build(q0, cl);
     }
 
     // One stage = 4*MT MFMAs of this wave.  `ac` holds the unpacked weight operands of stage u, `an` receives those of
-    // stage u+1; bq is the rolling activation-operand buffer (tile t lives in bq[t % PD], PD divides MT).
-    auto stage = [&](auto pref_static, bool pref_rt, int u, int slot, v4i(&ac)[4], v4i(&an)[4]) {
+    // stage u+1; bq is the rolling activation-operand buffer (tile t lives in bq[t % PD], PD divides MT).  PAR = u & 1.
+    auto stage = [&](auto par_c, auto pref_static, bool pref_a, bool pref_w, int u, int slot, v4i(&ac)[4], v4i(&an)[4]) {
+        constexpr int PAR = decltype(par_c)::value;
         const int slot_n = slot + 1 == NS ? 0 : slot + 1;
         const int slot_d = slot == 0 ? NS - 1 : slot - 1;          // (u + NS - 1) % NS
+        const int ps = slot >> 1, ps_n = slot_n >> 1;              // activation pair slots of stage u / u+1
+        const int ps_d = ps == 0 ? NS / 2 - 1 : ps - 1;            // (u/2 + 2) % (NS/2)
         Raw qn;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const v4i b_use = bq[mt % PD];
             if (!(DBG & 4)) {
-                if (mt + PD < MT) bq[mt % PD] = read_b(slot, mt + PD);
-                else bq[mt % PD] = read_b(slot_n, mt + PD - MT);
+                if (mt + PD < MT) bq[mt % PD] = read_b(ps, PAR, mt + PD);
+                else bq[mt % PD] = read_b(ps_n, PAR ^ 1, mt + PD - MT);
             }
             if (mt == 0) qn = read_w(slot_n);
-            if (mt < NDMA) {
-                if (DBG & 2) {
-                } else if (decltype(pref_static)::value) issue_piece(u + NS - 1, slot_d, mt);
-                else if (pref_rt) issue_piece(u + NS - 1, slot_d, mt);
+            if (!(DBG & 2)) {
+                constexpr bool st = decltype(pref_static)::value;
+                if (PAR == 0 && mt < NA2) {
+                    if (st || pref_a) issue_a((u >> 1) + 2, ps_d, mt);
+                } else if (mt - (PAR == 0 ? NA2 : 0) < NW) {
+                    if (st || pref_w) issue_w(u + NS - 1, slot_d, mt - (PAR == 0 ? NA2 : 0));
+                }
             }
             if (MT == 8 && mt >= 2 && mt < 6) an[mt - 2] = build(qn, mt - 2);
             if (MT == 4 && mt >= 2) {
@@ -242,32 +287,29 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     };
     // barrier(u): stage u+1 has landed (this wave's pieces by the counted wait; the barrier extends that to every
     // wave's) while later stages stay in flight, and every wave is done reading stage u-1, whose slot is refilled next
-    auto tail_wait = [&](int u) {
-        const int rem = nh - 1 - u;
-        if (rem >= NS - 2) wait_vm<(NS - 3) * NDMA>();
-        else if (rem == 3) wait_vm<2 * NDMA>();
-        else if (rem == 2) wait_vm<1 * NDMA>();
-        else wait_vm<0>();
-    };
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
     int u = 0, slot = 0;
     for (; u + NS < nh; u += 2) {                      // steady state: both stages of the pair prefetch, no branches
-        wait_vm<(DBG & 2) ? 0 : (NS - 3) * NDMA>();
-        if (!(DBG & 8)) raw_barrier();
-        stage(std::true_type{}, true, u, slot, a0, a1);
+        if (u) wait_vm<(DBG & 2) ? 0 : 3 * NW + NA2>();            // (u = 0: the prologue's wait and barrier)
+        if (u && !(DBG & 8)) raw_barrier();
+        stage(c0{}, std::true_type{}, true, true, u, slot, a0, a1);
         slot = slot + 1 == NS ? 0 : slot + 1;
-        wait_vm<(DBG & 2) ? 0 : (NS - 3) * NDMA>();
+        wait_vm<(DBG & 2) ? 0 : 3 * NW + NA2>();
         if (!(DBG & 8)) raw_barrier();
-        stage(std::true_type{}, true, u + 1, slot, a1, a0);
+        stage(c1{}, std::true_type{}, true, true, u + 1, slot, a1, a0);
         slot = slot + 1 == NS ? 0 : slot + 1;
     }
     for (; u < nh; u += 2) {                           // drain
-        tail_wait(u);
-        raw_barrier();
-        stage(std::false_type{}, u + NS - 1 < nh, u, slot, a0, a1);
+        if (u) {
+            wait_vm_dyn((DBG & 2) ? 0 : allowed(u));
+            raw_barrier();
+        }
+        stage(c0{}, std::false_type{}, u + 4 < nh, u + NS - 1 < nh, u, slot, a0, a1);
         slot = slot + 1 == NS ? 0 : slot + 1;
-        tail_wait(u + 1);
+        wait_vm_dyn((DBG & 2) ? 0 : allowed(u + 1));
         raw_barrier();
-        stage(std::false_type{}, u + NS < nh, u + 1, slot, a1, a0);
+        stage(c1{}, std::false_type{}, false, u + NS < nh, u + 1, slot, a1, a0);
         slot = slot + 1 == NS ? 0 : slot + 1;
     }
 
@@ -358,7 +400,7 @@ int launch_tiled(const int8_t* A, const uint8_t* W, const int8_t* zeros, const i
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, A, W, zeros, scales8,
                        reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
                        reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K,
-                       nbm, g_tiled_flags);
+                       nbm);
     return qs_launch_status("w4a8 gemm (tiled)");
 }
 
