@@ -35,14 +35,18 @@ n = B * Hkv * 8 * 16
 out = torch.zeros((n,), dtype=torch.int64, device=dev)
 assert lib.qs_debug_copy_split_workspace(out.data_ptr(), n * 8) == 0
 st = out.cpu().numpy().reshape(B * Hkv, 8, 16).astype(np.float64)
-t0 = st[:, :, 0].min()
-st = np.where(st > 0, st - t0, np.nan)
+st = np.where(st > 0, st, np.nan)
+wg0 = np.nanmin(st[:, :, 0], axis=1)                  # every workgroup's own first entry
+skew = wg0 - np.nanmin(wg0)
+rel = st - wg0[:, None, None]
 names = ["entry", "tl", "dma issued", "phaseA in", "phaseA done", "K0 in", "pg0 done", "K1 in", "pg1 done", "K2 in", "pg2 done", "", "loop done", "sync1", "merged", "end"]
-print(f"L={L} VAR={VAR}: stamps in s_memtime ticks relative to the first wave's entry (mean / min / max over all waves)")
+print(f"L={L} VAR={VAR}: s_memtime ticks (shader cycles) since the workgroup's first wave entered; mean / min / max over workgroups x waves")
 for i, nm in enumerate(names):
     if not nm: continue
-    x = st[:, :, i]
+    x = rel[:, :, i]
     if np.all(np.isnan(x)): continue
-    print(f"  {i:2d} {nm:12s} mean {np.nanmean(x):9.0f}  min {np.nanmin(x):9.0f}  max {np.nanmax(x):9.0f}   wave0 mean {np.nanmean(st[:, 0, i]):9.0f}  wave7 mean {np.nanmean(st[:, 7, i]):9.0f}")
-print("  per-workgroup end: mean", np.nanmean(np.nanmax(st[:, :, 15], axis=1)), "max", np.nanmax(st[:, :, 15]))
+    print(f"  {i:2d} {nm:12s} mean {np.nanmean(x):7.0f}  min {np.nanmin(x):7.0f}  max {np.nanmax(x):7.0f}   wave0 {np.nanmean(rel[:, 0, i]):7.0f}  wave3 {np.nanmean(rel[:, 3, i]):7.0f}  wave7 {np.nanmean(rel[:, 7, i]):7.0f}")
+end = np.nanmax(rel[:, :, 15], axis=1)
+print(f"  workgroup lifetime: mean {end.mean():.0f}  min {end.min():.0f}  max {end.max():.0f};  start skew: mean {skew.mean():.0f}  max {skew.max():.0f};  "
+      f"last end since first entry: {np.nanmax(st[:, :, 15]) - np.nanmin(wg0):.0f}")
 lib.qs_set_attention_variant(0)
