@@ -179,6 +179,9 @@ int qs_rms_norm(void* out, const void* input, const void* weight, float epsilon,
 int qs_silu_and_mul(void* out, const void* input, int num_tokens, int d, qs_stream_t stream);
 /* fp16 residual add (the reference does this with a torch add, llama_w4a8_unpad.py:348,360): a += b */
 int qs_residual_add(void* a, const void* b, int64_t numel, qs_stream_t stream);
+/* greedy sampling helper (the reference's sampler is torch: argmax over the fp16 logits, layers/sampler.py): out[r] = index
+ * of the first maximum of row r of x (fp16 [rows, n], row stride in elements, 16-byte aligned rows; NaN-free). */
+int qs_argmax_rows(const void* x, int64_t* out, int rows, int n, int64_t row_stride, qs_stream_t stream);
 
 /* Pair fusions for the decode loop (no reference counterpart; each is BIT-IDENTICAL to the two calls it replaces and
  * exists because at decode batch sizes every one of these row kernels is a fixed ~5 us latency chain):

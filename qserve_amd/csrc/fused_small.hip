@@ -434,6 +434,82 @@ extern "C" int qs_residual_add(void* a, const void* b, int64_t numel, qs_stream_
     return qs_launch_status("residual_add");
 }
 
+/* ---- greedy sampling helper: row-wise argmax of fp16 logits (first maximum wins; NaN-free input) -------------------- */
+namespace {
+__device__ __forceinline__ void argmax_pick(float& bv, int& bi, float v, int i) {
+    if (v > bv || (v == bv && i < bi)) {
+        bv = v;
+        bi = i;
+    }
+}
+// one workgroup of 1024 threads per row; every thread requests all its 16-byte chunks before looking at any
+template <int MAXC>
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const _Float16* __restrict__ x, int64_t* __restrict__ out,
+                                                            int n, int64_t row_stride) {
+    const _Float16* row = x + (size_t)blockIdx.x * row_stride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nchunk = n >> 3;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c0 = 0; c0 < nchunk; c0 += MAXC * 1024) {       // one trip up to MAXC * 8192 columns
+        h8 v[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = c0 + tid + c * 1024;
+            if (ch < nchunk) v[c] = load8(row + (size_t)ch * 8);
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = c0 + tid + c * 1024;
+            if (ch < nchunk) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) argmax_pick(bv, bi, (float)v[c][e], ch * 8 + e);
+            }
+        }
+    }
+    for (int i = (nchunk << 3) + tid; i < n; i += 1024) argmax_pick(bv, bi, (float)row[i], i);   // n % 8 tail
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = __shfl_xor(bv, m, 64);
+        const int oi = __shfl_xor(bi, m, 64);
+        argmax_pick(bv, bi, ov, oi);
+    }
+    __shared__ float s_v[16];
+    __shared__ int s_i[16];
+    if (lane == 0) {
+        s_v[wave] = bv;
+        s_i[wave] = bi;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        bv = lane < 16 ? s_v[lane] : -INFINITY;
+        bi = lane < 16 ? s_i[lane] : 0x7fffffff;
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
+            const float ov = __shfl_xor(bv, m, 64);
+            const int oi = __shfl_xor(bi, m, 64);
+            argmax_pick(bv, bi, ov, oi);
+        }
+        if (lane == 0) out[blockIdx.x] = bi == 0x7fffffff ? 0 : bi;
+    }
+}
+}  // namespace
+
+extern "C" int qs_argmax_rows(const void* x, int64_t* out, int rows, int n, int64_t row_stride, qs_stream_t stream) {
+    QS_REQUIRE(x && out, "argmax_rows: null pointer");
+    QS_REQUIRE(n > 0 && row_stride >= n && row_stride % 8 == 0, "argmax_rows: n=%d, row stride %lld (must be >= n, multiple of 8)", n,
+               (long long)row_stride);
+    if (rows <= 0) return QS_OK;
+    const int chunks = ((n >> 3) + 1023) / 1024;
+    auto launch = [&](auto k) {
+        hipLaunchKernelGGL(k, dim3(rows), dim3(1024), 0, (hipStream_t)stream, (const _Float16*)x, out, n, row_stride);
+    };
+    if (chunks <= 4) launch(argmax_rows_kernel<4>);
+    else if (chunks <= 8) launch(argmax_rows_kernel<8>);
+    else launch(argmax_rows_kernel<16>);
+    return qs_launch_status("argmax_rows");
+}
+
 /* ---- pair fusions (bit-identical to the two ops they replace; see the kernels) ---------------------------------- */
 extern "C" int qs_add_residual_rms_norm_general(int8_t* out, void* hidden_io, const void* delta, const void* weight,
                                                 void* input_sum, void* scaling, float epsilon, int num_tokens,

@@ -34,6 +34,13 @@ def residual_add_(a, b):
     """a += b (fp16), the residual add the reference does with a torch add (llama_w4a8_unpad.py:348,360)."""
     _check(_lib.qs_residual_add(a.data_ptr(), b.data_ptr(), a.numel(), stream()), "residual_add")
 
+def argmax_rows_(logits, out):
+    """out[r] = argmax(logits[r]) (fp16 [rows, n] -> int64 [rows]); the greedy sampler of the benchmark step."""
+    assert logits.dtype == torch.float16 and logits.dim() == 2 and logits.stride(1) == 1 and out.dtype == torch.int64
+    _check(_lib.qs_argmax_rows(logits.data_ptr(), out.data_ptr(), logits.size(0), logits.size(1), logits.stride(0), stream()),
+           "argmax_rows")
+
+
 LLAMA3_8B = dict(name="Llama-3-8B", hidden=4096, heads=32, kv_heads=8, inter=14336, layers=32, vocab=128256,
                  rope_theta=5e5, eps=1e-5)
 QWEN15_72B = dict(name="Qwen1.5-72B", hidden=8192, heads=64, kv_heads=64, inter=24576, layers=80, vocab=152064,
@@ -277,7 +284,7 @@ class DecodeEngine:
         torch.index_select(h, 0, last, out=self.hidden)
         layernorm_ops.rms_norm(self.final, self.hidden, self.norm_w, cfg["eps"])
         logits = torch.matmul(self.final, self.lm_head.t())
-        torch.argmax(logits, dim=-1, out=self.tokens)
+        argmax_rows_(logits, self.tokens)
         self.lengths.fill_(prompt_len + 1)
 
     # ---- one decode step (llama_w4a8_unpad.py:330-361 per layer) --------------------------------------------
@@ -355,7 +362,7 @@ class DecodeEngine:
         layernorm_ops.rms_norm(self.final, h, self.norm_w, cfg["eps"])
         if self.with_lm_head:
             logits = torch.matmul(self.final, self.lm_head.t())      # un-quantised fp16 lm_head (:392,476)
-            torch.argmax(logits, dim=-1, out=self.tokens)            # greedy sampler
+            argmax_rows_(logits, self.tokens)                        # greedy sampler
         self.lengths.add_(1)
 
 

@@ -137,6 +137,13 @@ def qs_residual_add(a, b, numel, stream):
     return 0
 
 
+def qs_argmax_rows(x, out, rows, n, row_stride, stream):
+    CALLS.append(("qs_argmax_rows", rows, n))
+    logits = _strided_rows(x, rows, row_stride, n, np.float16)
+    _arr(out, (rows,), np.int64)[:] = np.argmax(logits.astype(np.float32), axis=1)   # first maximum, like the kernel
+    return 0
+
+
 def qs_add_residual_rms_norm_general(out, hidden_io, delta, weight, input_sum, scaling, eps, T, hidden, stream):
     qs_residual_add(hidden_io, delta, T * hidden, stream)
     return qs_rms_norm_general(out, hidden_io, weight, input_sum, scaling, eps, T, hidden, stream)
@@ -221,7 +228,7 @@ def qs_flash_attn_varlen_fwd(q, k, v, out, cu_q, cu_k, batch, H, Hkv, head_dim, 
 
 SYMBOLS = {f.__name__: f for f in (
     qs_w4a8_per_chn_gemm, qs_w4a8_per_group_gemm, qs_invoke_quant, qs_rms_norm_general, qs_rms_norm, qs_silu_and_mul,
-    qs_residual_add, qs_add_residual_rms_norm_general, qs_silu_and_mul_quant, qs_compute_padding_offsets,
+    qs_residual_add, qs_argmax_rows, qs_add_residual_rms_norm_general, qs_silu_and_mul_quant, qs_compute_padding_offsets,
     qs_apply_bias_rope_update_kv_cache, qs_single_query_attention, qs_single_query_attention_quant,
     qs_flash_attn_varlen_fwd)}
 

@@ -261,3 +261,23 @@ def test_wave_reductions_round_like_the_shuffle_butterfly(gpu):
     assert torch.equal(o[:, 2], o[:, 3]), "wave_max differs from the shuffle butterfly"
     assert torch.allclose(out[:, 0], x.view(-1, 64).double().sum(1).float(), rtol=1e-4, atol=1e-3)
     assert torch.equal(out[:, 2], x.view(-1, 64).max(1).values)
+
+
+# ---- greedy sampling helper ------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,n,pad", [(1, 8, 0), (3, 1000, 0), (64, 128256, 0), (5, 152064, 0), (7, 4099, 5), (2, 300000, 0)])
+def test_argmax_rows_is_first_maximum(gpu, rows, n, pad):
+    """qs_argmax_rows against numpy's argmax (first maximum), incl. ties, a strided view, n % 8 != 0 and vocabularies
+    larger than one pass."""
+    from qserve_amd.decode import argmax_rows_
+    r = np.random.default_rng(rows * 31 + n)
+    stride = (n + pad + 7) // 8 * 8
+    x = (r.standard_normal((rows, stride)) * 4).astype(np.float16)
+    x[:, n:] = 100.0                                        # beyond the row: must never win
+    if n >= 8:
+        x[0, [n - 1, n // 2, 3]] = 50.0                      # ties: the first one counts
+    xd = dev(x)
+    out = torch.full((rows,), -7, dtype=torch.int64, device=gpu)
+    argmax_rows_(xd[:, :n], out)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), np.argmax(x[:, :n].astype(np.float32), axis=1))
