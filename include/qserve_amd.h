@@ -86,8 +86,8 @@ int qs_w8a8_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscal
  *   3000 ... tiled (prefill) kernel off, 3001 / 3002 ... forced with the 256- / 128-token tile;
  *   4000 ... ring (decode) kernel off, 4001 ... ring kernel without K slices,
  *   4100 + 100*(k_slices-1) + 10*m_tiles + units ... forced ring geometry;
- *   5000 + bits ... A/B switches of the ring kernel (1: weight DMA without the non-temporal hint); sticky until reset
- *                   with 5000;
+ *   5000 + bits ... A/B switches of the ring kernel (1: weight DMA without the non-temporal hint; 256 * d: ring depth d;
+ *                   32 / 64: TIMING ONLY, wrong results - no MFMA / no operand reads); sticky until reset with 5000;
  *   3100 + bits ... TIMING EXPERIMENTS ONLY (kernel parts switched off, results are wrong by design). */
 void qs_set_gemm_variant(int variant);
 

@@ -592,7 +592,7 @@ extern "C" void qs_set_gemm_variant(int variant) {
         g_tiled_dbg = variant - 3100;
         return;
     }
-    if (variant >= 5000 && variant < 5100) {
+    if (variant >= 5000 && variant < 7000) {
         g_ring_flags = variant - 5000;
         return;
     }

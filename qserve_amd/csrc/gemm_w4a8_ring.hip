@@ -25,7 +25,10 @@
 
 // A/B switches (qs_set_gemm_variant(5000 + bits); every setting computes the same results):
 //   1 = weight DMA with the default cache policy instead of non-temporal
-//   16 * d = ring depth d (3..6, if 160 KiB allow): sensitivity to the bytes in flight
+//   32 / 64 = timing only, WRONG RESULTS: no MFMA / no LDS operand reads (what is left is the DMA + barrier pipeline:
+//        gate_up at M = 64 17.5 us -> 16.3 / 16.8, both off 15.9 us = 4.2 us of head and tail + 512 KB per CU at 44 GB/s,
+//        the rate scripts/microbench_cufill.hip measures for this L2 + HBM mix with nothing else going on)
+//   256 * d = ring depth d (3..6, if 160 KiB allow): sensitivity to the bytes in flight
 int g_ring_flags = 0;
 
 namespace {
@@ -304,18 +307,23 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
     auto round = [&](int i, int slot, const Ops& cur, Ops& nxt) {
         const int slot_n = slot + 1 == ns ? 0 : slot + 1;
         const int slot_d = slot == 0 ? ns - 1 : slot - 1;
-        const Raw qn = read_raw(slot_n);
+        Raw qn;
+        if (!(flags & 64)) {
+            qn = read_raw(slot_n);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) nxt.b[mt] = read_b(slot_n, mt);
+            for (int mt = 0; mt < MT; ++mt) nxt.b[mt] = read_b(slot_n, mt);
+        }
         if (i + ns - 1 < nloc) issue(i + ns - 1, slot_d);
+        if (!(flags & 32)) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-            for (int cl = 0; cl < 4; ++cl)
-                acc[mt][cl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a[cl], cur.b[mt], acc[mt][cl], 0, 0, 0);
-            if (mt == 0) {
+                for (int cl = 0; cl < 4; ++cl)
+                    acc[mt][cl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a[cl], cur.b[mt], acc[mt][cl], 0, 0, 0);
+                if (mt == 0) {
 #pragma unroll
-                for (int cl = 0; cl < 4; ++cl) nxt.a[cl] = build(qn, cl);
+                    for (int cl = 0; cl < 4; ++cl) nxt.a[cl] = build(qn, cl);
+                }
             }
         }
     };
@@ -610,7 +618,7 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
     if (ns > 5) ns = 5;
     const int nloc = (K / 64) / ksplit / KG;
     if (ns > nloc + 1) ns = nloc + 1;
-    if (const int f = (g_ring_flags >> 4) & 7) {       // A/B: forced depth (sensitivity to the bytes in flight)
+    if (const int f = (g_ring_flags >> 8) & 7) {       // A/B: forced depth (sensitivity to the bytes in flight)
         if (f >= 3 && (size_t)KG * f * GSTAGE <= 160 * 1024 && f <= nloc + 1) ns = f;
     }
     if (ns < 3) ns = 3;                                // the slot read ahead and the slot refilled must differ
