@@ -229,7 +229,10 @@ MODEL_SHAPES = {   # one layer of the reference's other supported dense models (
 def test_other_model_shapes_run_and_fuse_identically(gpu, name, gs):
     """Every kernel of the path at the layer shapes of the other dense models the reference lists (hidden sizes 5120 /
     7168 / 8192, GQA groups 1 / 7 / 8, K not a multiple of 1024): prefill + decode steps, eager and captured, fused
-    pairs == op-by-op."""
+    pairs == op-by-op.  (Plumbing test.  The oracle comparisons for these shapes are per kernel - every GEMM of these
+    layers in tests/test_gemm_gpu.py::test_other_model_shapes_exact, the GQA group sizes in tests/test_attention_gpu.py
+    - and end to end, engine on the device against the engine on the oracle, in
+    tests/test_loader.py::test_device_engine_matches_oracle_engine.)"""
     from qserve_amd.decode import DecodeEngine
     cfg = dict(MODEL_SHAPES[name], name=name, layers=1, vocab=1024, rope_theta=1e4, eps=1e-5)
     outs = []

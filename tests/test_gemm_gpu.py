@@ -230,6 +230,53 @@ def test_tp_shard_shapes_exact(gpu, M, N, K):
     assert ulp_diff_f16(out.cpu().numpy(), out_ref).max() == 0
 
 
+# one layer of every other dense model the reference lists (qserve README model zoo): hidden / heads / kv heads / inter
+OTHER_MODELS = {"llama2-7b": (4096, 32, 32, 11008), "llama2-13b": (5120, 40, 40, 13824), "yi-34b": (7168, 56, 8, 20480),
+                "llama2-70b": (8192, 64, 8, 28672), "qwen1.5-72b": (8192, 64, 64, 24576), "mistral-7b": (4096, 32, 8, 14336)}
+OTHER_GEMMS = sorted({(n, k) for hid, H, Hkv, inter in OTHER_MODELS.values()
+                      for n, k in (((H + 2 * Hkv) * 128, hid), (hid, H * 128), (2 * inter, hid), (hid, inter))})
+
+
+@pytest.mark.parametrize("N,K", OTHER_GEMMS)
+@pytest.mark.parametrize("M,per_group", [(6, False), (64, False), (6, True)])
+def test_other_model_shapes_exact(gpu, M, N, K, per_group):
+    """Every GEMM shape of one layer of the other dense models (K = 11 008, 13 824, 20 480, 24 576, 28 672; N up to
+    57 344) through the dispatcher's own choice at decode batch sizes: INT32 accumulators exact against an independent
+    integer matmul, fp16 output bit-exact against the oracle epilogue."""
+    if per_group:
+        if K % 128:
+            pytest.skip("g128 needs K % 128 == 0")
+        import qserve_backend.qgemm_w4a8_per_group as op
+        pr = per_group_problem_torch(M, N, K, gpu, seed=N + K)
+        acc = torch.full((M, N), -7, dtype=torch.int32, device=gpu)
+        op.gemm_forward_acc(pr["A"], pr["qweight"], pr["s2_zeros"], pr["s2_scales"], acc)
+        ref = int_matmul_torch(pr["A"], pr["w8"])
+        assert torch.equal(acc.to(torch.int64), ref)
+        out = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+        op.gemm_forward_cuda(pr["A"], pr["qweight"], pr["s2_zeros"], pr["s2_scales"], pr["wscales"], pr["ascales"], out)
+        out_ref = w4a8.epilogue_per_group(ref.cpu().numpy().astype(np.int32), pr["wscales"].cpu().numpy(),
+                                          pr["ascales"].cpu().numpy())
+        assert ulp_diff_f16(out.cpu().numpy(), out_ref).max() == 0
+        return
+    import qserve_backend.qgemm_w4a8_per_chn as op
+    g = torch.Generator(device=gpu).manual_seed(N * 5 + K + M)
+    W = torch.randint(-128, 128, (N, K // 2), dtype=torch.int8, device=gpu, generator=g)
+    A = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=gpu, generator=g)
+    acc = torch.empty((M, N), dtype=torch.int32, device=gpu)
+    op.gemm_forward_acc(A, W, acc)
+    ref = int_matmul_torch(A, unpack_qweight_torch(W))
+    assert torch.equal(acc.to(torch.int64), ref)
+    r = np.random.default_rng(N + K)
+    ws = r.uniform(0.001, 0.01, N).astype(np.float16)
+    wz = r.uniform(-0.05, 0.05, N).astype(np.float16)
+    sa = r.uniform(0.005, 0.05, M).astype(np.float16)
+    ss = r.uniform(-20, 20, M).astype(np.float16)
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+    op.gemm_forward_cuda(A, W, dev(ws), dev(sa), dev(wz), dev(ss), out)
+    out_ref = w4a8.epilogue_per_chn(acc.cpu().numpy(), ws, sa, wz, ss)
+    assert ulp_diff_f16(out.cpu().numpy(), out_ref).max() == 0
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 49152, 1024), (37, 57344, 2048), (16, 65536, 1024)])
 def test_very_wide_n(gpu, M, N, K):
     """N >= 49152 (single-GPU 70 B-class gate_up; more than one round of workgroups): per-channel exact vs a device

@@ -278,3 +278,63 @@ def test_tp2_engine_over_gloo_processes(built_lib, group_size):
     mp.spawn(_gloo_worker, args=(port, group_size, ret), nprocs=2, join=True)
     assert isinstance(ret[0], list) and isinstance(ret[1], list), (ret[0], ret[1])
     assert ret[0] == ret[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("group_size,bias", [(-1, False), (128, False), (-1, True)])
+def test_device_engine_matches_oracle_engine(gpu, monkeypatch, group_size, bias):
+    """End to end, device against oracle: the same checkpoint, prompt and op sequence once through the HIP library on
+    the GPU and once through the oracle-backed host simulator (tests/_fake_abi.py) - prompt phase (GEMMs, prefill KV
+    writer, flash attention) and two decode steps.  Layer 0's cache pages must be BIT-EQUAL (integer GEMM, norm, RoPE
+    and page quantisation are exact against the oracle); deeper layers and the hidden states sit behind the attention
+    kernels' 1e-3 / 2e-3 tolerances, so they are compared by relative L2 (measured 1-4 %: a 1e-3 difference that
+    crosses an int8 / 4-bit rounding boundary is amplified by the following GEMM; an op wired to the wrong buffer gives
+    50-100 %)."""
+    import _fake_abi
+    from qserve_amd import decode as D
+    from qserve_amd import loader
+    sd = make_checkpoint(group_size, bias, seed=4)
+    B, P = 3, 70
+    tok = torch.randint(0, CFG["vocab"], (B * P,), generator=torch.Generator().manual_seed(2))
+
+    def run(device):
+        eng = D.DecodeEngine(CFG, B, P, 8, group_size=group_size, device=device, with_lm_head=True, seed=13,
+                             weights=loader.load_llama_w4a8(sd, CFG, group_size, load_norm_weights=True, device=device))
+        eng.prefill(P, tokens=tok.to(device))
+        hist = [(eng.hidden.float().cpu().clone(), eng.tokens.cpu().clone(),
+                 [[p.cpu().clone() for p in pl] for pl in eng.pools])]
+        return eng, hist
+
+    dev_eng, dev_hist = run("cuda:0")
+    first = dev_hist[0][1]
+    for _ in range(2):
+        dev_eng.step()
+        dev_hist.append((dev_eng.final.float().cpu().clone(), dev_eng.tokens.cpu().clone(), None))
+    torch.cuda.synchronize()
+
+    _fake_abi.install(monkeypatch)
+    cpu_eng, cpu_hist = run("cpu")
+    # layer 0 of the prompt phase: exact
+    for which in (0, 1):
+        assert torch.equal(dev_hist[0][2][0][which], cpu_hist[0][2][0][which]), "layer-0 cache pages differ from the oracle"
+    a, b = dev_hist[0][0], cpu_hist[0][0]
+    rel = ((a - b).norm() / b.norm()).item()
+    assert torch.isfinite(a).all() and rel < 8e-2, rel
+    # later layers' pages: their inputs already differ by the attention tolerance, so values near a 4-bit rounding
+    # boundary land on the neighbouring code (measured: 2-3 % of the bytes); a wrong page / head / token gives ~94 %
+    for li in range(1, CFG["layers"]):
+        for which in (0, 1):
+            d = dev_hist[0][2][li][which] != cpu_hist[0][2][li][which]
+            assert d.float().mean().item() < 0.10, (li, which, d.float().mean().item())
+    # decode steps from the SAME state: take the device's cache and tokens over, then compare step by step
+    for li in range(CFG["layers"]):
+        for which in (0, 1):
+            cpu_eng.pools[li][which].copy_(dev_hist[0][2][li][which])
+    cpu_eng.tokens.copy_(first)
+    cpu_eng.hidden.copy_(dev_hist[0][0].half())
+    for s in range(1, 3):
+        cpu_eng.step()
+        a, b = dev_hist[s][0], cpu_eng.final.float()
+        rel = ((a - b).norm() / b.norm()).item()
+        assert torch.isfinite(a).all() and rel < 8e-2, (s, rel)
+        cpu_eng.tokens.copy_(dev_hist[s][1])          # greedy near-ties: stay on the device's sequence
