@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--tp-full-graph", action="store_true",
                     help="N>1: capture the all-reduces into the step's hipGraph as well (default: one graph per segment "
                          "between the collectives, collectives issued eagerly - independent of capture support in RCCL)")
+    ap.add_argument("--direct-allreduce", action="store_true",
+                    help="N>1: the library's direct-access all-reduce (qs_comm_*, one kernel per collective, whole step in "
+                         "one hipGraph) instead of torch.distributed; opt-in - not measured on multi-GPU hardware")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="N>1 (tensor parallel): weak = --batch sequences PER GPU (global batch = batch x N, so every "
                          "rank keeps N=1's GEMM MACs and KV bytes); strong = --batch is the global batch")
@@ -301,9 +304,13 @@ def main():
         _lib.lib.qs_set_attention_variant(args.attn_variant)
     cfg = {"llama3-8b": D.LLAMA3_8B, "llama2-7b": D.LLAMA2_7B, "llama2-70b": D.LLAMA2_70B, "qwen1.5-72b": D.QWEN15_72B,
            "tiny": D.TINY}[args.model]
+    direct = None
+    if world > 1 and args.direct_allreduce:
+        from qserve_amd import tp as TP
+        direct = TP.DirectAllReduce(args.batch * cfg["hidden"], device=dev)
     eng = D.DecodeEngine(cfg, args.batch, args.prompt_len, args.max_new, group_size=args.group_size,
                          int4_kv=not args.kv8, device=dev, tp_rank=rank, tp_world=world,
-                         fuse_pairs=not args.op_by_op)
+                         fuse_pairs=not args.op_by_op, direct_allreduce=direct)
     # the whole cache of the generation (prompt + max_new - 1 positions) is written by the prefill writer up front, so
     # that any context of the run (start / mid / end) reads real quantised pages; `lengths` selects the context
     full_ctx = args.prompt_len + args.max_new - 1
@@ -428,6 +435,18 @@ def main():
         torch.cuda.synchronize()
         extra.update(all_reduce_us=round(e0.elapsed_time(e1) * 1e3 / 50, 2), all_reduce_bytes=buf.numel() * 2,
                      all_reduces_per_step=2 * cfg["layers"], collective_backend=f"{backend} ({world} ranks)")
+        if direct is not None:
+            for _ in range(5):
+                direct.all_reduce(buf.numel())
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(50):
+                direct.all_reduce(buf.numel())
+            e1.record()
+            torch.cuda.synchronize()
+            extra.update(direct_all_reduce_us=round(e0.elapsed_time(e1) * 1e3 / 50, 2),
+                         step_collectives="library direct-access all-reduce (qs_comm_all_reduce_f16)",
+                         direct_all_reduce_timeouts=bool(direct.error()))
 
     # ---- per-kernel timing + roofline ---------------------------------------------------------------------------------
     roof, roof_family, kernels = None, None, None
@@ -509,7 +528,8 @@ def main():
                        "global_batch": args.batch, "context_start": start_len + args.warmup,
                        "parallelism": f"tp{world}",
                        "hipgraph": ("piecewise (collectives issued eagerly between the pieces)"
-                                    if graphed and world > 1 and not args.tp_full_graph else graphed), "layers": cfg["layers"],
+                                    if graphed and world > 1 and not args.tp_full_graph and direct is None else graphed),
+                       "layers": cfg["layers"],
                        "op_sequence": "reference ops one by one" if args.op_by_op else
                        "reference ops; (residual add, layer norm) and (silu_and_mul, quant) issued as bit-identical "
                        "fused pairs (qserve_amd/fused.py)",

@@ -210,6 +210,30 @@ int qs_flash_attn_varlen_fwd(const void* q, const void* k, const void* v, void* 
                              int64_t q_stride0, int64_t k_stride0, int64_t v_stride0, int64_t o_stride0,
                              int max_seqlen_q, int max_seqlen_k, float softmax_scale, int causal, qs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Direct-access fp16 sum all-reduce for the tensor-parallel step (no reference counterpart: the reference's
+ * tensor parallelism is inert).  Every rank owns one uncached buffer pair (input | output) that all peers map through
+ * HIP IPC; one kernel per call: flag exchange, each rank reduces its slice straight out of the peers' inputs (fp32, rank
+ * order, one rounding) and writes it straight into everybody's output, flag exchange.  A kernel on the caller's stream
+ * like any other: capturable in a hipGraph.  All waits are bounded (qs_comm_error reports a timeout).  UNMEASURED on
+ * multi-GPU hardware; torch.distributed / RCCL stays the default of qserve_amd.tp.all_reduce_sum_.
+ *   qs_comm_create        allocates this rank's region (current device), returns the communicator and a 64-byte IPC handle
+ *   qs_comm_connect       handles = world x 64 bytes in rank order (gathered by the caller, e.g. all_gather_object)
+ *   qs_comm_connect_local same-process ranks: the other communicators themselves, no IPC (tests)
+ *   qs_comm_input/output  device pointers: the rank's addend is written to input (e.g. as the row-parallel GEMM's output
+ *                         buffer), the sum over all ranks is in output once qs_comm_all_reduce_f16's kernel has retired
+ *   numel % (8 * world) == 0, numel * 2 <= payload_bytes. */
+int qs_comm_create(int rank, int world, int64_t payload_bytes, void** comm_out, void* ipc_handle64);
+int qs_comm_connect(void* comm, const void* handles);
+int qs_comm_connect_local(void* comm, void* const* peer_comms);
+void* qs_comm_input(void* comm);
+void* qs_comm_output(void* comm);
+int qs_comm_all_reduce_f16(void* comm, int64_t numel, qs_stream_t stream);
+/* tests: the calls of all ranks of a same-process group (qs_comm_connect_local) as ONE dispatch */
+int qs_comm_all_reduce_f16_group(void* const* comms, int world, int64_t numel, qs_stream_t stream);
+int qs_comm_error(void* comm);
+int qs_comm_destroy(void* comm);
+
 /* Device self-test (tests/test_fused_gpu.py): the DPP / permlane wave reductions every row kernel uses round exactly like
  * the shuffle butterfly they replace.  in: float [n] (n % 64 == 0); out: float [n/64][4] = {sum, sum by shuffles, max, max
  * by shuffles} per 64-value block. */

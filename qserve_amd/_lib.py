@@ -39,6 +39,15 @@ SIGNATURES = {
     "qs_add_residual_rms_norm_general": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "qs_silu_and_mul_quant": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "qs_debug_wave_reduce_selftest": (_i, [_vp, _vp, _i, _vp]),
+    "qs_comm_create": (_i, [_i, _i, _i64, C.POINTER(C.c_void_p), _vp]),
+    "qs_comm_connect": (_i, [_vp, _vp]),
+    "qs_comm_connect_local": (_i, [_vp, C.POINTER(C.c_void_p)]),
+    "qs_comm_input": (_vp, [_vp]),
+    "qs_comm_output": (_vp, [_vp]),
+    "qs_comm_all_reduce_f16": (_i, [_vp, _i64, _vp]),
+    "qs_comm_all_reduce_f16_group": (_i, [C.POINTER(C.c_void_p), _i, _i64, _vp]),
+    "qs_comm_error": (_i, [_vp]),
+    "qs_comm_destroy": (_i, [_vp]),
     "qs_debug_copy_split_workspace": (_i, [_vp, C.c_size_t]),
     "qs_flash_attn_varlen_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _f,
                                       _i, _vp]),

@@ -101,7 +101,8 @@ class W4A8Linear:
 
 class DecodeEngine:
     def __init__(self, cfg, batch, prompt_len, max_new, group_size=-1, int4_kv=True, device="cuda:0", seed=0,
-                 tp_rank=0, tp_world=1, with_lm_head=True, fuse_pairs=True, weights=None):
+                 tp_rank=0, tp_world=1, with_lm_head=True, fuse_pairs=True, weights=None,
+                 direct_allreduce=None):
         """weights: None = synthetic random-quantised tensors of the right shapes; otherwise this rank's tensors as
         qserve_amd.loader.load_llama_w4a8 returns them (checkpoint path)."""
         self.cfg, self.B, self.dev = cfg, batch, torch.device(device)
@@ -174,7 +175,15 @@ class DecodeEngine:
         self.q_scale = torch.empty((B,), dtype=f16, device=self.dev)
         self.q_sum = torch.empty((B,), dtype=f16, device=self.dev)
         self.qkv_buf = torch.empty((B, self.qkv_n), dtype=f16, device=self.dev)
-        self.proj_out = torch.empty((B, hid), dtype=f16, device=self.dev)
+        # row-parallel partial output / its sum over the ranks.  With the library's direct all-reduce (tp.DirectAllReduce)
+        # the GEMMs write straight into the communicator's input buffer and the sum appears in its output buffer
+        self.ar = direct_allreduce
+        if self.ar is not None:
+            assert tp_world > 1 and (B * hid) % (8 * tp_world) == 0
+            self.proj_out, self.proj_res = self.ar.input((B, hid)), self.ar.output((B, hid))
+        else:
+            self.proj_out = torch.empty((B, hid), dtype=f16, device=self.dev)
+            self.proj_res = self.proj_out
         self.gate_up_buf = torch.empty((B, 2 * inter), dtype=f16, device=self.dev)
         self.mlp_act = torch.empty((B, inter), dtype=f16, device=self.dev)
         self.final = torch.empty((B, hid), dtype=f16, device=self.dev)
@@ -336,11 +345,13 @@ class DecodeEngine:
                 else:
                     fused_kernels.invoke_quant(qo, attn, self.q_scale)
             L["o"](qo, self.q_scale, self.q_sum, self.proj_out)
+            res = self.proj_out
             if self.tp_world > 1:
                 yield self.proj_out
+                res = self.proj_res
                 if L["o"].defer_bias and L["o"].bias is not None:
-                    self.proj_out += L["o"].bias          # once, after the reduce
-            add_norm_quant(h, self.proj_out, L["ln2"])
+                    res += L["o"].bias                    # once, after the reduce
+            add_norm_quant(h, res, L["ln2"])
             L["gate_up"](qa, self.q_scale, self.q_sum, self.gate_up_buf)
             if fuse:
                 fusedmod.silu_and_mul_quant(self.q_mlp, self.gate_up_buf, self.q_scale, sums)
@@ -351,14 +362,16 @@ class DecodeEngine:
                 else:
                     fused_kernels.invoke_quant(self.q_mlp, self.mlp_act, self.q_scale)
             L["down"](self.q_mlp, self.q_scale, self.q_sum, self.proj_out)
+            res = self.proj_out
             if self.tp_world > 1:
                 yield self.proj_out
+                res = self.proj_res
                 if L["down"].defer_bias and L["down"].bias is not None:
-                    self.proj_out += L["down"].bias
+                    res += L["down"].bias
             if li + 1 < nl:
-                add_norm_quant(h, self.proj_out, self.layers[li + 1]["ln1"])   # next layer's input norm
+                add_norm_quant(h, res, self.layers[li + 1]["ln1"])   # next layer's input norm
             else:
-                residual_add_(h, self.proj_out)
+                residual_add_(h, res)
         layernorm_ops.rms_norm(self.final, h, self.norm_w, cfg["eps"])
         if self.with_lm_head:
             logits = torch.matmul(self.final, self.lm_head.t())      # un-quantised fp16 lm_head (:392,476)
@@ -366,9 +379,15 @@ class DecodeEngine:
         self.lengths.add_(1)
 
 
+    def _reduce(self, partial):
+        if self.ar is not None:
+            self.ar.all_reduce(partial.numel())       # a kernel on the current stream (capturable)
+        else:
+            tpmod.all_reduce_sum_(partial)
+
     def step(self):
         for partial in self._segments():
-            tpmod.all_reduce_sum_(partial)
+            self._reduce(partial)
 
     def capture(self, piecewise=None):
         """Capture one step in hipGraph(s) (removes ~400 launches of host overhead per step).
@@ -378,7 +397,7 @@ class DecodeEngine:
         library supporting stream capture, and the host only issues ~2 calls per layer and rank.
         `piecewise=False` captures the collectives too (needs a capturable backend)."""
         if piecewise is None:
-            piecewise = self.tp_world > 1
+            piecewise = self.tp_world > 1 and self.ar is None   # the direct all-reduce is an ordinary kernel: one graph
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -406,7 +425,7 @@ class DecodeEngine:
             pieces.append((g, partial))
             if partial is None:
                 break
-            tpmod.all_reduce_sum_(partial)    # keeps the data flow of the capture pass identical to a real step
+            self._reduce(partial)             # keeps the data flow of the capture pass identical to a real step
         self.pieces = pieces
         self.graph = None
         return pieces
@@ -416,7 +435,7 @@ class DecodeEngine:
             for g, partial in self.pieces:
                 g.replay()
                 if partial is not None:
-                    tpmod.all_reduce_sum_(partial)
+                    self._reduce(partial)
         elif self.graph is not None:
             self.graph.replay()
         else:

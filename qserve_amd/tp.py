@@ -76,6 +76,96 @@ def all_reduce_sum_(t, group=None):
     return t
 
 
+class _DevicePtr:
+    """A raw device allocation as a __cuda_array_interface__ object (torch.as_tensor wraps it without copying)."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 3,
+                                         "strides": None}
+        self._owner = owner
+
+
+class DirectAllReduce:
+    """The library's direct-access all-reduce (include/qserve_amd.h `qs_comm_*`, csrc/direct_allreduce.hip) for one rank.
+
+    Usage: the row-parallel GEMM writes its partial output into `input((B, hidden))`, `all_reduce(numel)` launches the
+    kernel on the current stream, the sum over the ranks is in `output((B, hidden))`.  Opt-in (DecodeEngine
+    `direct_allreduce=`, bench.py `--direct-allreduce`): not measured on multi-GPU hardware; `all_reduce_sum_` over
+    torch.distributed stays the default.  `numel` must be a multiple of 8 * world."""
+
+    def __init__(self, max_numel, group=None, device=None, _local=None):
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        from ._lib import check, lib
+        self._lib, self._check = lib, check
+        if _local is None:
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        else:
+            self.rank, self.world = _local
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        unit = 8 * self.world
+        self.max_numel = (int(max_numel) + unit - 1) // unit * unit
+        comm, handle = C.c_void_p(), C.create_string_buffer(64)
+        with torch.cuda.device(self.device):
+            check(lib.qs_comm_create(self.rank, self.world, self.max_numel * 2, C.byref(comm), handle), "comm_create")
+        self._comm = comm
+        self.handle = bytes(handle.raw)
+        if _local is None:
+            handles = [None] * self.world
+            dist.all_gather_object(handles, self.handle, group=group)
+            with torch.cuda.device(self.device):
+                check(lib.qs_comm_connect(comm, b"".join(handles)), "comm_connect")
+
+    @classmethod
+    def local_group(cls, world, max_numel, device=None):
+        """`world` communicators of ONE process, connected by address (tests: ranks driven on separate streams)."""
+        import ctypes as C
+        comms = [cls(max_numel, device=device, _local=(r, world)) for r in range(world)]
+        arr = (C.c_void_p * world)(*[c._comm for c in comms])
+        for c in comms:
+            c._check(c._lib.qs_comm_connect_local(c._comm, arr), "comm_connect_local")
+        return comms
+
+    def _view(self, ptr, shape):
+        import torch
+        n = 1
+        for d in shape:
+            n *= d
+        assert n <= self.max_numel
+        return torch.as_tensor(_DevicePtr(ptr, shape, "<f2", self), device=self.device)
+
+    def input(self, shape):
+        return self._view(self._lib.qs_comm_input(self._comm), shape)
+
+    def output(self, shape):
+        return self._view(self._lib.qs_comm_output(self._comm), shape)
+
+    def all_reduce(self, numel):
+        from .backend._util import stream
+        self._check(self._lib.qs_comm_all_reduce_f16(self._comm, int(numel), stream()), "comm_all_reduce")
+
+    @staticmethod
+    def all_reduce_group(comms, numel):
+        """All ranks of a `local_group` in ONE dispatch on the current stream (tests)."""
+        import ctypes as C
+
+        from .backend._util import stream
+        arr = (C.c_void_p * len(comms))(*[c._comm for c in comms])
+        comms[0]._check(comms[0]._lib.qs_comm_all_reduce_f16_group(arr, len(comms), int(numel), stream()), "comm_all_reduce_group")
+
+    def error(self):
+        """Synchronises; True if a call gave up waiting for a peer since the last query."""
+        return bool(self._lib.qs_comm_error(self._comm))
+
+    def close(self):
+        if self._comm:
+            self._lib.qs_comm_destroy(self._comm)
+            self._comm = None
+
+
 class RowParallelLinear:
     """y = all_reduce( gemm(x_shard) ) (+ bias once, after the reduce).
 

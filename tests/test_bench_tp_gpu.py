@@ -36,3 +36,12 @@ def test_bench_two_ranks_piecewise_graphs(gpu):
     out, err = _run([], 29542)
     assert out["n_gpus"] == 2 and out["value"] > 0
     assert str(out["config"]["hipgraph"]).startswith("piecewise"), err[-2000:]
+
+
+def test_bench_two_ranks_direct_allreduce_single_graph(gpu):
+    """`--direct-allreduce`: the library's own collective (an ordinary kernel) - the whole tensor-parallel step is ONE
+    hipGraph; the line carries the collective's latency next to the process group's."""
+    out, err = _run(["--direct-allreduce"], 29543)
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert out["config"]["hipgraph"] is True, err[-2000:]
+    assert out["config"]["direct_all_reduce_us"] > 0 and out["config"]["direct_all_reduce_timeouts"] is False
