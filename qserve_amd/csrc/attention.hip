@@ -471,6 +471,112 @@ __global__ __launch_bounds__(TPB) void prefill_kv_kernel(_Float16* __restrict__ 
     }
 }
 
+// Vectorised form (used whenever the library's RoPE table covers the sequence): 8 lanes per head, every lane owns dims
+// 8 dg .. 8 dg + 7 of the low half and the same dims of the high half (a NeoX pair is (d, 64 + d)), i.e. two 16-byte
+// accesses per head and direction instead of 2-byte ones, cos / sin from the table (the same double-evaluated,
+// float-rounded values as rope_coef), min / max over the 8 lanes of a head group.  Identical arithmetic per element.
+template <bool INT4>
+__device__ __forceinline__ void group_quant_store(const h8& lo, const h8& hi, uint8_t* dst, __half* scale_p, __half* zero_p,
+                                                  int dg) {
+    float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        mx = fmaxf(mx, fmaxf((float)lo[j], (float)hi[j]));
+        mn = fminf(mn, fminf((float)lo[j], (float)hi[j]));
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+        mn = fminf(mn, __shfl_xor(mn, m, 64));
+    }
+    const QParams p = make_qparams(mn, mx, INT4);
+    unsigned ul[8], uh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ul[j] = quant_u8(lo[j], p);
+        uh[j] = quant_u8(hi[j], p);
+    }
+    if (INT4) {                                            // byte i = dims (2i, 2i+1): Utils.h:1838-1852
+        u32 wl = 0, wh = 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            wl |= (((ul[2 * m] & 0xFu) | ((ul[2 * m + 1] & 0xFu) << 4)) << (8 * m));
+            wh |= (((uh[2 * m] & 0xFu) | ((uh[2 * m + 1] & 0xFu) << 4)) << (8 * m));
+        }
+        *reinterpret_cast<u32*>(dst + 4 * dg) = wl;
+        *reinterpret_cast<u32*>(dst + 32 + 4 * dg) = wh;
+    } else {
+        u32 a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            a0 |= ul[m] << (8 * m);
+            a1 |= ul[4 + m] << (8 * m);
+            b0 |= uh[m] << (8 * m);
+            b1 |= uh[4 + m] << (8 * m);
+        }
+        *reinterpret_cast<uint2*>(dst + 8 * dg) = make_uint2(a0, a1);
+        *reinterpret_cast<uint2*>(dst + 64 + 8 * dg) = make_uint2(b0, b1);
+    }
+    if (dg == 0) {
+        *scale_p = __builtin_bit_cast(__half, p.scale);
+        *zero_p = __builtin_bit_cast(__half, p.zero);
+    }
+}
+
+template <bool INT4>
+__global__ __launch_bounds__(TPB) void prefill_kv_vec_kernel(_Float16* __restrict__ qkv, const int* __restrict__ seq_lens,
+                                                             const int* __restrict__ padding_offset,
+                                                             const int64_t* __restrict__ kv_pointers, int num_tokens,
+                                                             int max_blocks, int head_num, int kv_head_num, int seq_len,
+                                                             const float2* __restrict__ rope_tab) {
+    constexpr int DHB = INT4 ? DH / 2 : DH;
+    const int t = blockIdx.x;
+    const int g = t + (padding_offset ? padding_offset[t] : 0);
+    const int b = g / seq_len, pos = g % seq_len;          // applyBias...h:186-194
+    if (pos >= seq_lens[b]) return;
+    const int dg = threadIdx.x & 7, slot0 = threadIdx.x >> 3;   // TPB / 8 head slots per pass
+    const int n = (head_num + 2 * kv_head_num) * DH;
+    _Float16* row = qkv + (size_t)t * n;
+    RopeCS cs[8];
+    {
+        const float4* tp = reinterpret_cast<const float4*>(rope_tab + (size_t)pos * 64 + 8 * dg);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 v = tp[j];
+            cs[2 * j].c = v.x, cs[2 * j].s = v.y, cs[2 * j + 1].c = v.z, cs[2 * j + 1].s = v.w;
+        }
+    }
+    for (int job = slot0; job < head_num + kv_head_num; job += TPB / 8) {
+        _Float16* hp = row + job * DH;                      // q heads, then k heads: contiguous in the row
+        const h8 lo = *reinterpret_cast<const h8*>(hp + 8 * dg), hi = *reinterpret_cast<const h8*>(hp + 64 + 8 * dg);
+        h8 rl, rh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 a, bb;
+            rope_pair((float)lo[j], (float)hi[j], cs[j], a, bb);
+            rl[j] = a;
+            rh[j] = bb;
+        }
+        *reinterpret_cast<h8*>(hp + 8 * dg) = rl;           // STORE_QKV, :386-388
+        *reinterpret_cast<h8*>(hp + 64 + 8 * dg) = rh;
+        if (job >= head_num && kv_pointers) {
+            const int hk = job - head_num;
+            const _Float16* vh = row + (head_num + kv_head_num) * DH + hk * DH;
+            const h8 vl = *reinterpret_cast<const h8*>(vh + 8 * dg), vhh = *reinterpret_cast<const h8*>(vh + 64 + 8 * dg);
+            const int blk = pos >> 6, slot = pos & 63;
+            const int64_t* tab = kv_pointers + (size_t)b * 2 * max_blocks;
+            uint8_t* kp = reinterpret_cast<uint8_t*>(tab[blk]);
+            uint8_t* vp = reinterpret_cast<uint8_t*>(tab[max_blocks + blk]);
+            __half* ksc = reinterpret_cast<__half*>(kp + (size_t)kv_head_num * PAGE_TOK * DHB);
+            __half* vsc = reinterpret_cast<__half*>(vp + (size_t)kv_head_num * PAGE_TOK * DHB);
+            group_quant_store<INT4>(rl, rh, kp + ((size_t)hk * PAGE_TOK + slot) * DHB, ksc + hk * PAGE_TOK + slot,
+                                    ksc + kv_head_num * PAGE_TOK + hk * PAGE_TOK + slot, dg);
+            group_quant_store<INT4>(vl, vhh, vp + ((size_t)hk * PAGE_TOK + slot) * DHB, vsc + hk * PAGE_TOK + slot,
+                                    vsc + kv_head_num * PAGE_TOK + hk * PAGE_TOK + slot, dg);
+        }
+    }
+}
+
 __global__ void padding_offsets_kernel(int* __restrict__ out, const int* __restrict__ cu, int max_seqlen) {
     const int b = blockIdx.x;
     const int beg = cu[b], end = cu[b + 1];
@@ -512,6 +618,8 @@ int launch_decode(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Fl
 
 }  // namespace
 
+// library-managed RoPE table (attention_mfma.hip)
+const float2* qs_rope_table(float base, int max_pos, hipStream_t st, int* len_out);
 // KV4 fast path on the matrix cores (attention_mfma.hip)
 int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
                           const int64_t* kvp, const int* len, _Float16* out, int H, int Hkv, int64_t qs, int64_t kvs,
@@ -520,8 +628,8 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
 int qs_launch_decode_mfma8(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
                            const int64_t* kvp, const int* len, _Float16* out, int H, int Hkv, int64_t qs, int64_t kvs,
                            int mb, int timestep, float base, int max_pos, int force_split);
-// 0 = MFMA kernel for KV4 with the split-KV heuristic (default), 1 = VALU kernel everywhere, 100 + n = MFMA kernel with
-// exactly n KV splits (A/B tests)
+// 0 = MFMA kernel for KV4 with the split-KV heuristic (default), 1 = VALU kernel everywhere, 2 = prefill writer in its
+// per-lane form (no RoPE table), 100 + n = MFMA kernel with exactly n KV splits (A/B tests)
 static int g_attn_variant = 0;
 extern "C" void qs_set_attention_variant(int variant) { g_attn_variant = variant; }
 
@@ -637,6 +745,19 @@ extern "C" int qs_apply_bias_rope_update_kv_cache(void* qkv, const int32_t* seq_
     (void)rotary_embedding_max_positions;
     if (num_tokens <= 0) return QS_OK;
     hipStream_t st = (hipStream_t)stream;
+    // the vectorised writer reads cos / sin from the library's table (positions < seq_len); without one (first call inside
+    // a stream capture, all table slots taken) the per-lane form computes them in the kernel
+    int tab_len = 0;
+    const float2* tab = g_attn_variant == 2 ? nullptr : qs_rope_table(rotary_embedding_base, seq_len, st, &tab_len);
+    if (tab && tab_len >= seq_len) {
+        if (int4_kv_cache)
+            hipLaunchKernelGGL(prefill_kv_vec_kernel<true>, dim3(num_tokens), dim3(TPB), 0, st, (_Float16*)qkv, seq_lens,
+                               padding_offset, kv_pointers, num_tokens, max_blocks, head_num, kv_head_num, seq_len, tab);
+        else
+            hipLaunchKernelGGL(prefill_kv_vec_kernel<false>, dim3(num_tokens), dim3(TPB), 0, st, (_Float16*)qkv, seq_lens,
+                               padding_offset, kv_pointers, num_tokens, max_blocks, head_num, kv_head_num, seq_len, tab);
+        return qs_launch_status("apply_bias_rope_update_kv_cache");
+    }
     if (int4_kv_cache)
         hipLaunchKernelGGL(prefill_kv_kernel<true>, dim3(num_tokens), dim3(TPB), 0, st, (_Float16*)qkv, seq_lens,
                            padding_offset, kv_pointers, num_tokens, max_blocks, head_num, kv_head_num, seq_len,

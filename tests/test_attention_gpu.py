@@ -93,6 +93,18 @@ def run_case(gpu, B, H, Hkv, lengths, int4, seed):
 
 
 @pytest.mark.parametrize("int4", [True, False])
+def test_prefill_writer_per_lane_form(gpu, int4):
+    """The prefill writer without the library's RoPE table (what runs when the first call arrives inside a stream
+    capture): same bit-exact pages and rotated q / k as the vectorised form the other tests exercise."""
+    from qserve_amd._lib import lib
+    lib.qs_set_attention_variant(2)
+    try:
+        run_case(gpu, 5, 8, 2, [1, 64, 65, 130, 200], int4, seed=77)
+    finally:
+        lib.qs_set_attention_variant(0)
+
+
+@pytest.mark.parametrize("int4", [True, False])
 @pytest.mark.parametrize("H,Hkv", [(32, 8), (8, 8), (4, 2), (8, 1), (7, 1), (6, 2), (5, 1)])
 def test_decode_ragged_lengths(gpu, int4, H, Hkv):
     # length 1 (no history), exact page boundaries, one past, ragged tail
