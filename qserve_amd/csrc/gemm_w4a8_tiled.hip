@@ -347,6 +347,10 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     constexpr int RS = 144;                            // staged row stride (bytes): 128 + 16 keeps 16-byte alignment
     raw_barrier();                                     // the rings are dead: every wave left the k loop
     uint8_t* const st = smem + wave * (16 * MT * RS);
+    _Float16* const orow = reinterpret_cast<_Float16*>(out) + n0 + wn * 64 + (lane & 7) * 8;
+    // per m-tile: convert -> stage 16 rows -> store them, so that the 32 MB of output of a 4096^3 launch start leaving
+    // while the later m-tiles are still being converted (the staged rows of an m-tile are written and read by the same
+    // wave: an LDS wait, no barrier)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const float sa = (float)sa_h[mt];
@@ -364,14 +368,13 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
             }
             *reinterpret_cast<h4*>(st + (16 * mt + li) * RS + (32 * (g >> 1) + 8 * cl + 4 * (g & 1)) * 2) = o;
         }
-    }
-    _Float16* const orow = reinterpret_cast<_Float16*>(out) + n0 + wn * 64 + (lane & 7) * 8;
 #pragma unroll
-    for (int i = 0; i < 2 * MT; ++i) {
-        const int r = i * 8 + (lane >> 3);
-        const int m = m0 + wm * (16 * MT) + r;
-        const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane & 7) * 16);
-        if (m < M) *reinterpret_cast<v4u*>(orow + (size_t)m * N) = v;
+        for (int i = 2 * mt; i < 2 * mt + 2; ++i) {
+            const int r = i * 8 + (lane >> 3);
+            const int m = m0 + wm * (16 * MT) + r;
+            const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane & 7) * 16);
+            if (m < M) *reinterpret_cast<v4u*>(orow + (size_t)m * N) = v;
+        }
     }
 }
 
