@@ -71,9 +71,13 @@ def parse():
     ap.add_argument("--tp-full-graph", action="store_true",
                     help="N>1: capture the all-reduces into the step's hipGraph as well (default: one graph per segment "
                          "between the collectives, collectives issued eagerly - independent of capture support in RCCL)")
-    ap.add_argument("--direct-allreduce", action="store_true",
-                    help="N>1: the library's direct-access all-reduce (qs_comm_*, one kernel per collective, whole step in "
-                         "one hipGraph) instead of torch.distributed; opt-in - not measured on multi-GPU hardware")
+    ap.add_argument("--collective", default="auto", choices=["auto", "rccl", "direct"],
+                    help="N>1: how the row-parallel partials are summed.  rccl = torch.distributed all-reduce, issued eagerly "
+                         "between hipGraph pieces; direct = the library's direct-access all-reduce (qs_comm_*: one kernel per "
+                         "collective, whole step in one hipGraph); auto (default) = direct if its start-up self-check on THIS "
+                         "machine passes (bit-exact against the gathered inputs, no time-out, not slower than the process "
+                         "group's all-reduce), else rccl - the line says which and why")
+    ap.add_argument("--direct-allreduce", action="store_true", help="same as --collective direct")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="N>1 (tensor parallel): weak = --batch sequences PER GPU (global batch = batch x N, so every "
                          "rank keeps N=1's GEMM MACs and KV bytes); strong = --batch is the global batch")
@@ -88,6 +92,68 @@ def parse():
         a.gpus = 1
     a.kv8 = bool(a.kv8)
     return a
+
+
+def direct_allreduce_or_none(numel, rank, world, dev, mode):
+    """The library's direct-access all-reduce, checked on this machine before it is trusted: every rank's result must be
+    bit-identical to the fp32 rank-order sum of the gathered inputs, no wait may time out and (mode "auto") it must not be
+    slower than the process group's all-reduce.  All ranks take the same decision.  -> (communicator | None, note)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from qserve_amd import tp as TP
+
+    def agree(ok):
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(ok))
+        return all(flags)
+
+    try:
+        comm = TP.DirectAllReduce(numel, device=dev)
+    except Exception as e:                                       # raised consistently on every rank
+        return None, f"torch.distributed ({str(e)[:200]})"
+    why = None
+    try:
+        for it in range(6):
+            x = (np.random.default_rng(977 * it + rank).standard_normal(numel) * 2).astype(np.float16)
+            parts = [None] * world
+            dist.all_gather_object(parts, x)
+            acc = np.zeros(numel, np.float32)
+            for p in parts:
+                acc = acc + p.astype(np.float32)
+            comm.input((numel,)).copy_(torch.from_numpy(x))
+            torch.cuda.synchronize()
+            dist.barrier()
+            comm.all_reduce(numel)
+            timed_out = comm.error()                             # synchronises
+            good = (not timed_out) and np.array_equal(comm.output((numel,)).cpu().numpy(), acc.astype(np.float16))
+            if not agree(good):
+                why = "self-check failed: " + ("a wait timed out" if timed_out else "result differs from the rank-order fp32 sum")
+                break
+        if why is None and mode == "auto":
+            buf = torch.zeros((numel,), dtype=torch.float16, device=dev)
+            times = []
+            for fn in (lambda: dist.all_reduce(buf), lambda: comm.all_reduce(numel)):
+                for _ in range(5):
+                    fn()
+                torch.cuda.synchronize()
+                dist.barrier()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(30):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                times.append(e0.elapsed_time(e1) / 30)
+            if not agree(times[1] <= times[0] and not comm.error()):
+                why = f"slower than the process group's all-reduce here ({times[1] * 1e3:.1f} vs {times[0] * 1e3:.1f} us on rank {rank})"
+    except Exception as e:
+        why = f"self-check raised {str(e)[:200]}"
+        agree(False)
+    if why is not None:
+        comm.close()
+        return None, f"torch.distributed ({why})"
+    return comm, "library direct-access all-reduce (qs_comm_all_reduce_f16), start-up self-check passed"
 
 
 def self_launch(args):
@@ -304,10 +370,10 @@ def main():
         _lib.lib.qs_set_attention_variant(args.attn_variant)
     cfg = {"llama3-8b": D.LLAMA3_8B, "llama2-7b": D.LLAMA2_7B, "llama2-70b": D.LLAMA2_70B, "qwen1.5-72b": D.QWEN15_72B,
            "tiny": D.TINY}[args.model]
-    direct = None
-    if world > 1 and args.direct_allreduce:
-        from qserve_amd import tp as TP
-        direct = TP.DirectAllReduce(args.batch * cfg["hidden"], device=dev)
+    direct, collective_note = None, None
+    mode = "direct" if args.direct_allreduce else args.collective
+    if world > 1 and mode != "rccl":
+        direct, collective_note = direct_allreduce_or_none(args.batch * cfg["hidden"], rank, world, dev, mode)
     eng = D.DecodeEngine(cfg, args.batch, args.prompt_len, args.max_new, group_size=args.group_size,
                          int4_kv=not args.kv8, device=dev, tp_rank=rank, tp_world=world,
                          fuse_pairs=not args.op_by_op, direct_allreduce=direct)
@@ -445,8 +511,8 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             extra.update(direct_all_reduce_us=round(e0.elapsed_time(e1) * 1e3 / 50, 2),
-                         step_collectives="library direct-access all-reduce (qs_comm_all_reduce_f16)",
                          direct_all_reduce_timeouts=bool(direct.error()))
+        extra.update(step_collectives=collective_note or "torch.distributed all-reduce (--collective rccl)")
 
     # ---- per-kernel timing + roofline ---------------------------------------------------------------------------------
     roof, roof_family, kernels = None, None, None

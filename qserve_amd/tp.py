@@ -109,15 +109,32 @@ class DirectAllReduce:
         unit = 8 * self.world
         self.max_numel = (int(max_numel) + unit - 1) // unit * unit
         comm, handle = C.c_void_p(), C.create_string_buffer(64)
+        err = None
         with torch.cuda.device(self.device):
-            check(lib.qs_comm_create(self.rank, self.world, self.max_numel * 2, C.byref(comm), handle), "comm_create")
-        self._comm = comm
+            try:
+                check(lib.qs_comm_create(self.rank, self.world, self.max_numel * 2, C.byref(comm), handle), "comm_create")
+            except RuntimeError as e:              # keep the collective calls below matched on every rank
+                if _local is not None:
+                    raise
+                err = str(e)
+        self._comm = comm if err is None else None
         self.handle = bytes(handle.raw)
         if _local is None:
             handles = [None] * self.world
-            dist.all_gather_object(handles, self.handle, group=group)
-            with torch.cuda.device(self.device):
-                check(lib.qs_comm_connect(comm, b"".join(handles)), "comm_connect")
+            dist.all_gather_object(handles, None if err else self.handle, group=group)
+            if err is None and all(h is not None for h in handles):
+                with torch.cuda.device(self.device):
+                    try:
+                        check(lib.qs_comm_connect(comm, b"".join(handles)), "comm_connect")
+                    except RuntimeError as e:
+                        err = str(e)
+            elif err is None:
+                err = "another rank could not create its communicator"
+            oks = [None] * self.world
+            dist.all_gather_object(oks, err, group=group)
+            if any(o is not None for o in oks):
+                self.close()
+                raise RuntimeError("direct all-reduce unavailable: " + "; ".join(f"rank {r}: {o}" for r, o in enumerate(oks) if o))
 
     @classmethod
     def local_group(cls, world, max_numel, device=None):

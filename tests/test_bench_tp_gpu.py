@@ -25,7 +25,7 @@ def _run(extra, port):
 
 
 def test_bench_two_ranks_eager(gpu):
-    out, _ = _run(["--no-graph"], 29541)
+    out, _ = _run(["--no-graph", "--collective", "rccl"], 29541)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 8
     assert out["config"]["parallelism"] == "tp2" and out["value"] > 0 and out["config"]["hipgraph"] is False
 
@@ -33,9 +33,10 @@ def test_bench_two_ranks_eager(gpu):
 def test_bench_two_ranks_piecewise_graphs(gpu):
     """Default N > 1 mode: one hipGraph per segment between the all-reduces, the collectives issued eagerly - works with
     any backend (here gloo, which could never be captured)."""
-    out, err = _run([], 29542)
+    out, err = _run(["--collective", "rccl"], 29542)
     assert out["n_gpus"] == 2 and out["value"] > 0
     assert str(out["config"]["hipgraph"]).startswith("piecewise"), err[-2000:]
+    assert out["config"]["step_collectives"].startswith("torch.distributed")
 
 
 def test_bench_two_ranks_direct_allreduce_single_graph(gpu):
@@ -45,3 +46,14 @@ def test_bench_two_ranks_direct_allreduce_single_graph(gpu):
     assert out["n_gpus"] == 2 and out["value"] > 0
     assert out["config"]["hipgraph"] is True, err[-2000:]
     assert out["config"]["direct_all_reduce_us"] > 0 and out["config"]["direct_all_reduce_timeouts"] is False
+
+
+def test_bench_two_ranks_default_picks_a_checked_collective(gpu):
+    """Default (`--collective auto`): the direct all-reduce is used only after its start-up self-check passed on this
+    machine; either way the line says which collective ran and why."""
+    out, err = _run([], 29544)
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    note = out["config"]["step_collectives"]
+    assert note.startswith("library direct-access all-reduce") or note.startswith("torch.distributed ("), note
+    if note.startswith("library"):
+        assert out["config"]["hipgraph"] is True and out["config"]["direct_all_reduce_timeouts"] is False
