@@ -222,7 +222,8 @@ int qs_flash_attn_varlen_fwd(const void* q, const void* k, const void* v, void* 
  *   qs_comm_connect_local same-process ranks: the other communicators themselves, no IPC (tests)
  *   qs_comm_input/output  device pointers: the rank's addend is written to input (e.g. as the row-parallel GEMM's output
  *                         buffer), the sum over all ranks is in output once qs_comm_all_reduce_f16's kernel has retired
- *   numel % (8 * world) == 0, numel * 2 <= payload_bytes. */
+ *   numel % (8 * world) == 0, numel * 2 <= payload_bytes.  After a time-out the ranks' device-side epochs no longer
+ *   match: destroy and re-create the communicators. */
 int qs_comm_create(int rank, int world, int64_t payload_bytes, void** comm_out, void* ipc_handle64);
 int qs_comm_connect(void* comm, const void* handles);
 int qs_comm_connect_local(void* comm, void* const* peer_comms);
