@@ -112,6 +112,14 @@ class DirectAllReduce:
         err = None
         with torch.cuda.device(self.device):
             try:
+                # warm-up: a one-rank communicator runs the kernel once, so that this process has loaded the code object
+                # before the first real call - whose waits for the peers are bounded to a few seconds
+                w, wh = C.c_void_p(), C.create_string_buffer(64)
+                check(lib.qs_comm_create(0, 1, 16, C.byref(w), wh), "comm_create (warm-up)")
+                check(lib.qs_comm_connect(w, bytes(wh.raw)), "comm_connect (warm-up)")
+                check(lib.qs_comm_all_reduce_f16(w, 8, None), "comm_all_reduce (warm-up)")
+                lib.qs_comm_error(w)
+                lib.qs_comm_destroy(w)
                 check(lib.qs_comm_create(self.rank, self.world, self.max_numel * 2, C.byref(comm), handle), "comm_create")
             except RuntimeError as e:              # keep the collective calls below matched on every rank
                 if _local is not None:
