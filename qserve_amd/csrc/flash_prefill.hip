@@ -29,7 +29,14 @@ typedef u32 v2u __attribute__((ext_vector_type(2)));
 #endif
 constexpr int DH = 128;
 constexpr int BM = 128;           // query rows per workgroup
-constexpr int BN = 64;            // keys per tile
+#ifndef QS_FLASH_NKB
+#define QS_FLASH_NKB 2
+#endif
+#ifndef QS_FLASH_OCC
+#define QS_FLASH_OCC 2
+#endif
+constexpr int NKB = QS_FLASH_NKB;  // 32-key blocks per tile
+constexpr int BN = 32 * NKB;      // keys per tile
 constexpr int KS_BYTES = BN * DH * 2;             // 16 KiB
 constexpr int VT_BYTES = BN * DH * 2;             // 16 KiB (row-major like K; transposed on read)
 
@@ -39,7 +46,7 @@ __device__ __forceinline__ u32 pack_h2(float a, float b) {
 }
 
 template <bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
+__global__ __launch_bounds__(256, QS_FLASH_OCC) void flash_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
                                                           const _Float16* __restrict__ v, _Float16* __restrict__ out,
                                                           const int* __restrict__ cu_q, const int* __restrict__ cu_k,
                                                           int num_heads, int num_kv_heads, int64_t q_stride0,
@@ -80,10 +87,10 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const _Float16* __res
     // ---- tile staging: thread t moves pieces t, t+256, t+512, t+768 (piece = key * 16 + 16-byte chunk) ----------------
     const _Float16* kg = k + (size_t)k_start * k_stride0 + (size_t)hkv * DH;
     const _Float16* vg = v + (size_t)k_start * v_stride0 + (size_t)hkv * DH;
-    v4u kreg[4], vreg[4];
+    v4u kreg[2 * NKB], vreg[2 * NKB];
     auto load_tile = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2 * NKB; ++i) {
             const int idx = tid + 256 * i, key = idx >> 4, ch = idx & 15;
             const int kk = t * BN + key;
             if (kk < len_k) {
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const _Float16* __res
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2 * NKB; ++i) {
             const int idx = tid + 256 * i, key = idx >> 4, ch = idx & 15;
             *reinterpret_cast<v4u*>(&s_k[buf][key * 256 + ((ch ^ (key & 15)) * 16)]) = kreg[i];
             *reinterpret_cast<v4u*>(&s_vt[buf][key * 256 + ((ch ^ ((key & 3) << 1)) * 16)]) = vreg[i];
@@ -122,9 +129,9 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const _Float16* __res
         if (!(QS_FLASH_DBG & 8) && t + 1 < ntiles) load_tile(t + 1);          // global loads in flight during the MFMAs below
 
         // ---------------- S^T = K Q^T : two blocks of 32 keys ----------------
-        v16f sacc[2];
+        v16f sacc[NKB];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
             const int key = 32 * kb + li;
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const _Float16* __res
                     sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qf[s], sacc[kb], 0, 0, 0);
                 }
             } else {
-                sacc[kb][0] = qf[kb][0];
+                sacc[kb][0] = (float)qf[kb][0];
             }
         }
         // sacc[kb][r] = score of (this lane's row, key t*64 + 32kb + (r&3) + 8(r>>2) + 4hi)
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const _Float16* __res
         float mx = -INFINITY;
         if (need_mask) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = t * BN + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const _Float16* __res
                 }
         } else {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
         }
@@ -168,9 +175,9 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const _Float16* __res
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);                  // m_run = -inf -> 0
         m_run = m_new;
         float psum = 0.f;
-        u32 pb[2][2][4];                                           // [kb][m]: 8 probabilities in B-operand order
+        u32 pb[NKB][2][4];                                           // [kb][m]: 8 probabilities in B-operand order
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -197,13 +204,13 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const _Float16* __res
         // lane c receives column c = (dim c, keys 0..3), i.e. exactly its four k-slots of the PV MFMA.
         const int ta = lane & 15, g1 = (lane >> 4) & 1;
         const int tkey = 4 * hi + (ta >> 2);                       // key within a 16-key block; tkey & 3 == ta >> 2
-        if (QS_FLASH_DBG & 2) oacc[0][0] += __builtin_bit_cast(float, pb[0][0][0] ^ pb[1][1][3]);
+        if (QS_FLASH_DBG & 2) oacc[0][0] += __builtin_bit_cast(float, pb[0][0][0] ^ pb[NKB - 1][1][3]);
 #pragma unroll
         for (int d = 0; d < ((QS_FLASH_DBG & 2) ? 0 : 4); ++d) {
             const int chunk = (4 * d + 2 * g1 + ((ta & 3) >> 1)) ^ ((ta >> 2) << 1);
             const uint8_t* vrow = &s_vt[buf][tkey * 256 + chunk * 16 + (ta & 1) * 8];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const int kofs = (32 * kb + 16 * m) * 256;
