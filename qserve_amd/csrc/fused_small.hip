@@ -81,10 +81,14 @@ __global__ __launch_bounds__(NT) void quant_kernel(int8_t* __restrict__ out, con
     h8 v[NC];
     float amax = 0.f, sum = 0.f;
 #pragma unroll
+    for (int c = 0; c < NC; ++c) {                     // all requests first (see add_residual_norm_quant_kernel)
+        const int i = (c * NT + threadIdx.x) * 8;
+        if (i < hidden) v[c] = load8(in + base + i);
+    }
+#pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int i = (c * NT + threadIdx.x) * 8;
         if (i < hidden) {
-            v[c] = load8(in + base + i);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float f = (float)v[c][j];
@@ -130,11 +134,17 @@ __global__ __launch_bounds__(TPB) void general_norm_quant_kernel(int8_t* __restr
     h8 v[NC], g[NC];
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
+    for (int c = 0; c < NC; ++c) {                     // all requests first (see add_residual_norm_quant_kernel)
         const int i = (c * TPB + threadIdx.x) * 8;
         if (i < hidden) {
             v[c] = load8(in + base + i);
             g[c] = load8(gamma + i);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i = (c * TPB + threadIdx.x) * 8;
+        if (i < hidden) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += (float)v[c][j];
         }
@@ -249,14 +259,24 @@ __global__ __launch_bounds__(TPB) void add_residual_norm_quant_kernel(int8_t* __
                                                                       int hidden) {
     __shared__ float sm[4][TPB / 64];
     const size_t base = (size_t)blockIdx.x * hidden;
-    h8 v[NC], g[NC];
+    h8 v[NC], g[NC], dl[NC];
     float s = 0.f;
+    // every load of the row is requested before the first one is used (with load and use in one loop body the second
+    // chunk's requests left only after the first chunk's data had arrived: two memory round trips instead of one)
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int i = (c * TPB + threadIdx.x) * 8;
         if (i < hidden) {
-            v[c] = load8(hidden_io + base + i) + load8(delta + base + i);    // residual_add_kernel's fp16 add
+            v[c] = load8(hidden_io + base + i);
+            dl[c] = load8(delta + base + i);
             g[c] = load8(gamma + i);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int i = (c * TPB + threadIdx.x) * 8;
+        if (i < hidden) {
+            v[c] = v[c] + dl[c];                                             // residual_add_kernel's fp16 add
             *reinterpret_cast<h8*>(hidden_io + base + i) = v[c];
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += (float)v[c][j];
@@ -454,9 +474,9 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const _Float16* __res
     for (int c0 = 0; c0 < nchunk; c0 += MAXC * 1024) {       // one trip up to MAXC * 8192 columns
         h8 v[MAXC];
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int ch = c0 + tid + c * 1024;
-            if (ch < nchunk) v[c] = load8(row + (size_t)ch * 8);
+        for (int c = 0; c < MAXC; ++c) {               // unconditional (clamped) loads: a load under a branch makes the compiler
+            const int ch = c0 + tid + c * 1024;        // drain the queue at every merge point - one load in flight at a time
+            v[c] = load8(row + (size_t)(ch < nchunk ? ch : nchunk - 1) * 8);
         }
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
@@ -497,8 +517,8 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const _Float16* __res
 
 extern "C" int qs_argmax_rows(const void* x, int64_t* out, int rows, int n, int64_t row_stride, qs_stream_t stream) {
     QS_REQUIRE(x && out, "argmax_rows: null pointer");
-    QS_REQUIRE(n > 0 && row_stride >= n && row_stride % 8 == 0, "argmax_rows: n=%d, row stride %lld (must be >= n, multiple of 8)", n,
-               (long long)row_stride);
+    QS_REQUIRE(n >= 8 && row_stride >= n && row_stride % 8 == 0, "argmax_rows: n=%d (>= 8), row stride %lld (must be >= n, multiple of 8)",
+               n, (long long)row_stride);
     if (rows <= 0) return QS_OK;
     const int chunks = ((n >> 3) + 1023) / 1024;
     auto launch = [&](auto k) {
