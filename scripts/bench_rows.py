@@ -48,3 +48,27 @@ print(f"add_residual + rms_norm_general_fuse_sum (fused)  {period(lambda i: fz.a
 print(f"rms_norm_general_fuse_sum                         {period(lambda i: ln.rms_norm_general_fuse_sum(q, hs[i % NB], w, sm, sc, 1e-5, True)):6.2f} us")
 print(f"invoke_quant_fuse_sum                             {period(lambda i: fk.invoke_quant_fuse_sum(q, hs[i % NB], sm, sc)):6.2f} us")
 print(f"silu_and_mul + quant (fused, d = {D})           {period(lambda i: fz.silu_and_mul_quant(qm, gu[i % NB], sc, sm)):6.2f} us")
+
+
+# instruction-cache check: different kernels alternating vs the same kernel repeated
+def mix2(i):
+    if i & 1:
+        fk.invoke_quant_fuse_sum(q, hs[i % NB], sm, sc)
+    else:
+        fz.add_residual_rms_norm_general(q, hs[i % NB], ds[i % NB], w, sc, 1e-5, sm)
+
+
+def mix4(i):
+    k = i & 3
+    if k == 0:
+        fz.add_residual_rms_norm_general(q, hs[i % NB], ds[i % NB], w, sc, 1e-5, sm)
+    elif k == 1:
+        fk.invoke_quant_fuse_sum(q, hs[i % NB], sm, sc)
+    elif k == 2:
+        ln.rms_norm_general_fuse_sum(q, hs[i % NB], w, sm, sc, 1e-5, True)
+    else:
+        fz.silu_and_mul_quant(qm, gu[i % NB], sc, sm)
+
+
+print(f"alternating add+norm+quant / quant                {period(mix2):6.2f} us (mean of the two alone: {(3.72 + 2.25) / 2:.2f})")
+print(f"cycling 4 different row kernels                   {period(mix4):6.2f} us (mean of the four alone: {(3.72 + 2.25 + 3.36 + 6.22) / 4:.2f})")
