@@ -460,7 +460,8 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
     if (g_variant >= 4100 && g_variant < 4500) {       // tests: force geometry 4100 + 100*(ksplit-1) + 10*mt + wn
         const int v = g_variant - 4100, ks = v / 100 + 1, mt = (v % 100) / 10, wn = v % 10;
         const int mb = ((M + 15) / 16 + mt - 1) / mt;
-        QS_REQUIRE((mt == 1 || mt == 2 || mt == 4) && (wn == 1 || wn == 2) && !(mt == 1 && wn == 2) &&
+        QS_REQUIRE((mt == 1 || mt == 2 || mt == 4) && (wn == 1 || wn == 2 || (wn == 4 && mt == 4)) &&
+                       !(mt == 1 && wn == 2) &&
                        N % (64 * wn) == 0 && (K / 64) % ks == 0 && (K / 64 / ks) % (8 / wn) == 0,
                    "w4a8 gemm: forced ring geometry mt=%d wn=%d ksplit=%d does not fit M=%d N=%d K=%d", mt, wn, ks, M, N,
                    K);
@@ -478,7 +479,8 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
     if (M <= 1024 && !(K < 1024 && M <= 64) && g_variant != 4000 && (g_variant < 1000 || g_variant >= 4000) &&
         (size_t)M * K < (1ull << 32) && (size_t)N * K / 2 < (1ull << 32)) {
         const int mt_all = (M + 15) / 16;
-        static const int geo[5][2] = {{4, 2}, {2, 2}, {4, 1}, {2, 1}, {1, 1}};
+        static const int geo[6][2] = {{4, 2}, {2, 2}, {4, 1}, {2, 1}, {1, 1}, {4, 4}};   // 4 units (2 K-groups): fewer bytes per CU where two-unit
+        // workgroups need a second round - M = 128 x N = 28 672: 26.8 vs 32.4 us (per-group 41.0 vs 47.0), M = 64 x 49 152: 48.9 vs 58.4
         // K slices (ksplit 2 / 4, int32 partial tiles meeting in a workspace, last arriver finishes): fewer bytes per
         // CU when neither tokens nor channels can be cut further, against the seam's cost; variant 4001
         // keeps ksplit = 1 (A/B)
@@ -491,7 +493,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         long best = -1;
         int bmt = 0, bwn = 0, bks = 1;
         for (int ks = 1; ks <= (g_variant == 4001 ? 1 : 4); ks *= 2)
-            for (int i = 0; i < 5; ++i) {
+            for (int i = 0; i < 6; ++i) {
                 const int mt = geo[i][0], wn = geo[i][1];
                 if (N % (64 * wn) != 0 || (K / 64) % ks != 0 || (K / 64 / ks) % (8 / wn) != 0) continue;
                 const int mb = (mt_all + mt - 1) / mt;
@@ -522,7 +524,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
             if (!ring_ws(bmt, mb, bks, &slabs, &counters)) {   // no workspace (e.g. first call inside a capture): best un-split
                 best = -1;
                 bks = 1;
-                for (int i = 0; i < 5; ++i) {
+                for (int i = 0; i < 6; ++i) {
                     const int mt = geo[i][0], wn = geo[i][1];
                     if (N % (64 * wn) != 0 || (K / 64) % (8 / wn) != 0) continue;
                     const long blocks = (long)((mt_all + mt - 1) / mt) * (N / (64 * wn));

@@ -89,6 +89,12 @@ __device__ __forceinline__ void raw_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// bytes of one K-group's ring slot: activations | weights | per-group meta (kernel and launcher must agree)
+template <int MT, int WN, int MODE>
+constexpr int ring_gstage() {
+    return 16 * MT * 64 + WN * 2048 + (MODE == 1 ? 2 * (WN > 2 ? 256 : 128) : 0);
+}
+
 // MT m-tiles (16 tokens each) per wave = tokens per workgroup / 16; WN units per workgroup; KG = 8 / WN K-groups.
 // KSPLIT = false folds every K-slice path away (the un-split launches keep exactly their earlier code).
 template <int MT, int WN, int MODE, int OUTK, bool KSPLIT>
@@ -106,8 +112,10 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
     constexpr int KG = 8 / WN;
     constexpr int ASTAGE = 16 * MT * 64;              // activation bytes per stage (64 k)
     constexpr int WSTAGE = WN * 2048;                 // packed weight bytes per stage
-    constexpr int MSTAGE = MODE == 1 ? 256 : 0;       // per-group scales | zeros of the WN units (<= 2 x 128 B)
-    constexpr int GSTAGE = ASTAGE + WSTAGE + MSTAGE;  // ring slot of one group
+    constexpr int MZ = WN > 2 ? 256 : 128;            // per-group meta of a stage: scales of the WN units | zeros at + MZ
+    constexpr int MSTAGE = MODE == 1 ? 2 * MZ : 0;
+    constexpr int GSTAGE = ring_gstage<MT, WN, MODE>();  // ring slot of one group
+    static_assert(GSTAGE == ASTAGE + WSTAGE + MSTAGE, "slot layout");
     constexpr int NPIECE = MT + 2 * WN;               // 1 KiB DMA pieces per group and stage
     static_assert(NPIECE % WN == 0, "pieces must split evenly over the waves of a group");
     constexpr int NDMA = NPIECE / WN + (MODE == 1 ? 1 : 0);   // VMEM instructions per wave and stage
@@ -189,7 +197,10 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
         }
     }
     // per-group meta: 16*WN dwords of scales (lanes 0-31) | zeros (lanes 32-63); surplus lanes repeat valid addresses
-    const int8_t* const m_base = ((lane & 32) ? zeros : scales8) + unit0 * 64 + ((lane & 31) & (16 * WN - 1)) * 4;
+    // (WN <= 2: one instruction carries both, lanes 0-31 scales | 32-63 zeros; WN = 4: 64 dwords each - the even waves
+    //  of a group fetch the scales, the odd ones the zeros)
+    const int8_t* const m_base = WN > 2 ? ((wn & 1) ? zeros : scales8) + unit0 * 64 + lane * 4
+                                        : ((lane & 32) ? zeros : scales8) + unit0 * 64 + ((lane & 31) & (16 * WN - 1)) * 4;
 
     auto dma16 = [&](u32 voff, const void* sbase, u32 lds_addr) {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
         }
         if (MODE == 1) {
             const int8_t* src = m_base + (size_t)(u >> 1) * N;
-            const u32 ml = dst + ASTAGE + WSTAGE;
+            const u32 ml = dst + ASTAGE + WSTAGE + (WN > 2 ? (wn & 1) * MZ : 0);
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(ml) : "memory");
         }
     };
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
     }
     const uint8_t* const pair_ring = smem + (kg - hf) * ns * GSTAGE;
     const int w_rd = ASTAGE + wn * 2048 + tsel * 1024 + (((g >> 1) ^ tsel)) * 128 + c * 16 + (g & 1) * 8;   // + e*256
-    const int m_rd = ASTAGE + WSTAGE + wn * 64 + (tsel * 8 + c) * 4;                               // zeros at +128
+    const int m_rd = ASTAGE + WSTAGE + wn * 64 + (tsel * 8 + c) * 4;                               // zeros at + MZ
     struct Raw {
         v2u r[4];
         u32 sdw, zdw;
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
         q.zdw = 0;
         if (MODE == 1) {
             q.sdw = *reinterpret_cast<const u32*>(s + m_rd);
-            q.zdw = *reinterpret_cast<const u32*>(s + m_rd + 128);
+            q.zdw = *reinterpret_cast<const u32*>(s + m_rd + MZ);
         }
         return q;
     };
@@ -609,7 +620,7 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
                 int mblocks, int ksplit, int* slabs, unsigned* counters, hipStream_t stream) {
     auto kern = w4a8_gemm_ring<MT, WN, MODE, OUTK, KSPLIT>;
     constexpr int KG = 8 / WN;
-    constexpr int GSTAGE = 16 * MT * 64 + WN * 2048 + (MODE == 1 ? 256 : 0);
+    constexpr int GSTAGE = ring_gstage<MT, WN, MODE>();
     // ring depth: as deep as 144 KiB of LDS allows, never deeper than a group's stage count + 1.  At most 5: every
     // stage layer carries 16 KiB of weights per CU, and beyond 4 layers (64 KiB per CU, 16 MB over the chip) in flight
     // the stream no longer gains while the pipeline fill gets longer (depth sweep 3 / 4 / 5 / 6 at M = 16: o 8.9 / 6.7 /
@@ -678,7 +689,9 @@ int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, con
                                                                   out, M, N, K, mblocks, 1, nullptr, nullptr, stream)
 #define QS_RM(MODEV, OUTV)                              \
     do {                                                \
-        if (wn == 2) {                                  \
+        if (wn == 4) {                                  \
+            if (mt == 4) QS_R(4, 4, MODEV, OUTV);       \
+        } else if (wn == 2) {                           \
             if (mt == 4) QS_R(4, 2, MODEV, OUTV);       \
             if (mt == 2) QS_R(2, 2, MODEV, OUTV);       \
         } else {                                        \

@@ -116,7 +116,9 @@ RING = [(4111, 16, 64, 1024), (4111, 40, 512, 2048), (4121, 23, 64, 1024), (4121
         (4422, 32, 256, 2048), (4442, 64, 128, 4096), (4411, 9, 192, 4096),
         # odd numbers of stages per K-group (K/64 not a multiple of 2*groups), down to a single stage
         (4122, 30, 128, 768), (4111, 16, 64, 1536), (4142, 64, 128, 256), (4121, 20, 64, 512), (4222, 33, 256, 1536),
-        (4122, 64, 256, 11008)]
+        (4122, 64, 256, 11008),
+        # four-unit workgroups (two K-groups): where 64 / 128 tokens meet many channels
+        (4144, 64, 256, 1024), (4144, 128, 512, 4096), (4144, 100, 256, 256), (4244, 64, 512, 2048), (4144, 37, 256, 11008)]
 
 
 @pytest.mark.parametrize("variant,M,N,K", RING)
