@@ -10,7 +10,8 @@
 //     (8 x 16 dims) in registers for the whole key loop;
 //   * key/value tiles of 64 keys are staged through LDS once per workgroup (shared by the 4 waves; the G query heads
 //     of a GQA group are separate workgroups that re-read the tiles from L2): K row-major with a 16-byte XOR swizzle,
-//     V row-major too (16-byte swizzle by key & 3) and TRANSPOSED ON READ by ds_read_b64_tr_b16, both tiles
+//     V row-major too (16-byte chunk ^ 4 (key & 3): the 32 lanes of a transpose read then hit 32 distinct 8-byte slots;
+//     chunk ^ 2 (key & 3), the round-1 form, left them two-way conflicted - SQ_LDS_BANK_CONFLICT was a third of the LDS cycles) and TRANSPOSED ON READ by ds_read_b64_tr_b16, both tiles
 //     double-buffered, one barrier per tile;
 //   * "swapped" products on v_mfma_f32_32x32x16_f16:  S^T = K Q^T  (A = K rows, B = Q rows, both plain 16-byte reads)
 //     leaves every lane holding 16 of the 32 scores of ITS OWN query row, so the softmax is register-only (one
@@ -45,6 +46,14 @@ __device__ __forceinline__ u32 pack_h2(float a, float b) {
     return __builtin_bit_cast(u32, v);
 }
 
+#ifdef QS_FLASH_TRACE
+// timing builds only (scripts/trace_flash.py): cycles per phase of the key loop, summed per wave
+__device__ unsigned long long* g_flash_trace = nullptr;
+#define QS_FT(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ft[i] += (unsigned)(n_ - ft_t); ft_t = n_; } while (0)
+#else
+#define QS_FT(i) do { } while (0)
+#endif
+
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, QS_FLASH_OCC) void flash_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
                                                           const _Float16* __restrict__ v, _Float16* __restrict__ out,
@@ -58,7 +67,10 @@ __global__ __launch_bounds__(256, QS_FLASH_OCC) void flash_fwd_kernel(const _Flo
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
+    // grid = (heads, sequences, query tiles): the query tile is the SLOWEST index and, for causal launches, reversed - the
+    // workgroups that see the most keys are dispatched first (longest-first keeps the tail of the launch short), and the
+    // G heads of a KV group run next to each other and share its K / V tiles through L2
+    const int h = blockIdx.x, b = blockIdx.y, qt = CAUSAL ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
     const int q_start = cu_q[b], len_q = cu_q[b + 1] - q_start;
     const int k_start = cu_k[b], len_k = cu_k[b + 1] - k_start;
     if (qt * BM >= len_q) return;
@@ -84,31 +96,47 @@ __global__ __launch_bounds__(256, QS_FLASH_OCC) void flash_fwd_kernel(const _Flo
     }
     const int ntiles = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
 
-    // ---- tile staging: thread t moves pieces t, t+256, t+512, t+768 (piece = key * 16 + 16-byte chunk) ----------------
+    // ---- tile staging by LDS-DMA: a 1 KiB piece = 4 keys x 256 B; wave w copies K pieces 4w .. 4w+3 and the same V pieces.
+    // The DMA writes lane-linear (lane l -> key l >> 4 of the piece, 16-byte position l & 15), so the XOR swizzles of the
+    // images are applied to the per-lane SOURCE chunk.  No staging registers, no ds_write pass; keys beyond the sequence
+    // are clamped to its last row (finite data; their scores are masked, their probabilities are 0).
     const _Float16* kg = k + (size_t)k_start * k_stride0 + (size_t)hkv * DH;
     const _Float16* vg = v + (size_t)k_start * v_stride0 + (size_t)hkv * DH;
-    v4u kreg[2 * NKB], vreg[2 * NKB];
-    auto load_tile = [&](int t) {
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const u32 lds_k = (u32)(size_t)(lptr_t)smem, lds_v = lds_k + 2 * KS_BYTES;
+    // scalar base (advances by one tile) + per-lane 32-bit byte offset (constant): no per-lane 64-bit arithmetic per piece
+    auto dma16 = [&](u32 voff, const void* sbase, u32 lds_addr) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+    };
+    static_assert(NKB == 2, "the DMA staging below is written for 64-key tiles");
+    u32 koff[4], voff[4];
 #pragma unroll
-        for (int i = 0; i < 2 * NKB; ++i) {
-            const int idx = tid + 256 * i, key = idx >> 4, ch = idx & 15;
-            const int kk = t * BN + key;
-            if (kk < len_k) {
-                kreg[i] = *reinterpret_cast<const v4u*>(kg + (size_t)kk * k_stride0 + ch * 8);
-                vreg[i] = *reinterpret_cast<const v4u*>(vg + (size_t)kk * v_stride0 + ch * 8);
-            } else {
-                kreg[i] = (v4u){0, 0, 0, 0};
-                vreg[i] = (v4u){0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+        const int key = 16 * wave + 4 * i + (lane >> 4), pos = lane & 15;
+        koff[i] = (u32)key * (u32)k_stride0 * 2u + (u32)((pos ^ (key & 15)) * 16);
+        voff[i] = (u32)key * (u32)v_stride0 * 2u + (u32)((pos ^ ((key & 3) << 2)) * 16);
+    }
+    auto load_tile = [&](int t, int buf) {
+        const _Float16* kb_ = kg + (size_t)t * BN * k_stride0;
+        const _Float16* vb_ = vg + (size_t)t * BN * v_stride0;
+        const bool ragged = t * BN + BN > len_k;        // wave-uniform: only the last tile of a sequence
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32 ko = koff[i], vo = voff[i];
+            if (ragged) {                                 // clamp the row to the sequence's last key
+                const int key = 16 * wave + 4 * i + (lane >> 4), pos = lane & 15;
+                int kc = len_k - 1 - t * BN;
+                kc = key < kc ? key : kc;
+                ko = (u32)kc * (u32)k_stride0 * 2u + (u32)((pos ^ (key & 15)) * 16);
+                vo = (u32)kc * (u32)v_stride0 * 2u + (u32)((pos ^ ((key & 3) << 2)) * 16);
             }
+            dma16(ko, kb_, lds_k + buf * KS_BYTES + (4 * wave + i) * 1024);
+            dma16(vo, vb_, lds_v + buf * VT_BYTES + (4 * wave + i) * 1024);
         }
     };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2 * NKB; ++i) {
-            const int idx = tid + 256 * i, key = idx >> 4, ch = idx & 15;
-            *reinterpret_cast<v4u*>(&s_k[buf][key * 256 + ((ch ^ (key & 15)) * 16)]) = kreg[i];
-            *reinterpret_cast<v4u*>(&s_vt[buf][key * 256 + ((ch ^ ((key & 3) << 1)) * 16)]) = vreg[i];
-        }
+    auto tiles_landed = [&]() {                       // every wave's pieces: own queue drained, then the barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     };
 
     v16f oacc[4];
@@ -118,34 +146,91 @@ __global__ __launch_bounds__(256, QS_FLASH_OCC) void flash_fwd_kernel(const _Flo
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    if (ntiles > 0) {
-        load_tile(0);
-        store_tile(0);
-    }
-    __syncthreads();
+    if (ntiles > 0) load_tile(0, 0);
+    tiles_landed();
+#ifdef QS_FLASH_STAGGER
+    // experiment: the two workgroups of a CU run identical code with identical timing and can settle in lockstep (both in
+    // their MFMA phase, then both in their VALU phase); delay every other workgroup by about half a tile
+    if ((blockIdx.x ^ blockIdx.y ^ blockIdx.z) & 1)
+        for (int i = 0; i < QS_FLASH_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
+#endif
 
+#ifdef QS_FLASH_TRACE
+    unsigned ft[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ft_t = __builtin_amdgcn_s_memtime();
+#endif
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
-        if (!(QS_FLASH_DBG & 8) && t + 1 < ntiles) load_tile(t + 1);          // global loads in flight during the MFMAs below
+        QS_FT(0);
+        if (!(QS_FLASH_DBG & 8) && t + 1 < ntiles) load_tile(t + 1, buf ^ 1);   // lands in the other buffers during this tile
+        // causal: the workgroup's key range ends at its LAST row's diagonal; a wave whose 32 rows all lie before this tile
+        // has nothing to add (every score masked) - it only takes part in the staging and the barrier
+        if (CAUSAL && t * BN > qt * BM + wave * 32 + 31 + shift) {
+            tiles_landed();
+            continue;
+        }
 
         // ---------------- S^T = K Q^T : two blocks of 32 keys ----------------
+        // operand reads run one group of 4 MFMAs ahead of the matrix pipe (two register sets): issued as written, they
+        // leave the compiler no choice but counted lgkmcnt waits - with read-then-use in one loop body every MFMA sat behind
+        // a full LDS round trip
         v16f sacc[NKB];
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-            const int key = 32 * kb + li;
-            const uint8_t* krow = &s_k[buf][key * 256];
-            if (!(QS_FLASH_DBG & 4)) {
+        if (!(QS_FLASH_DBG & 4)) {
+            h8 ka[2][4];
+            auto read_k = [&](int g, h8 (&dst)[4]) {       // group g = (kb = g >> 1, s = 4 (g & 1) .. +3)
+                const int key = 32 * (g >> 1) + li;
+                const uint8_t* krow = &s_k[buf][key * 256];
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    const h8 ka = *reinterpret_cast<const h8*>(krow + (((2 * s + hi) ^ (key & 15)) * 16));
-                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qf[s], sacc[kb], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    const int sl = 4 * (g & 1) + j;
+                    dst[j] = *reinterpret_cast<const h8*>(krow + (((2 * sl + hi) ^ (key & 15)) * 16));
                 }
-            } else {
-                sacc[kb][0] = (float)qf[kb][0];
+            };
+            read_k(0, ka[0]);
+            read_k(1, ka[1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    sacc[g >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[g & 1][j], qf[4 * (g & 1) + j], sacc[g >> 1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 2 < 4) read_k(g + 2, ka[g & 1]);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        } else {
+            sacc[0][0] = (float)qf[0][0];
         }
+        // A operands of O^T += V^T P^T by the LDS transpose read: a 16-lane group (16 consecutive dims, one lane half) reads
+        // the [4 keys][16 dims] block of the row-major tile - lane a supplies the 8-byte piece (key a>>2, dims 4(a&3)..+3) -
+        // and lane c receives column c = (dim c, keys 0..3), i.e. exactly its four k-slots of the PV MFMA.  Group d = the
+        // four MFMAs of output dims 32d .. 32d+31; group 0 is requested here, under the softmax.
+        const int ta = lane & 15, g1 = (lane >> 4) & 1;
+        const int tkey = 4 * hi + (ta >> 2);                       // key within a 16-key block; tkey & 3 == ta >> 2
+        h8 va[2][4];
+        auto read_v = [&](int d, h8 (&dst)[4]) {
+            const int chunk = (4 * d + 2 * g1 + ((ta & 3) >> 1)) ^ ((ta >> 2) << 2);   // V image swizzle: chunk ^ 4 (key & 3)
+            const uint8_t* vrow = &s_vt[buf][tkey * 256 + chunk * 16 + (ta & 1) * 8];
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int kofs = (32 * kb + 16 * m) * 256;
+                    typedef short s4 __attribute__((ext_vector_type(4)));
+                    typedef __attribute__((address_space(3))) s4* lds_s4;
+                    const s4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(vrow + kofs));             // keys +0..3
+                    const s4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(vrow + kofs + 8 * 256));   // keys +8..11
+                    const v2u lo = __builtin_bit_cast(v2u, t0), hi2 = __builtin_bit_cast(v2u, t1);
+                    dst[2 * kb + m] = __builtin_bit_cast(h8, (v4u){lo.x, lo.y, hi2.x, hi2.y});
+                }
+        };
+        QS_FT(1);                                                  // DMA issue + Q.K^T
+        if (!(QS_FLASH_DBG & 2)) read_v(0, va[0]);
+        __builtin_amdgcn_sched_barrier(0);
         // sacc[kb][r] = score of (this lane's row, key t*64 + 32kb + (r&3) + 8(r>>2) + 4hi)
         // masking only where the tile touches the diagonal or the end of the keys (wave-uniform test); raw scores
         // stay unscaled, the scale is folded into the exponent's fma
@@ -198,35 +283,38 @@ __global__ __launch_bounds__(256, QS_FLASH_OCC) void flash_fwd_kernel(const _Flo
                 for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
         }
 
+        QS_FT(2);                                                  // mask + softmax + O rescale
         // ---------------- O^T += V^T P^T ----------------
-        // A = V^T fragments by the LDS transpose read: a 16-lane group (16 consecutive dims, one lane half) reads the
-        // [4 keys][16 dims] block of the row-major tile - lane a supplies the 8-byte piece (key a>>2, dims 4(a&3)..+3) - and
-        // lane c receives column c = (dim c, keys 0..3), i.e. exactly its four k-slots of the PV MFMA.
-        const int ta = lane & 15, g1 = (lane >> 4) & 1;
-        const int tkey = 4 * hi + (ta >> 2);                       // key within a 16-key block; tkey & 3 == ta >> 2
-        if (QS_FLASH_DBG & 2) oacc[0][0] += __builtin_bit_cast(float, pb[0][0][0] ^ pb[NKB - 1][1][3]);
+        if (QS_FLASH_DBG & 2) {
+            oacc[0][0] += __builtin_bit_cast(float, pb[0][0][0] ^ pb[NKB - 1][1][3]);
+        } else {
+            read_v(1, va[1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int d = 0; d < ((QS_FLASH_DBG & 2) ? 0 : 4); ++d) {
-            const int chunk = (4 * d + 2 * g1 + ((ta & 3) >> 1)) ^ ((ta >> 2) << 1);
-            const uint8_t* vrow = &s_vt[buf][tkey * 256 + chunk * 16 + (ta & 1) * 8];
+            for (int d = 0; d < 4; ++d) {
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb)
+                for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int kofs = (32 * kb + 16 * m) * 256;
-                    typedef short s4 __attribute__((ext_vector_type(4)));
-                    typedef __attribute__((address_space(3))) s4* lds_s4;
-                    const s4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(vrow + kofs));             // keys +0..3
-                    const s4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(vrow + kofs + 8 * 256));   // keys +8..11
-                    const v2u lo = __builtin_bit_cast(v2u, t0), hi2 = __builtin_bit_cast(v2u, t1);
-                    const h8 va = __builtin_bit_cast(h8, (v4u){lo.x, lo.y, hi2.x, hi2.y});
-                    const h8 pbv = __builtin_bit_cast(h8, (v4u){pb[kb][m][0], pb[kb][m][1], pb[kb][m][2], pb[kb][m][3]});
-                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pbv, oacc[d], 0, 0, 0);
-                }
+                    for (int m = 0; m < 2; ++m) {
+                        const h8 pbv = __builtin_bit_cast(h8, (v4u){pb[kb][m][0], pb[kb][m][1], pb[kb][m][2], pb[kb][m][3]});
+                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[d & 1][2 * kb + m], pbv, oacc[d], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                if (d + 2 < 4) read_v(d + 2, va[d & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (!(QS_FLASH_DBG & 8) && t + 1 < ntiles) store_tile(buf ^ 1);
-        __syncthreads();
+        QS_FT(3);                                                  // P.V
+        tiles_landed();
+        QS_FT(4);                                                  // wait for the next tile + barrier
     }
+#ifdef QS_FLASH_TRACE
+    if (g_flash_trace && lane == 0) {
+        unsigned long long* o = g_flash_trace + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = ft[i];
+        o[5] = ntiles;
+    }
+#endif
 
     // ---- epilogue: normalise, fp16, 8-byte stores (4 consecutive dims per accumulator quad) ---------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -247,6 +335,13 @@ __global__ __launch_bounds__(256, QS_FLASH_OCC) void flash_fwd_kernel(const _Flo
 
 }  // namespace
 
+#ifdef QS_FLASH_TRACE
+extern "C" int qs_debug_flash_trace(void* buf) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_flash_trace), &p, sizeof(p));
+}
+#endif
+
 extern "C" int qs_flash_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out,
                                         const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int batch,
                                         int num_heads, int num_kv_heads, int head_dim, int64_t q_stride0,
@@ -265,8 +360,11 @@ extern "C" int qs_flash_attn_varlen_fwd(const void* q, const void* k, const void
     QS_REQUIRE(softmax_scale > 0.f, "flash_attn_varlen: softmax_scale must be positive");
     if (batch == 0 || max_seqlen_q == 0) return QS_OK;
     const float scale_log2 = softmax_scale * 1.4426950408889634f;
-    dim3 grid((max_seqlen_q + BM - 1) / BM, num_heads, batch);
-    constexpr int SMEM = 2 * KS_BYTES + 2 * VT_BYTES;
+    dim3 grid(num_heads, batch, (max_seqlen_q + BM - 1) / BM);
+#ifndef QS_FLASH_LDSPAD
+#define QS_FLASH_LDSPAD 0
+#endif
+    constexpr int SMEM = 2 * KS_BYTES + 2 * VT_BYTES + QS_FLASH_LDSPAD;   // (pad: occupancy experiments)
     static bool configured_dev[QS_MAX_DEVICES] = {};   // the attribute belongs to the (kernel, device) pair
     bool& configured = configured_dev[qs_device_slot()];
     if (!configured) {
