@@ -29,7 +29,12 @@ typedef u32 v2u __attribute__((ext_vector_type(2)));
 #define QS_FLASH_DBG 0            // timing experiments (scripts/bench_flash.py; results wrong): 1 no exp2, 2 no P.V, 4 no Q.K^T, 8 no tile loads
 #endif
 constexpr int DH = 128;
-constexpr int BM = 128;           // query rows per workgroup
+#ifndef QS_FLASH_NW
+#define QS_FLASH_NW 4
+#endif
+constexpr int NWV = QS_FLASH_NW;  // waves per workgroup (32 query rows each)
+constexpr int BM = 32 * NWV;      // query rows per workgroup
+constexpr int PPW = 16 / NWV;     // 1 KiB DMA pieces of a K (and of a V) tile per wave
 #ifndef QS_FLASH_NKB
 #define QS_FLASH_NKB 2
 #endif
@@ -55,7 +60,7 @@ __device__ unsigned long long* g_flash_trace = nullptr;
 #endif
 
 template <bool CAUSAL>
-__global__ __launch_bounds__(256, QS_FLASH_OCC) void flash_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
+__global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
                                                           const _Float16* __restrict__ v, _Float16* __restrict__ out,
                                                           const int* __restrict__ cu_q, const int* __restrict__ cu_k,
                                                           int num_heads, int num_kv_heads, int64_t q_stride0,
@@ -109,10 +114,10 @@ __global__ __launch_bounds__(256, QS_FLASH_OCC) void flash_fwd_kernel(const _Flo
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
     };
     static_assert(NKB == 2, "the DMA staging below is written for 64-key tiles");
-    u32 koff[4], voff[4];
+    u32 koff[PPW], voff[PPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int key = 16 * wave + 4 * i + (lane >> 4), pos = lane & 15;
+    for (int i = 0; i < PPW; ++i) {
+        const int key = 4 * (PPW * wave + i) + (lane >> 4), pos = lane & 15;
         koff[i] = (u32)key * (u32)k_stride0 * 2u + (u32)((pos ^ (key & 15)) * 16);
         voff[i] = (u32)key * (u32)v_stride0 * 2u + (u32)((pos ^ ((key & 3) << 2)) * 16);
     }
@@ -121,17 +126,17 @@ __global__ __launch_bounds__(256, QS_FLASH_OCC) void flash_fwd_kernel(const _Flo
         const _Float16* vb_ = vg + (size_t)t * BN * v_stride0;
         const bool ragged = t * BN + BN > len_k;        // wave-uniform: only the last tile of a sequence
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < PPW; ++i) {
             u32 ko = koff[i], vo = voff[i];
             if (ragged) {                                 // clamp the row to the sequence's last key
-                const int key = 16 * wave + 4 * i + (lane >> 4), pos = lane & 15;
+                const int key = 4 * (PPW * wave + i) + (lane >> 4), pos = lane & 15;
                 int kc = len_k - 1 - t * BN;
                 kc = key < kc ? key : kc;
                 ko = (u32)kc * (u32)k_stride0 * 2u + (u32)((pos ^ (key & 15)) * 16);
                 vo = (u32)kc * (u32)v_stride0 * 2u + (u32)((pos ^ ((key & 3) << 2)) * 16);
             }
-            dma16(ko, kb_, lds_k + buf * KS_BYTES + (4 * wave + i) * 1024);
-            dma16(vo, vb_, lds_v + buf * VT_BYTES + (4 * wave + i) * 1024);
+            dma16(ko, kb_, lds_k + buf * KS_BYTES + (PPW * wave + i) * 1024);
+            dma16(vo, vb_, lds_v + buf * VT_BYTES + (PPW * wave + i) * 1024);
         }
     };
     auto tiles_landed = [&]() {                       // every wave's pieces: own queue drained, then the barrier
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(256, QS_FLASH_OCC) void flash_fwd_kernel(const _Flo
     }
 #ifdef QS_FLASH_TRACE
     if (g_flash_trace && lane == 0) {
-        unsigned long long* o = g_flash_trace + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        unsigned long long* o = g_flash_trace + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NWV + wave) * 8;
         for (int i = 0; i < 5; ++i) o[i] = ft[i];
         o[5] = ntiles;
     }
@@ -379,11 +384,11 @@ extern "C" int qs_flash_attn_varlen_fwd(const void* q, const void* k, const void
         configured = true;
     }
     if (causal)
-        hipLaunchKernelGGL(flash_fwd_kernel<true>, grid, dim3(256), SMEM, (hipStream_t)stream, (const _Float16*)q,
+        hipLaunchKernelGGL(flash_fwd_kernel<true>, grid, dim3(64 * NWV), SMEM, (hipStream_t)stream, (const _Float16*)q,
                            (const _Float16*)k, (const _Float16*)v, (_Float16*)out, cu_seqlens_q, cu_seqlens_k, num_heads,
                            num_kv_heads, q_stride0, k_stride0, v_stride0, o_stride0, scale_log2);
     else
-        hipLaunchKernelGGL(flash_fwd_kernel<false>, grid, dim3(256), SMEM, (hipStream_t)stream, (const _Float16*)q,
+        hipLaunchKernelGGL(flash_fwd_kernel<false>, grid, dim3(64 * NWV), SMEM, (hipStream_t)stream, (const _Float16*)q,
                            (const _Float16*)k, (const _Float16*)v, (_Float16*)out, cu_seqlens_q, cu_seqlens_k, num_heads,
                            num_kv_heads, q_stride0, k_stride0, v_stride0, o_stride0, scale_log2);
     return qs_launch_status("flash_attn_varlen");

@@ -13,8 +13,9 @@ qkv = torch.randn((T, (H + 2 * Hkv) * 128), dtype=torch.float16, device=dev)
 q, k, v = qkv.split([H * 128, Hkv * 128, Hkv * 128], dim=-1)
 q, k, v = q.reshape(T, H, 128), k.reshape(T, Hkv, 128), v.reshape(T, Hkv, 128)
 cu = torch.arange(0, B + 1, dtype=torch.int32, device=dev) * L
-nq = (L + 127) // 128
-buf = torch.zeros((B * H * nq * 4 * 8,), dtype=torch.int64, device=dev)
+NW = int(os.environ.get("NW", "4"))
+nq = (L + 32 * NW - 1) // (32 * NW)
+buf = torch.zeros((B * H * nq * NW * 8,), dtype=torch.int64, device=dev)
 lib.qs_debug_flash_trace.argtypes = [ctypes.c_void_p]
 assert lib.qs_debug_flash_trace(buf.data_ptr()) == 0
 for _ in range(2):
