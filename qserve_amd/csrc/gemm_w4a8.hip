@@ -588,10 +588,15 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
 }  // namespace
 
 extern int g_tiled_dbg;   // gemm_w4a8_tiled.hip: timing experiments (3100 + bits)
+extern int g_tiled_order; // gemm_w4a8_tiled.hip: tile order A/B (3200 + mode)
 extern int g_ring_flags;  // gemm_w4a8_ring.hip: A/B switches of the decode kernel (5000 + bits), results unchanged
 extern "C" void qs_set_gemm_variant(int variant) {
     if (variant >= 3100 && variant < 3200) {
         g_tiled_dbg = variant - 3100;
+        return;
+    }
+    if (variant >= 3200 && variant < 3300) {
+        g_tiled_order = variant - 3200;
         return;
     }
     if (variant >= 5000 && variant < 7000) {

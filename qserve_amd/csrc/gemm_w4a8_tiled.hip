@@ -23,6 +23,7 @@
 #include <type_traits>
 
 int g_tiled_dbg = 0;   // qs_set_gemm_variant(3100 + bits): 1 no MFMA, 2 no DMA, 4 no operand reads, 8 no barrier
+int g_tiled_order = 0; // qs_set_gemm_variant(3200 + mode): tile order A/B (0 default, 1 M-fastest bands, 2 N-fastest bands)
 namespace {
 
 constexpr int NS = 6;                      // weight ring depth (stages of 64 k); the activation ring holds NS/2 stage pairs
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
                                                           const __half* __restrict__ ascales,
                                                           const __half* __restrict__ wszs,
                                                           const __half* __restrict__ assums, void* __restrict__ out,
-                                                          int M, int N, int K, int nbm) {
+                                                          int M, int N, int K, int nbm, int order) {
     constexpr int BM = 32 * MT;                       // tokens per workgroup
     constexpr int APAIR = BM * 128;                   // activation bytes per stage pair (128 k)
     constexpr int NA2 = APAIR / 8192;                 // 8 KiB all-thread DMA instructions per activation pair
@@ -108,9 +109,40 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 15, g = lane >> 4;
     const int tsel = li >> 3, c = li & 7;
-    // tile coordinates: consecutive workgroups walk M first inside a band of channels (weights of the band stay in L2).
-    // (an XCD-aware variant - every XCD owning a contiguous 4 x 2 super-tile of the grid - measured no better.)
-    const int bm = blockIdx.x % nbm, bn = blockIdx.x / nbm;
+    // tile coordinates
+    int bm, bn;
+    {
+        const int nbn = N / BN, id = blockIdx.x;
+        if (order == 1) {                                 // round-1 order: M fastest inside a band of channels
+            bm = id % nbm, bn = id / nbm;
+        } else if (order == 2) {                          // N fastest inside a band of tokens
+            bn = id % nbn, bm = id / nbn;
+        } else {
+            // 16 x 16 super-tiles (256 workgroups = one round of the chip): 16 activation tiles + 16 weight tiles = 24 MB at
+            // K = 4096 are fetched once per super-tile and re-served by L2 / the Infinity Cache, instead of every
+            // activation tile once per channel band (M = 65 536 x N = 28 672: 30 GB of activation reads -> ~3 GB)
+            const int sm = 16, sn = 16;
+            const int full_m = nbm / sm, rem_m = nbm % sm;        // super-rows; the last one may be narrower
+            const int per_row = sm * nbn;                         // workgroups per full super-row
+            int srow = id / per_row, in_row = id % per_row, hgt = sm;
+            if (srow >= full_m) {                                 // remainder rows: height rem_m
+                srow = full_m;
+                in_row = id - full_m * per_row;
+                hgt = rem_m;
+            }
+            const int per_st = hgt * sn;                          // workgroups per (full-width) super-tile of this row
+            int scol = in_row / per_st, in_st = in_row % per_st, wid = sn;
+            const int full_n = nbn / sn;
+            if (scol >= full_n) {                                 // last, narrower super-tile of the row
+                scol = full_n;
+                in_st = in_row - full_n * per_st;
+                wid = nbn % sn;
+            }
+            bm = srow * sm + in_st % hgt;
+            bn = scol * sn + in_st / hgt;
+            (void)wid;
+        }
+    }
     const int m0 = bm * BM, n0 = bn * BN;
     const int KT = K >> 5;
     const int nh = K >> 6;                            // stages (even: K % 128 == 0)
@@ -403,7 +435,7 @@ int launch_tiled(const int8_t* A, const uint8_t* W, const int8_t* zeros, const i
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, A, W, zeros, scales8,
                        reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
                        reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K,
-                       nbm);
+                       nbm, g_tiled_order);
     return qs_launch_status("w4a8 gemm (tiled)");
 }
 
