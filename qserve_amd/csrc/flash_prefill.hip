@@ -72,10 +72,15 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // grid = (heads, sequences, query tiles): the query tile is the SLOWEST index and, for causal launches, reversed - the
-    // workgroups that see the most keys are dispatched first (longest-first keeps the tail of the launch short), and the
-    // G heads of a KV group run next to each other and share its K / V tiles through L2
-    const int h = blockIdx.x, b = blockIdx.y, qt = CAUSAL ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
+    // grid = (heads, query tiles, sequences).  All workgroups of ONE sequence are dispatched next to each other (its K / V -
+    // 0.5 MB per KV head at 1024 tokens - are fetched from HBM once and re-served by L2 / the Infinity Cache to its
+    // query tiles and heads), inside a sequence the query tiles run last-to-first for causal launches (the workgroups that
+    // see the most keys start first: longest-first keeps the tail short), and the head index is permuted so that
+    // workgroups 8 apart - which share an XCD and its L2 - are the G heads of one KV group.
+    // (measured at 64 x 1024 / 4 x 8192 tokens: query tile fastest 417 / 740 TFLOP/s, query tile slowest 449 / 822, this
+    //  order 508 / 858)
+    const int b = blockIdx.z, qt = CAUSAL ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+    const int h = (int)(blockIdx.x % num_kv_heads) * (num_heads / num_kv_heads) + (int)(blockIdx.x / num_kv_heads);
     const int q_start = cu_q[b], len_q = cu_q[b + 1] - q_start;
     const int k_start = cu_k[b], len_k = cu_k[b + 1] - k_start;
     if (qt * BM >= len_q) return;
@@ -365,7 +370,7 @@ extern "C" int qs_flash_attn_varlen_fwd(const void* q, const void* k, const void
     QS_REQUIRE(softmax_scale > 0.f, "flash_attn_varlen: softmax_scale must be positive");
     if (batch == 0 || max_seqlen_q == 0) return QS_OK;
     const float scale_log2 = softmax_scale * 1.4426950408889634f;
-    dim3 grid(num_heads, batch, (max_seqlen_q + BM - 1) / BM);
+    dim3 grid(num_heads, (max_seqlen_q + BM - 1) / BM, batch);
 #ifndef QS_FLASH_LDSPAD
 #define QS_FLASH_LDSPAD 0
 #endif
