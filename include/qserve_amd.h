@@ -88,6 +88,9 @@ int qs_w8a8_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscal
  *   4100 + 100*(k_slices-1) + 10*m_tiles + units ... forced ring geometry;
  *   5000 + bits ... A/B switches of the ring kernel (1: weight DMA without the non-temporal hint; 256 * d: ring depth d;
  *                   32 / 64: TIMING ONLY, wrong results - no MFMA / no operand reads); sticky until reset with 5000;
+ *   3200 + 10*p + o ... tiled kernel A/B, sticky until reset with 3200: tile order o (0 super-tiles, 1 / 2 token- /
+ *                   channel-fastest bands); p = 1 one workgroup per tile instead of one per CU walking the tiles,
+ *                   p = 2 three workgroups walk all tiles (tests of the tile-to-tile hand-over);
  *   3100 + bits ... TIMING EXPERIMENTS ONLY (kernel parts switched off, results are wrong by design). */
 void qs_set_gemm_variant(int variant);
 

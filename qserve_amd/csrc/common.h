@@ -43,6 +43,18 @@ static inline int qs_device_slot() {
     return d;
 }
 
+// compute units of the current device (cached per device; 256 on MI355X)
+static inline int qs_num_cus() {
+    static int cus[QS_MAX_DEVICES] = {};
+    int& n = cus[qs_device_slot()];
+    if (n == 0) {
+        int d = 0, v = 0;
+        (void)hipGetDevice(&d);
+        n = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && v > 0 ? v : 256;
+    }
+    return n;
+}
+
 // wave64 reductions -------------------------------------------------------------------------------
 // The classic xor butterfly (offsets 32, 16, 8, 4, 2, 1; every lane ends with the result) with the SAME pairing and the
 // same order of operations as a __shfl_xor loop - so fp32 sums round identically, bit for bit - but without its six

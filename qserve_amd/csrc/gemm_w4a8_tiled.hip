@@ -23,7 +23,8 @@
 #include <type_traits>
 
 int g_tiled_dbg = 0;   // qs_set_gemm_variant(3100 + bits): 1 no MFMA, 2 no DMA, 4 no operand reads, 8 no barrier
-int g_tiled_order = 0; // qs_set_gemm_variant(3200 + mode): tile order A/B (0 default, 1 M-fastest bands, 2 N-fastest bands)
+int g_tiled_order = 0; // qs_set_gemm_variant(3200 + 10 * p + mode): tile order A/B (mode 0 default, 1 M-fastest bands, 2 N-fastest
+                       // bands); p = 1: one workgroup per tile instead of per CU, p = 2: three workgroups walk all tiles (tests)
 namespace {
 
 constexpr int NS = 6;                      // weight ring depth (stages of 64 k); the activation ring holds NS/2 stage pairs
@@ -109,10 +110,12 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 15, g = lane >> 4;
     const int tsel = li >> 3, c = li & 7;
-    // tile coordinates
-    int bm, bn;
-    {
-        const int nbn = N / BN, id = blockIdx.x;
+    // A workgroup walks the tiles id = blockIdx.x, + gridDim.x, ... (PERSIST: one workgroup per CU, the next tile's pipeline
+    // fill is issued before this tile's epilogue; otherwise gridDim.x = number of tiles and the loop runs once)
+    constexpr bool PERSIST = MT == 8 && OUTK == 0 && !(DBG & 2);
+    const int ntiles = nbm * (N / BN);
+    auto tile_coords = [&](int id, int& bm, int& bn) {
+        const int nbn = N / BN;
         if (order == 1) {                                 // round-1 order: M fastest inside a band of channels
             bm = id % nbm, bn = id / nbm;
         } else if (order == 2) {                          // N fastest inside a band of tokens
@@ -142,8 +145,8 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
             bn = scol * sn + in_st / hgt;
             (void)wid;
         }
-    }
-    const int m0 = bm * BM, n0 = bn * BN;
+    };
+    int m0, n0;                                       // current tile (of the DMA sources: runs one tile ahead at the end)
     const int KT = K >> 5;
     const int nh = K >> 6;                            // stages (even: K % 128 == 0)
 
@@ -160,22 +163,26 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     // (inline asm rather than __builtin_amdgcn_global_load_lds: the compiler books the builtin as a FLAT access and
     // from then on degrades every counted LDS wait in the loop to lgkmcnt(0))
     u32 a_off[NA2];
-#pragma unroll
-    for (int i = 0; i < NA2; ++i) {
-        const int P = lane >> 2, pa = P >> 2, q = P & 3;
-        const int half = (q >> 1) ^ (pa & 1);
-        const int r = (i * 8 + wave) * 8 + 2 * pa + (q & 1);      // tile row this lane copies in instruction i
-        int row = m0 + r;
-        row = row < M ? row : M - 1;
-        a_off[i] = (u32)row * (u32)K + half * 64 + (((lane & 3) ^ aswz((r >> 2) & 3)) * 16);
-    }
     u32 w_off;
-    {
+    const int8_t* m_base;
+    auto setup = [&](int id) {
+        int bm, bn;
+        tile_coords(id, bm, bn);
+        m0 = bm * BM, n0 = bn * BN;
+#pragma unroll
+        for (int i = 0; i < NA2; ++i) {
+            const int P = lane >> 2, pa = P >> 2, q = P & 3;
+            const int half = (q >> 1) ^ (pa & 1);
+            const int r = (i * 8 + wave) * 8 + 2 * pa + (q & 1);  // tile row this lane copies in instruction i
+            int row = m0 + r;
+            row = row < M ? row : M - 1;
+            a_off[i] = (u32)row * (u32)K + half * 64 + (((lane & 3) ^ aswz((r >> 2) & 3)) * 16);
+        }
         const int unit = wave >> 1, t = wave & 1;                  // this wave copies tile row 2*unit+t of the band
         const int e = lane >> 4, kk = ((lane >> 3) & 1) ^ t, cc = lane & 7;
         w_off = ((u32)(n0 / 32 + unit * 2 + t) * (u32)KT + kk) * 512u + cc * 64 + e * 16;
-    }
-    const int8_t* const m_base = ((wave & 1) ? zeros : scales8) + n0;
+        m_base = ((wave & 1) ? zeros : scales8) + n0;
+    };
     const u32 m_off = lane * 4;
     const u32 lds0 = (u32)(size_t)(lptr_t)smem;
 
@@ -246,13 +253,10 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     };
 
     v4i acc[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int cl = 0; cl < 4; ++cl) acc[mt][cl] = (v4i){0, 0, 0, 0};
+    v4i a0[4], a1[4], bq[PD];
 
-    // ---- prologue: weights of stages 0..NS-2 and two activation pairs in flight, operands of stage 0 in registers ----
-    if (!(DBG & 2)) {
+    // ---- pipeline fill: weights of stages 0..NS-2 and two activation pairs in flight --------------------------------
+    auto issue_fill = [&]() {
 #pragma unroll
         for (int i = 0; i < NW; ++i) issue_w(0, 0, i);
 #pragma unroll
@@ -266,17 +270,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
                     for (int i = 0; i < NW; ++i) issue_w(2 * q + t, 2 * q + t, i);
                 }
         }
-    }
-    wait_vm_dyn((DBG & 2) ? 0 : allowed(0));
-    raw_barrier();
-    v4i a0[4], a1[4], bq[PD];
-    {
-        const Raw q0 = read_w(0);
-#pragma unroll
-        for (int t = 0; t < PD; ++t) bq[t] = read_b(0, 0, t);
-#pragma unroll
-        for (int cl = 0; cl < 4; ++cl) a0[cl] = build(q0, cl);
-    }
+    };
 
     // One stage = 4*MT MFMAs of this wave.  `ac` holds the unpacked weight operands of stage u, `an` receives those of
     // stage u+1; bq is the rolling activation-operand buffer (tile t lives in bq[t % PD], PD divides MT).  PAR = u & 1.
@@ -321,92 +315,144 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     // wave's) while later stages stay in flight, and every wave is done reading stage u-1, whose slot is refilled next
     using c0 = std::integral_constant<int, 0>;
     using c1 = std::integral_constant<int, 1>;
-    int u = 0, slot = 0;
-    for (; u + NS < nh; u += 2) {                      // steady state: both stages of the pair prefetch, no branches
-        if (u) wait_vm<(DBG & 2) ? 0 : 3 * NW + NA2>();            // (u = 0: the prologue's wait and barrier)
-        if (u && !(DBG & 8)) raw_barrier();
-        stage(c0{}, std::true_type{}, true, true, u, slot, a0, a1);
-        slot = slot + 1 == NS ? 0 : slot + 1;
-        wait_vm<(DBG & 2) ? 0 : 3 * NW + NA2>();
-        if (!(DBG & 8)) raw_barrier();
-        stage(c1{}, std::true_type{}, true, true, u + 1, slot, a1, a0);
-        slot = slot + 1 == NS ? 0 : slot + 1;
-    }
-    for (; u < nh; u += 2) {                           // drain
-        if (u) {
-            wait_vm_dyn((DBG & 2) ? 0 : allowed(u));
-            raw_barrier();
-        }
-        stage(c0{}, std::false_type{}, u + 4 < nh, u + NS - 1 < nh, u, slot, a0, a1);
-        slot = slot + 1 == NS ? 0 : slot + 1;
-        wait_vm_dyn((DBG & 2) ? 0 : allowed(u + 1));
-        raw_barrier();
-        stage(c1{}, std::false_type{}, false, u + NS < nh, u + 1, slot, a1, a0);
-        slot = slot + 1 == NS ? 0 : slot + 1;
-    }
-
-    // ---- fused epilogue -----------------------------------------------------------------------------------------
-    // all scale loads first (one latency), then a store-only tail the memory pipe can stream
-    const int ncol0 = n0 + wn * 64 + 32 * (g >> 1) + 4 * (g & 1);
-    const int mrow0 = m0 + wm * (16 * MT) + li;
-    if (OUTK == 1) {
+    int tile = blockIdx.x;
+    setup(tile);
+    if (!(DBG & 2)) issue_fill();
+    bool first = true;
+    while (true) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = mrow0 + 16 * mt;
-            if (m >= M) continue;
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl) acc[mt][cl] = (v4i){0, 0, 0, 0};
+        // first tile: W(0), A(0), W(1) have landed, the rest of the fill stays in flight.  Later tiles: the fill was issued
+        // before the previous tile's epilogue - everything (its stores included) is complete
+        if (first) wait_vm_dyn((DBG & 2) ? 0 : allowed(0));
+        else wait_vm<0>();
+        first = false;
+        raw_barrier();
+        {
+            const Raw q0 = read_w(0);
+#pragma unroll
+            for (int t = 0; t < PD; ++t) bq[t] = read_b(0, 0, t);
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl) a0[cl] = build(q0, cl);
+        }
+        int u = 0, slot = 0;
+        for (; u + NS < nh; u += 2) {                  // steady state: both stages of the pair prefetch, no branches
+            if (u) wait_vm<(DBG & 2) ? 0 : 3 * NW + NA2>();        // (u = 0: the fill's wait and barrier)
+            if (u && !(DBG & 8)) raw_barrier();
+            stage(c0{}, std::true_type{}, true, true, u, slot, a0, a1);
+            slot = slot + 1 == NS ? 0 : slot + 1;
+            wait_vm<(DBG & 2) ? 0 : 3 * NW + NA2>();
+            if (!(DBG & 8)) raw_barrier();
+            stage(c1{}, std::true_type{}, true, true, u + 1, slot, a1, a0);
+            slot = slot + 1 == NS ? 0 : slot + 1;
+        }
+        for (; u < nh; u += 2) {                       // drain
+            if (u) {
+                wait_vm_dyn((DBG & 2) ? 0 : allowed(u));
+                raw_barrier();
+            }
+            stage(c0{}, std::false_type{}, u + 4 < nh, u + NS - 1 < nh, u, slot, a0, a1);
+            slot = slot + 1 == NS ? 0 : slot + 1;
+            wait_vm_dyn((DBG & 2) ? 0 : allowed(u + 1));
+            raw_barrier();
+            stage(c1{}, std::false_type{}, false, u + NS < nh, u + 1, slot, a1, a0);
+            slot = slot + 1 == NS ? 0 : slot + 1;
+        }
+
+        // ---- fused epilogue -------------------------------------------------------------------------------------
+        const int em0 = m0, en0 = n0;                  // (m0 / n0 move on to the next tile below)
+        const int next = tile + (int)gridDim.x;
+        const int ncol0 = en0 + wn * 64 + 32 * (g >> 1) + 4 * (g & 1);
+        const int mrow0 = em0 + wm * (16 * MT) + li;
+        if (OUTK == 1) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = mrow0 + 16 * mt;
+                if (m >= M) continue;
+#pragma unroll
+                for (int cl = 0; cl < 4; ++cl)
+                    *reinterpret_cast<v4i*>(reinterpret_cast<int*>(out) + (size_t)m * N + ncol0 + 8 * cl) = acc[mt][cl];
+            }
+            if (next >= ntiles) break;
+            raw_barrier();                             // every wave left the k loop: the rings may be refilled
+            tile = next;
+            setup(tile);
+            if (!(DBG & 2)) issue_fill();
+            continue;
+        }
+        // all scale loads first (one latency), converted and pinned BEFORE the next tile's fill is issued: a wait the
+        // compiler places after the fill would also wait for the fill (vmcnt retires in order)
+        float wsf[4][4], wzf[4][4], saf[MT], ssf[MT];
+        {
+            h4 ws4[4], wz4[4];
+            _Float16 sa_h[MT], ss_h[MT];
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl) {
+                ws4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wscales) + ncol0 + 8 * cl);
+                if (MODE == 0) wz4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wszs) + ncol0 + 8 * cl);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                int m = mrow0 + 16 * mt;
+                m = m < M ? m : M - 1;
+                sa_h[mt] = reinterpret_cast<const _Float16*>(ascales)[m];
+                if (MODE == 0) ss_h[mt] = reinterpret_cast<const _Float16*>(assums)[m];
+            }
 #pragma unroll
             for (int cl = 0; cl < 4; ++cl)
-                *reinterpret_cast<v4i*>(reinterpret_cast<int*>(out) + (size_t)m * N + ncol0 + 8 * cl) = acc[mt][cl];
-        }
-        return;
-    }
-    h4 ws4[4], wz4[4];
-    _Float16 sa_h[MT], ss_h[MT];
 #pragma unroll
-    for (int cl = 0; cl < 4; ++cl) {
-        ws4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wscales) + ncol0 + 8 * cl);
-        if (MODE == 0) wz4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wszs) + ncol0 + 8 * cl);
-    }
+                for (int r = 0; r < 4; ++r) {
+                    wsf[cl][r] = (float)ws4[cl][r];
+                    wzf[cl][r] = MODE == 0 ? (float)wz4[cl][r] : 0.f;
+                    asm volatile("" : "+v"(wsf[cl][r]), "+v"(wzf[cl][r]));
+                }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int m = mrow0 + 16 * mt;
-        m = m < M ? m : M - 1;
-        sa_h[mt] = reinterpret_cast<const _Float16*>(ascales)[m];
-        if (MODE == 0) ss_h[mt] = reinterpret_cast<const _Float16*>(assums)[m];
-    }
-    // fp16 tile of this wave (16*MT tokens x 64 channels) goes through LDS so that every store instruction writes
-    // whole 128-byte rows (the accumulator layout would scatter 8-byte pieces over 32 lines per instruction)
-    constexpr int RS = 144;                            // staged row stride (bytes): 128 + 16 keeps 16-byte alignment
-    raw_barrier();                                     // the rings are dead: every wave left the k loop
-    uint8_t* const st = smem + wave * (16 * MT * RS);
-    _Float16* const orow = reinterpret_cast<_Float16*>(out) + n0 + wn * 64 + (lane & 7) * 8;
-    // per m-tile: convert -> stage 16 rows -> store them, so that the 32 MB of output of a 4096^3 launch start leaving
-    // while the later m-tiles are still being converted (the staged rows of an m-tile are written and read by the same
-    // wave: an LDS wait, no barrier)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const float sa = (float)sa_h[mt];
-        const float ss = MODE == 0 ? (float)ss_h[mt] : 0.f;
-#pragma unroll
-        for (int cl = 0; cl < 4; ++cl) {
-            const v4i s = acc[mt][cl];
-            h4 o;
-            if (MODE == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(s[r], (float)ws4[cl][r], sa, (float)wz4[cl][r], ss);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(s[r], (float)ws4[cl][r], sa);
+            for (int mt = 0; mt < MT; ++mt) {
+                saf[mt] = (float)sa_h[mt];
+                ssf[mt] = MODE == 0 ? (float)ss_h[mt] : 0.f;
+                asm volatile("" : "+v"(saf[mt]), "+v"(ssf[mt]));
             }
-            *reinterpret_cast<h4*>(st + (16 * mt + li) * RS + (32 * (g >> 1) + 8 * cl + 4 * (g & 1)) * 2) = o;
         }
+        raw_barrier();                                 // the rings are dead: every wave left the k loop
+        if (PERSIST && next < ntiles) {                // next tile's fill: pair slots 0, 1 and weight slots 0..4
+            setup(next);
+            issue_fill();
+        }
+        // The fp16 tile of this wave goes through LDS, 16 tokens x 64 channels at a time, so that every store
+        // instruction writes whole 128-byte rows (the accumulator layout would scatter 8-byte pieces over 32 lines per
+        // instruction).  The staging rows live in activation pair slot 2, which the fill does not touch; they are
+        // written and read by the same wave: an LDS wait, no barrier.
+        constexpr int RS = 144;                        // staged row stride (bytes): 128 + 16 keeps 16-byte alignment
+        uint8_t* const st = a_ring + (PERSIST ? 2 * APAIR : 0) + wave * (16 * RS);
+        _Float16* const orow = reinterpret_cast<_Float16*>(out) + en0 + wn * 64 + (lane & 7) * 8;
 #pragma unroll
-        for (int i = 2 * mt; i < 2 * mt + 2; ++i) {
-            const int r = i * 8 + (lane >> 3);
-            const int m = m0 + wm * (16 * MT) + r;
-            const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane & 7) * 16);
-            if (m < M) *reinterpret_cast<v4u*>(orow + (size_t)m * N) = v;
+        for (int mt = 0; mt < MT; ++mt) {
+            const float sa = saf[mt], ss = ssf[mt];
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl) {
+                const v4i s = acc[mt][cl];
+                h4 o;
+                if (MODE == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(s[r], wsf[cl][r], sa, wzf[cl][r], ss);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(s[r], wsf[cl][r], sa);
+                }
+                *reinterpret_cast<h4*>(st + li * RS + (32 * (g >> 1) + 8 * cl + 4 * (g & 1)) * 2) = o;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = i * 8 + (lane >> 3);
+                const int m = em0 + wm * (16 * MT) + 16 * mt + r;
+                const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane & 7) * 16);
+                if (m < M) *reinterpret_cast<v4u*>(orow + (size_t)m * N) = v;
+            }
         }
+        if (!PERSIST || next >= ntiles) break;
+        tile = next;
     }
 }
 
@@ -416,9 +462,7 @@ int launch_tiled(const int8_t* A, const uint8_t* W, const int8_t* zeros, const i
                  hipStream_t stream) {
     auto kern = w4a8_gemm_tiled<MT, MODE, OUTK, DBG>;
     constexpr int BM = 32 * MT;
-    size_t smem = (size_t)NS * (BM * 64 + WSTAGE + 512);
-    const size_t stage_out = (size_t)8 * 16 * MT * 144;          // epilogue staging aliases the rings
-    if (smem < stage_out) smem = stage_out;
+    const size_t smem = (size_t)NS * (BM * 64 + WSTAGE + 512);   // (the epilogue's 18 KiB of staging rows alias the rings)
     static bool configured_dev[QS_MAX_DEVICES] = {};   // the attribute belongs to the (kernel, device) pair
     bool& configured = configured_dev[qs_device_slot()];
     if (!configured) {
@@ -431,11 +475,15 @@ int launch_tiled(const int8_t* A, const uint8_t* W, const int8_t* zeros, const i
         configured = true;
     }
     const int nbm = (M + BM - 1) / BM;
-    dim3 grid(nbm * (N / BN));
+    const int ntiles = nbm * (N / BN);
+    constexpr bool persist = MT == 8 && OUTK == 0 && !(DBG & 2);
+    const int cus = qs_num_cus();
+    const int pmode = g_tiled_order / 10;             // 0: one workgroup per CU, 1: one per tile, 2: three (tests)
+    dim3 grid(persist && pmode != 1 && ntiles > (pmode == 2 ? 3 : cus) ? (pmode == 2 ? 3 : cus) : ntiles);
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, A, W, zeros, scales8,
                        reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
                        reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K,
-                       nbm, g_tiled_order);
+                       nbm, g_tiled_order % 10);
     return qs_launch_status("w4a8 gemm (tiled)");
 }
 

@@ -87,6 +87,42 @@ def test_tiled_per_group_vs_oracle(gpu, tiled_variant, M, N, K, valid):
     assert ulp_diff_f16(out.cpu().numpy(), out_ref).max() == 0
 
 
+@pytest.mark.parametrize("mode", ["per_channel", "per_group"])
+@pytest.mark.parametrize("M,N,K", [(1000, 768, 512), (1281, 1024, 256), (700, 2560, 1152)])
+def test_tiled_workgroup_walks_several_tiles(gpu, mode, M, N, K):
+    """Variant 3220: three workgroups walk all the (256-token) tiles - the next tile's pipeline fill is issued before the
+    epilogue of the current one (what one workgroup per CU does at prompt sizes).  Same bits as one workgroup per tile
+    (3210) and as the oracle."""
+    import qserve_backend.qgemm_w4a8_per_chn as opc
+    import qserve_backend.qgemm_w4a8_per_group as opg
+    from qserve_amd import _lib
+    if mode == "per_channel":
+        pr = synth.per_channel_problem(M, N, K, seed=M + K)
+        _, out_ref = w4a8.gemm_per_chn(pr["A"], pr["qweight"], pr["wscales"], pr["ascales"], pr["w_szs"], pr["a_ssums"])
+        args = [dev(pr[k]) for k in ("A", "qweight", "wscales", "ascales", "w_szs", "a_ssums")]
+        fn = opc.gemm_forward_cuda
+    else:
+        pr = synth.per_group_problem(M, N, K, seed=M + K)
+        _, out_ref = w4a8.gemm_per_group(pr["A"], pr["qweight"], pr["s2_zeros"], pr["s2_scales"], pr["wscales"], pr["ascales"])
+        args = [dev(pr[k]) for k in ("A", "qweight", "s2_zeros", "s2_scales", "wscales", "ascales")]
+        fn = opg.gemm_forward_cuda
+    outs = []
+    try:
+        _lib.lib.qs_set_gemm_variant(3001)
+        for v in (3220, 3210):
+            _lib.lib.qs_set_gemm_variant(v)
+            out = torch.full((M + 2, N), float("nan"), dtype=torch.float16, device=gpu)
+            for _ in range(2):                         # twice: nothing is left behind in LDS or in the workspace
+                fn(*args, out[:M])
+            assert torch.isnan(out[M:]).all(), "rows beyond M were written"
+            outs.append(out[:M].cpu().numpy())
+    finally:
+        _lib.lib.qs_set_gemm_variant(3200)
+        _lib.lib.qs_set_gemm_variant(-1)
+    assert ulp_diff_f16(outs[0], out_ref).max() == 0
+    assert np.array_equal(outs[0].view(np.uint16), outs[1].view(np.uint16))
+
+
 def test_tiled_kernel_equals_decode_kernel(gpu):
     """Same problem through both code paths (variant 3000 = tiled kernel off, 3001 = forced with the 128-token tile)."""
     import qserve_backend.qgemm_w4a8_per_group as op
