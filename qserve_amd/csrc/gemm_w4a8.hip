@@ -426,7 +426,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
     const int units = N / 64;
     // compute-bound shapes (prefill): LDS-tiled kernel (gemm_w4a8_tiled.hip), 256- or 128-token tiles, taken once the
     // tiles fill the chip; variant 3000 disables it, 3001 / 3002 force the 256- / 128-token tile
-    if (N % 256 == 0 && K >= 256 && (size_t)M * K < (1ull << 32) && (size_t)N * K / 2 < (1ull << 32)) {
+    if (N % 256 == 0 && K >= 256 && K < (1 << 24) && (size_t)M * K < (1ull << 32) && (size_t)N * K / 2 < (1ull << 32)) {
         int tmt = 0;
         if (g_variant == 3001) tmt = 8;
         else if (g_variant == 3002) tmt = 4;

@@ -165,18 +165,19 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     u32 a_off[NA2];
     u32 w_off;
     const int8_t* m_base;
+    // instruction i of a wave copies tile rows (i*8 + wave)*8 .. +7: lane -> row a_r0 + 64 i, byte a_c inside the row's
+    // 128 k (the swizzle term (r >> 2) & 3 does not depend on i)
+    const int a_r0 = wave * 8 + 2 * (lane >> 4) + ((lane >> 2) & 1);
+    const u32 a_c = ((((lane >> 3) & 1) ^ ((lane >> 4) & 1)) * 64) + (((lane & 3) ^ aswz((a_r0 >> 2) & 3)) * 16);
     auto setup = [&](int id) {
         int bm, bn;
         tile_coords(id, bm, bn);
         m0 = bm * BM, n0 = bn * BN;
 #pragma unroll
         for (int i = 0; i < NA2; ++i) {
-            const int P = lane >> 2, pa = P >> 2, q = P & 3;
-            const int half = (q >> 1) ^ (pa & 1);
-            const int r = (i * 8 + wave) * 8 + 2 * pa + (q & 1);  // tile row this lane copies in instruction i
-            int row = m0 + r;
+            int row = m0 + a_r0 + 64 * i;
             row = row < M ? row : M - 1;
-            a_off[i] = (u32)row * (u32)K + half * 64 + (((lane & 3) ^ aswz((r >> 2) & 3)) * 16);
+            a_off[i] = __umul24((u32)row, (u32)K) + a_c;           // M, K < 2^24 and M * K < 2^32 (checked by the dispatcher)
         }
         const int unit = wave >> 1, t = wave & 1;                  // this wave copies tile row 2*unit+t of the band
         const int e = lane >> 4, kk = ((lane >> 3) & 1) ^ t, cc = lane & 7;
@@ -382,37 +383,32 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
             if (!(DBG & 2)) issue_fill();
             continue;
         }
-        // all scale loads first (one latency), converted and pinned BEFORE the next tile's fill is issued: a wait the
+        // all scale loads first (one latency), pinned as complete BEFORE the next tile's fill is issued: a wait the
         // compiler places after the fill would also wait for the fill (vmcnt retires in order)
-        float wsf[4][4], wzf[4][4], saf[MT], ssf[MT];
-        {
-            h4 ws4[4], wz4[4];
-            _Float16 sa_h[MT], ss_h[MT];
+        h4 ws4[4], wz4[4];
+        _Float16 sa_h[MT], ss_h[MT];
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl) {
+            ws4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wscales) + ncol0 + 8 * cl);
+            if (MODE == 0) wz4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wszs) + ncol0 + 8 * cl);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            int m = mrow0 + 16 * mt;
+            m = m < M ? m : M - 1;
+            sa_h[mt] = reinterpret_cast<const _Float16*>(ascales)[m];
+            if (MODE == 0) ss_h[mt] = reinterpret_cast<const _Float16*>(assums)[m];
+        }
+        if (PERSIST) {
 #pragma unroll
             for (int cl = 0; cl < 4; ++cl) {
-                ws4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wscales) + ncol0 + 8 * cl);
-                if (MODE == 0) wz4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wszs) + ncol0 + 8 * cl);
+                asm volatile("" : "+v"(ws4[cl]));
+                if (MODE == 0) asm volatile("" : "+v"(wz4[cl]));
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                int m = mrow0 + 16 * mt;
-                m = m < M ? m : M - 1;
-                sa_h[mt] = reinterpret_cast<const _Float16*>(ascales)[m];
-                if (MODE == 0) ss_h[mt] = reinterpret_cast<const _Float16*>(assums)[m];
-            }
-#pragma unroll
-            for (int cl = 0; cl < 4; ++cl)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    wsf[cl][r] = (float)ws4[cl][r];
-                    wzf[cl][r] = MODE == 0 ? (float)wz4[cl][r] : 0.f;
-                    asm volatile("" : "+v"(wsf[cl][r]), "+v"(wzf[cl][r]));
-                }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                saf[mt] = (float)sa_h[mt];
-                ssf[mt] = MODE == 0 ? (float)ss_h[mt] : 0.f;
-                asm volatile("" : "+v"(saf[mt]), "+v"(ssf[mt]));
+                asm volatile("" : "+v"(sa_h[mt]));
+                if (MODE == 0) asm volatile("" : "+v"(ss_h[mt]));
             }
         }
         raw_barrier();                                 // the rings are dead: every wave left the k loop
@@ -429,17 +425,18 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
         _Float16* const orow = reinterpret_cast<_Float16*>(out) + en0 + wn * 64 + (lane & 7) * 8;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const float sa = saf[mt], ss = ssf[mt];
+            const float sa = (float)sa_h[mt];
+            const float ss = MODE == 0 ? (float)ss_h[mt] : 0.f;
 #pragma unroll
             for (int cl = 0; cl < 4; ++cl) {
                 const v4i s = acc[mt][cl];
                 h4 o;
                 if (MODE == 0) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(s[r], wsf[cl][r], sa, wzf[cl][r], ss);
+                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(s[r], (float)ws4[cl][r], sa, (float)wz4[cl][r], ss);
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(s[r], wsf[cl][r], sa);
+                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(s[r], (float)ws4[cl][r], sa);
                 }
                 *reinterpret_cast<h4*>(st + li * RS + (32 * (g >> 1) + 8 * cl + 4 * (g & 1)) * 2) = o;
             }
