@@ -67,6 +67,22 @@ int qs_w4a8_per_group_gemm(const int8_t* in_feats, const int8_t* kernel, const i
                            const int8_t* scales_i8, const void* wscales, const void* ascales, void* out_feats,
                            int M, int N, int K, qs_stream_t stream);
 
+/* gate_up GEMM + silu_and_mul in one launch (engine-side fusion, like the pairs further down; no reference op of its
+ * own: the MLP of llama_w4a8_unpad.py:262-271 issues gate_up_proj, then activation_ops.silu_and_mul).
+ *   kernel   the stacked gate_up weight [N, K/2], rows 0 .. N/2-1 = gate, N/2 .. N-1 = up (load_weights' row
+ *            concatenation), consumed unchanged;   out_act half [M, N/2];
+ *   out_act[m, c] = half(float(silu_h(Y[m, c])) * float(Y[m, N/2 + c]))  with Y = the fp16 result of the plain GEMM entry
+ *            above on the same arguments - i.e. bit-identical to  qs_w4a8_*_gemm(..., tmp) ; qs_silu_and_mul(out_act, tmp).
+ *   tmp      half [M, N] scratch or NULL: shapes whose kernel family has no activation epilogue (K-sliced geometries,
+ *            the round-1 kernels) run as those two launches through it; NULL makes them an error.
+ * Requirements: those of the plain entries and N % 128 == 0. */
+int qs_w4a8_per_chn_gemm_silu_mul(const int8_t* in_feats, const int8_t* kernel, const void* wscales,
+                                  const void* ascales, const void* w_szs, const void* a_ssums, void* out_act, void* tmp,
+                                  int M, int N, int K, qs_stream_t stream);
+int qs_w4a8_per_group_gemm_silu_mul(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros,
+                                    const int8_t* scales_i8, const void* wscales, const void* ascales, void* out_act,
+                                    void* tmp, int M, int N, int K, qs_stream_t stream);
+
 /* Debug/parity entry points: same kernels, but the raw INT32 accumulators are written to acc_out [M,N]
  * instead of the fp16 epilogue (the reference keeps them in registers: gemm_cuda.cu:327). */
 int qs_w4a8_per_chn_gemm_acc(const int8_t* in_feats, const int8_t* kernel, int32_t* acc_out, int M, int N, int K,
@@ -91,6 +107,7 @@ int qs_w8a8_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscal
  *   3200 + 10*p + o ... tiled kernel A/B, sticky until reset with 3200: tile order o (0 super-tiles, 1 / 2 token- /
  *                   channel-fastest bands); p = 1 one workgroup per tile instead of one per CU walking the tiles,
  *                   p = 2 three workgroups walk all tiles (tests of the tile-to-tile hand-over);
+ *   3301 / 3300 ... qs_w4a8_*_gemm_silu_mul always as two launches / default (sticky);
  *   3100 + bits ... TIMING EXPERIMENTS ONLY (kernel parts switched off, results are wrong by design). */
 void qs_set_gemm_variant(int variant);
 

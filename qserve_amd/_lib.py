@@ -17,6 +17,8 @@ SIGNATURES = {
     "qs_w4a8_per_chn_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_w4a8_per_group_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_w4a8_per_chn_gemm_acc": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "qs_w4a8_per_chn_gemm_silu_mul": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "qs_w4a8_per_group_gemm_silu_mul": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_w4a8_per_group_gemm_acc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_w8a8_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_set_gemm_variant": (None, [_i]),

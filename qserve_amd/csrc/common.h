@@ -43,6 +43,13 @@ static inline int qs_device_slot() {
     return d;
 }
 
+// silu(x) rounded to fp16 with the hardware exp2 / rcp forms (what the reference's --use_fast_math build computes; see
+// fused_small.hip).  Shared by the row kernels and by the GEMM epilogue that applies silu * mul to gate_up.
+__device__ __forceinline__ _Float16 qs_silu_h(float xf) {
+    const float e = __builtin_amdgcn_exp2f(xf * -1.4426950408889634f);
+    return (_Float16)(xf * __builtin_amdgcn_rcpf(1.0f + e));
+}
+
 // compute units of the current device (cached per device; 256 on MI355X)
 static inline int qs_num_cus() {
     static int cus[QS_MAX_DEVICES] = {};

@@ -71,10 +71,7 @@ __device__ __forceinline__ h8 load8(const _Float16* p) { return *reinterpret_cas
 // hardware forms here (v_exp_f32, v_rcp_f32; ~1 ulp each, far below the fp16 rounding that follows).  The IEEE forms
 // (libm expf + correctly rounded division) cost 37 VALU instructions per element and made silu_and_mul(+quant) the
 // one VALU-bound row kernel: 7.0 us per decode launch, 1.13 ms per 65 536-token prompt layer.
-__device__ __forceinline__ _Float16 silu_h(float xf) {
-    const float e = __builtin_amdgcn_exp2f(xf * -1.4426950408889634f);
-    return (_Float16)(xf * __builtin_amdgcn_rcpf(1.0f + e));
-}
+__device__ __forceinline__ _Float16 silu_h(float xf) { return qs_silu_h(xf); }
 
 __device__ __forceinline__ void store_q8(int8_t* p, const float (&v)[8], float mul) { qs_store_q8(p, v, mul); }
 

@@ -402,10 +402,15 @@ int qs_launch_gemm_tiled(int mode, int outk, const int8_t* A, const uint8_t* W, 
                          const void* assums, void* out, int M, int N, int K, int mtile, hipStream_t stream);
 namespace {
 
+constexpr int QS_UNFUSED = 1 << 20;   // internal: the chosen kernel has no activation epilogue
+
 template <int MODE, int OUTK>
 int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
              const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K,
-             qs_stream_t stream_) {
+             qs_stream_t stream_, bool act = false) {
+    // act: `out` is [M, N/2] = silu(gate) * up of the stacked gate_up result (epilogue of the ring / tiled kernels,
+    // OUTK = 2 there); QS_UNFUSED when the shape is served by a kernel without that epilogue (the caller runs the two ops)
+    const int outk = act ? 2 : OUTK;
     QS_REQUIRE(M >= 0 && N > 0 && K > 0, "w4a8 gemm: bad shape M=%d N=%d K=%d", M, N, K);
     QS_REQUIRE(N % 64 == 0, "w4a8 gemm: N=%d must be a multiple of 64", N);
     QS_REQUIRE(K % 128 == 0, "w4a8 gemm: K=%d must be a multiple of 128", K);
@@ -439,7 +444,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
             else if (M >= 256 && ((M + 127) / 128) * nb >= (MODE == 0 ? 96 : 192)) tmt = 4;
         }
         if (tmt)
-            return qs_launch_gemm_tiled(MODE, OUTK, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,
+            return qs_launch_gemm_tiled(MODE, outk, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,
                                         tmt, stream);
     }
     // decode shapes: LDS-DMA ring kernel with operands read one stage ahead (gemm_w4a8_ring.hip); variant 4000
@@ -460,6 +465,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
     if (g_variant >= 4100 && g_variant < 4500) {       // tests: force geometry 4100 + 100*(ksplit-1) + 10*mt + wn
         const int v = g_variant - 4100, ks = v / 100 + 1, mt = (v % 100) / 10, wn = v % 10;
         const int mb = ((M + 15) / 16 + mt - 1) / mt;
+        if (act && ks > 1) return QS_UNFUSED;
         QS_REQUIRE((mt == 1 || mt == 2 || mt == 4) && (wn == 1 || wn == 2 || (wn == 4 && mt == 4)) &&
                        !(mt == 1 && wn == 2) &&
                        N % (64 * wn) == 0 && (K / 64) % ks == 0 && (K / 64 / ks) % (8 / wn) == 0,
@@ -468,7 +474,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         int* slabs = nullptr;
         unsigned* counters = nullptr;
         QS_REQUIRE(ring_ws(mt, mb, ks, &slabs, &counters), "w4a8 gemm: no split-K workspace for the forced geometry");
-        return qs_launch_gemm_ring(MODE, OUTK, mt, wn, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N,
+        return qs_launch_gemm_ring(MODE, outk, mt, wn, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N,
                                    K, mb, ks, slabs, counters, stream);
     }
     // Geometry choice (measured: scripts/bench_gemm.py for the Llama-3-8B shapes, scripts/bench_gemm_shard.py for the
@@ -492,7 +498,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         };
         long best = -1;
         int bmt = 0, bwn = 0, bks = 1;
-        for (int ks = 1; ks <= (g_variant == 4001 ? 1 : 4); ks *= 2)
+        for (int ks = 1; ks <= (g_variant == 4001 || act ? 1 : 4); ks *= 2)
             for (int i = 0; i < 6; ++i) {
                 const int mt = geo[i][0], wn = geo[i][1];
                 if (N % (64 * wn) != 0 || (K / 64) % ks != 0 || (K / 64 / ks) % (8 / wn) != 0) continue;
@@ -506,7 +512,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         // the older register-staged split-K kernel takes any K and cuts the tokens down to 16 per workgroup: same byte
         // model, ~20 % slower at equal bytes (measured) - it wins where K leaves the ring kernel only coarse geometries
         // (Llama-2-7B down_proj: K = 11 008 = 172 stages, two-unit workgroups only)
-        if (best >= 0 && units < 256 && units % 8 == 0 && M > 16 && M <= 128) {
+        if (best >= 0 && !act && units < 256 && units % 8 == 0 && M > 16 && M <= 128) {
             int mto = 1;
             for (int cand = 4; cand >= 1; cand >>= 1)
                 if (cand <= mt_all && (long)units * ((mt_all + cand - 1) / cand) >= 192) {
@@ -534,10 +540,11 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
                 mb = (mt_all + bmt - 1) / bmt;
             }
             if (best >= 0)
-                return qs_launch_gemm_ring(MODE, OUTK, bmt, bwn, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out,
+                return qs_launch_gemm_ring(MODE, outk, bmt, bwn, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out,
                                            M, N, K, mb, bks, slabs, counters, stream);
         }
     }
+    if (act) return QS_UNFUSED;
     // many channels: LDS-shared activation tiles + LDS-DMA rings (gemm_w4a8_lds.hip); variant 2000 forces the
     // split-K kernel, 2001 forces the LDS kernel (A/B tests)
     if ((((units >= 256 && M > 16) || M >= 384) && g_variant != 2000 || g_variant == 2001) && N % 128 == 0 && K >= 256)
@@ -590,6 +597,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
 extern int g_tiled_dbg;   // gemm_w4a8_tiled.hip: timing experiments (3100 + bits)
 extern int g_tiled_order; // gemm_w4a8_tiled.hip: tile order A/B (3200 + mode)
 extern int g_ring_flags;  // gemm_w4a8_ring.hip: A/B switches of the decode kernel (5000 + bits), results unchanged
+extern int g_act_off;
 extern "C" void qs_set_gemm_variant(int variant) {
     if (variant >= 3100 && variant < 3200) {
         g_tiled_dbg = variant - 3100;
@@ -597,6 +605,10 @@ extern "C" void qs_set_gemm_variant(int variant) {
     }
     if (variant >= 3200 && variant < 3300) {
         g_tiled_order = variant - 3200;
+        return;
+    }
+    if (variant == 3300 || variant == 3301) {
+        g_act_off = variant - 3300;
         return;
     }
     if (variant >= 5000 && variant < 7000) {
@@ -631,6 +643,43 @@ extern "C" int qs_w4a8_per_group_gemm(const int8_t* in_feats, const int8_t* kern
                                       void* out_feats, int M, int N, int K, qs_stream_t stream) {
     return dispatch<1, 0>(in_feats, kernel, zeros, scales_i8, wscales, ascales, nullptr, nullptr, out_feats, M, N, K,
                           stream);
+}
+
+// gate_up GEMM + silu_and_mul in one launch where the kernel family has the epilogue, as two launches through `tmp`
+// ([M, N] fp16) otherwise - bit-identical either way (the epilogue applies silu_and_mul's arithmetic to the fp16-rounded
+// GEMM outputs)
+int g_act_off = 0;   // qs_set_gemm_variant(3301 / 3300): always two launches / default (A/B, tests)
+namespace {
+template <int MODE>
+int gate_up_silu(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros, const int8_t* scales_i8,
+                 const void* wscales, const void* ascales, const void* w_szs, const void* a_ssums, void* out_act,
+                 void* tmp, int M, int N, int K, qs_stream_t stream) {
+    QS_REQUIRE(N > 0 && N % 128 == 0, "w4a8 gate_up + silu: N=%d must stack two multiples of 64 channels", N);
+    if (M == 0) return QS_OK;
+    QS_REQUIRE(out_act, "w4a8 gate_up + silu: null output");
+    int rc = g_act_off ? QS_UNFUSED
+                       : dispatch<MODE, 0>(in_feats, kernel, zeros, scales_i8, wscales, ascales, w_szs, a_ssums, out_act, M,
+                                           N, K, stream, true);
+    if (rc != QS_UNFUSED) return rc;
+    QS_REQUIRE(tmp, "w4a8 gate_up + silu: this shape needs the [M, N] fp16 scratch `tmp` (two launches)");
+    rc = dispatch<MODE, 0>(in_feats, kernel, zeros, scales_i8, wscales, ascales, w_szs, a_ssums, tmp, M, N, K, stream);
+    if (rc != QS_OK) return rc;
+    return qs_silu_and_mul(out_act, tmp, M, N / 2, stream);
+}
+}  // namespace
+
+extern "C" int qs_w4a8_per_chn_gemm_silu_mul(const int8_t* in_feats, const int8_t* kernel, const void* wscales,
+                                             const void* ascales, const void* w_szs, const void* a_ssums,
+                                             void* out_act, void* tmp, int M, int N, int K, qs_stream_t stream) {
+    return gate_up_silu<0>(in_feats, kernel, nullptr, nullptr, wscales, ascales, w_szs, a_ssums, out_act, tmp, M, N, K,
+                           stream);
+}
+
+extern "C" int qs_w4a8_per_group_gemm_silu_mul(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros,
+                                               const int8_t* scales_i8, const void* wscales, const void* ascales,
+                                               void* out_act, void* tmp, int M, int N, int K, qs_stream_t stream) {
+    return gate_up_silu<1>(in_feats, kernel, zeros, scales_i8, wscales, ascales, nullptr, nullptr, out_act, tmp, M, N, K,
+                           stream);
 }
 
 extern "C" int qs_w4a8_per_chn_gemm_acc(const int8_t* in_feats, const int8_t* kernel, int32_t* acc_out, int M, int N,

@@ -149,6 +149,13 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
         kq = sub / mblocks;
     }
     const int unit0 = nblk * WN;                      // first 64-channel unit of the workgroup
+    // OUTK == 2 (gate_up + silu * mul): N stacks [gate | up] (N/2 channels each); "unit" j then means gate channels
+    // 32 j .. + 31 as its 32-channel tile row t = 0 and up channels N/2 + 32 j .. as t = 1 - both values of an output
+    // element end up in one wave (lanes l and l + 32), and the workgroup writes 32 WN channels of the [M, N/2] result
+    constexpr bool ACT = OUTK == 2;
+    static_assert(!(ACT && KSPLIT), "the activation epilogue exists in the un-split form only");
+    auto trow = [&](int unit, int t) { return ACT ? (t ? N / 64 + unit : unit) : unit * 2 + t; };          // 32-channel tile row
+    auto chan32 = [&](int unit, int t) { return ACT ? (t ? N / 2 + 32 * unit : 32 * unit) : unit * 64 + 32 * t; };
     const int m0 = mblk * (16 * MT);
     const int KT = K >> 5;
     const int nst = (K >> 6) / ksplit;                // 64-k stages of this workgroup's K slice
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
         } else {
             const int q = p - MT, unit = q >> 1, t = q & 1;
             const int e = lane >> 4, kk = ((lane >> 3) & 1) ^ t, cc = lane & 7;
-            p_off[j] = ((u32)((unit0 + unit) * 2 + t) * (u32)KT + kk) * 512u + cc * 64 + e * 16;
+            p_off[j] = ((u32)trow(unit0 + unit, t) * (u32)KT + kk) * 512u + cc * 64 + e * 16;
             p_isw[j] = true;
             p_lds[j] = ASTAGE + q * 1024;
         }
@@ -199,8 +206,9 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
     // per-group meta: 16*WN dwords of scales (lanes 0-31) | zeros (lanes 32-63); surplus lanes repeat valid addresses
     // (WN <= 2: one instruction carries both, lanes 0-31 scales | 32-63 zeros; WN = 4: 64 dwords each - the even waves
     //  of a group fetch the scales, the odd ones the zeros)
-    const int8_t* const m_base = WN > 2 ? ((wn & 1) ? zeros : scales8) + unit0 * 64 + lane * 4
-                                        : ((lane & 32) ? zeros : scales8) + unit0 * 64 + ((lane & 31) & (16 * WN - 1)) * 4;
+    const int m_dw = WN > 2 ? lane : ((lane & 31) & (16 * WN - 1));    // dword of the workgroup's 16 WN (unit-major)
+    const int8_t* const m_base = (WN > 2 ? ((wn & 1) ? zeros : scales8) : ((lane & 32) ? zeros : scales8)) +
+                                 chan32(unit0 + (m_dw >> 4), (m_dw >> 3) & 1) + (m_dw & 7) * 4;
 
     auto dma16 = [&](u32 voff, const void* sbase, u32 lds_addr) {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
 #endif
 
     // ---- reduce the KG partial tiles through LDS, fused epilogue -----------------------------------------------------
-    const int ncol0 = (unit0 + wn) * 64 + 32 * (g >> 1) + 4 * (g & 1);
+    const int ncol0 = chan32(unit0 + wn, g >> 1) + 4 * (g & 1);
     constexpr int NP = MT * 4;                         // 16 x 16 result pieces per wave: piece pc = mt*4 + cl
     // DISTRIBUTED form (no K slices): piece pc is finished by K-group pc % KG - every group sums, scales and converts a
     // 1/KG share of the tile instead of groups 1..KG-1 handing everything to group 0 and leaving (timeline trace,
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
         _Float16 sa_h[PPG], ss_h[PPG];
         __syncthreads();                               // rings are dead (every wave drained its DMA queue)
         QS_STAMP(4);
-        if (OUTK == 0) {                               // scale operands of the OWN pieces, requested here: their latency hides under the exchange below (before the
+        if (OUTK != 1) {                               // scale operands of the OWN pieces, requested here: their latency hides under the exchange below (before the
                                                        // barrier the k loop's operand buffers are still live and the compiler spills)
 #pragma unroll
             for (int q = 0; q < PPG; ++q) {
@@ -429,8 +437,9 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
             }
         }
         __syncthreads();
-        constexpr int RS = 144;                        // staged fp16 row: 128 B + 16 (keeps 16-byte alignment)
-        uint8_t* const st = smem + (size_t)KG * WN * (KG - 1) * PPG * 1024 + wn * (16 * MT * RS);
+        constexpr int RS = ACT ? 64 * WN + 16 : 144;   // staged fp16 row: 128 B + 16 (keeps 16-byte alignment); ACT: the
+                                                       // workgroup's 32 WN result channels in one row
+        uint8_t* const st = smem + (size_t)KG * WN * (KG - 1) * PPG * 1024 + (ACT ? wn * 64 : wn * (16 * MT * RS));
 #pragma unroll
         for (int q = 0; q < PPG; ++q) {
 #pragma unroll
@@ -456,7 +465,22 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
 #pragma unroll
                             for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(sum[r], (float)ws4[q][r], sa);
                         }
-                        *reinterpret_cast<h4*>(st + (16 * mt + li) * RS + (32 * (g >> 1) + 8 * cl + 4 * (g & 1)) * 2) = o;
+                        if (ACT) {
+                            // lanes 0-31 hold the gate values, lanes 32-63 the up values of the same (token, channel):
+                            // silu_and_mul's arithmetic on the fp16-rounded GEMM outputs (activation_kernels.cu:11,21-32)
+                            const v2u ob = __builtin_bit_cast(v2u, o);
+                            // one swap hands every lane the pair it finishes: r[0] = (x of lanes 0-31 | y of lanes 0-31) = gate elements
+                            // 0, 1 for the lower half, 2, 3 for the upper; r[1] = (x | y of lanes 32-63) = the matching up elements
+                            const auto sw = __builtin_amdgcn_permlane32_swap(ob.x, ob.y, false, false);
+                            const h2 gt = __builtin_bit_cast(h2, (u32)sw[0]), up = __builtin_bit_cast(h2, (u32)sw[1]);
+                            const int hh = g >> 1;
+                            h2 a;
+                            a[0] = (_Float16)((float)qs_silu_h((float)gt[0]) * (float)up[0]);
+                            a[1] = (_Float16)((float)qs_silu_h((float)gt[1]) * (float)up[1]);
+                            *reinterpret_cast<h2*>(st + (16 * mt + li) * RS + (8 * cl + 4 * (g & 1) + 2 * hh) * 2) = a;
+                        } else {
+                            *reinterpret_cast<h4*>(st + (16 * mt + li) * RS + (32 * (g >> 1) + 8 * cl + 4 * (g & 1)) * 2) = o;
+                        }
                     }
                 }
             }
@@ -464,6 +488,20 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
         if (OUTK == 1) return;
         __syncthreads();                               // the fp16 tile of every unit is staged
         QS_STAMP(5);
+        if (ACT) {                                     // rows of 64 WN bytes, shared by all eight waves
+            constexpr int LPR = 4 * WN, RPI = 64 / LPR;                // lanes per row, rows per instruction
+            const uint8_t* const sa0 = smem + (size_t)KG * WN * (KG - 1) * PPG * 1024;
+            _Float16* const arow = reinterpret_cast<_Float16*>(out) + unit0 * 32 + (lane % LPR) * 8;
+#pragma unroll
+            for (int i = 0; i < 16 * MT / RPI; ++i) {
+                if (i % 8 != wave) continue;
+                const int r = i * RPI + lane / LPR;
+                const int m = m0 + r;
+                const v4u v = *reinterpret_cast<const v4u*>(sa0 + r * RS + (lane % LPR) * 16);
+                if (m < M) *reinterpret_cast<v4u*>(arow + (size_t)m * (N / 2)) = v;
+            }
+            return;
+        }
         _Float16* const orow = reinterpret_cast<_Float16*>(out) + (unit0 + wn) * 64 + (lane & 7) * 8;
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
@@ -476,6 +514,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
         QS_STAMP(6);
         return;
     }
+    if (ACT) return;                                   // (never instantiated with K slices)
     h4 ws4[4], wz4[4];
     _Float16 sa_h[MT], ss_h[MT];
     if (OUTK == 0 && kg == 0) {                        // requested now: their latency overlaps the reduction
@@ -682,6 +721,30 @@ int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, con
         g_qs_plan.p[0] = mt, g_qs_plan.p[1] = wn, g_qs_plan.p[2] = mblocks, g_qs_plan.p[3] = ksplit;
         return QS_OK;
     }
+#define QS_RA(MTV, WNV, MODEV)                                                                                       \
+    return launch_ring<MTV, WNV, MODEV, 2, false>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,    \
+                                                  mblocks, 1, nullptr, nullptr, stream)
+    if (outk == 2) {                                   // gate_up + silu * mul: un-split geometries only
+        if (ksplit > 1) {
+            qs_set_error("w4a8 gemm (ring): the activation epilogue has no K-sliced form");
+            return QS_ENOSUP;
+        }
+#define QS_RAM(MODEV)                                   \
+    do {                                                \
+        if (wn == 4 && mt == 4) QS_RA(4, 4, MODEV);     \
+        if (wn == 2 && mt == 4) QS_RA(4, 2, MODEV);     \
+        if (wn == 2 && mt == 2) QS_RA(2, 2, MODEV);     \
+        if (wn == 1 && mt == 4) QS_RA(4, 1, MODEV);     \
+        if (wn == 1 && mt == 2) QS_RA(2, 1, MODEV);     \
+        if (wn == 1 && mt == 1) QS_RA(1, 1, MODEV);     \
+    } while (0)
+        if (mode == 0) QS_RAM(0);
+        else QS_RAM(1);
+#undef QS_RAM
+        qs_set_error("w4a8 gemm (ring): unsupported geometry mt=%d wn=%d", mt, wn);
+        return QS_ENOSUP;
+    }
+#undef QS_RA
 #define QS_R(MTV, WNV, MODEV, OUTV)                                                                                   \
     return ksplit > 1 ? launch_ring<MTV, WNV, MODEV, OUTV, true>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, \
                                                                  M, N, K, mblocks, ksplit, slabs, counters, stream)      \

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     const int tsel = li >> 3, c = li & 7;
     // A workgroup walks the tiles id = blockIdx.x, + gridDim.x, ... (PERSIST: one workgroup per CU, the next tile's pipeline
     // fill is issued before this tile's epilogue; otherwise gridDim.x = number of tiles and the loop runs once)
-    constexpr bool PERSIST = MT == 8 && OUTK == 0 && !(DBG & 2);
+    constexpr bool PERSIST = MT == 8 && OUTK != 1 && !(DBG & 2);
     const int ntiles = nbm * (N / BN);
     auto tile_coords = [&](int id, int& bm, int& bn) {
         const int nbn = N / BN;
@@ -146,6 +146,11 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
             (void)wid;
         }
     };
+    // OUTK == 2 (gate_up + silu * mul, see gemm_w4a8_ring.hip): N stacks [gate | up]; unit j = gate channels 32 j .. as its
+    // tile row t = 0 and up channels N/2 + 32 j .. as t = 1; the workgroup writes 128 channels of the [M, N/2] result
+    constexpr bool ACT = OUTK == 2;
+    auto trow = [&](int unit, int t) { return ACT ? (t ? N / 64 + unit : unit) : unit * 2 + t; };
+    auto chan32 = [&](int unit, int t) { return ACT ? (t ? N / 2 + 32 * unit : 32 * unit) : unit * 64 + 32 * t; };
     int m0, n0;                                       // current tile (of the DMA sources: runs one tile ahead at the end)
     const int KT = K >> 5;
     const int nh = K >> 6;                            // stages (even: K % 128 == 0)
@@ -163,28 +168,41 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     // (inline asm rather than __builtin_amdgcn_global_load_lds: the compiler books the builtin as a FLAT access and
     // from then on degrades every counted LDS wait in the loop to lgkmcnt(0))
     u32 a_off[NA2];
-    u32 w_off;
+    // weights and per-group meta: per-lane offsets are tile-independent, the tile moves the scalar bases
+    const uint8_t* w_base;
     const int8_t* m_base;
+    u32 w_off, m_off;
+    {
+        const int unit = wave >> 1, t = wave & 1;                  // this wave copies tile row t of the tile's unit `unit`
+        const int e = lane >> 4, kk = ((lane >> 3) & 1) ^ t, cc = lane & 7;
+        w_off = ((u32)trow(unit, t) * (u32)KT + kk) * 512u + cc * 64 + e * 16;
+        m_off = chan32(lane >> 4, (lane >> 3) & 1) + (lane & 7) * 4;   // dword `lane` of the tile's 64
+    }
     // instruction i of a wave copies tile rows (i*8 + wave)*8 .. +7: lane -> row a_r0 + 64 i, byte a_c inside the row's
     // 128 k (the swizzle term (r >> 2) & 3 does not depend on i)
-    const int a_r0 = wave * 8 + 2 * (lane >> 4) + ((lane >> 2) & 1);
-    const u32 a_c = ((((lane >> 3) & 1) ^ ((lane >> 4) & 1)) * 64) + (((lane & 3) ^ aswz((a_r0 >> 2) & 3)) * 16);
+    // (everything derived from the lane id outside the k loop is recomputed from a "laundered" copy: kept live across
+    //  the loop - 128 accumulators + operand buffers, 256 registers - these constants were what the compiler spilled)
+    auto fresh = [](int v) {
+        asm volatile("" : "+v"(v));
+        return v;
+    };
     auto setup = [&](int id) {
         int bm, bn;
         tile_coords(id, bm, bn);
         m0 = bm * BM, n0 = bn * BN;
+        const int ln = fresh(lane);
+        const int a_r0 = wave * 8 + 2 * (ln >> 4) + ((ln >> 2) & 1);
+        const u32 a_c = ((((ln >> 3) & 1) ^ ((ln >> 4) & 1)) * 64) + (((ln & 3) ^ aswz((a_r0 >> 2) & 3)) * 16);
 #pragma unroll
         for (int i = 0; i < NA2; ++i) {
             int row = m0 + a_r0 + 64 * i;
             row = row < M ? row : M - 1;
             a_off[i] = __umul24((u32)row, (u32)K) + a_c;           // M, K < 2^24 and M * K < 2^32 (checked by the dispatcher)
         }
-        const int unit = wave >> 1, t = wave & 1;                  // this wave copies tile row 2*unit+t of the band
-        const int e = lane >> 4, kk = ((lane >> 3) & 1) ^ t, cc = lane & 7;
-        w_off = ((u32)(n0 / 32 + unit * 2 + t) * (u32)KT + kk) * 512u + cc * 64 + e * 16;
-        m_base = ((wave & 1) ? zeros : scales8) + n0;
+        // first tile row / channel of the tile: trow(u0 + unit, t) = trow(unit, t) + trow(u0, 0), same for chan32
+        w_base = W + (size_t)trow(n0 / 64, 0) * KT * 512;
+        m_base = ((wave & 1) ? zeros : scales8) + chan32(n0 / 64, 0);
     };
-    const u32 m_off = lane * 4;
     const u32 lds0 = (u32)(size_t)(lptr_t)smem;
 
     auto dma16 = [&](u32 voff, const void* sbase, u32 lds_addr) {
@@ -199,7 +217,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
         dma16(a_off[i], A + (size_t)pr * 128, lds0 + pslot * APAIR + (i * 8 + wave) * 1024);
     };
     auto issue_w = [&](int u, int slot, int i) {                   // i = 0: weights of stage u, 1: its per-group meta
-        if (i == 0) dma16(w_off, W + (size_t)u * 1024, lds0 + (NS / 2) * APAIR + slot * WSTAGE + wave * 1024);
+        if (i == 0) dma16(w_off, w_base + (size_t)u * 1024, lds0 + (NS / 2) * APAIR + slot * WSTAGE + wave * 1024);
         else dma4(m_off, m_base + (size_t)(u >> 1) * N, lds0 + (NS / 2) * APAIR + NS * WSTAGE + slot * 512 + (wave & 1) * 256);
     };
     // Issue order of a wave (vmcnt retires in order): W(0), then for q = 0, 1, ...: A(q), W(2q+1), W(2q+2).  The
@@ -365,7 +383,9 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
         // ---- fused epilogue -------------------------------------------------------------------------------------
         const int em0 = m0, en0 = n0;                  // (m0 / n0 move on to the next tile below)
         const int next = tile + (int)gridDim.x;
-        const int ncol0 = en0 + wn * 64 + 32 * (g >> 1) + 4 * (g & 1);
+        const int lane_e = fresh(lane);
+        const int li = lane_e & 15, g = lane_e >> 4;   // (shadow the loop's copies, see `fresh`)
+        const int ncol0 = chan32(en0 / 64 + wn, g >> 1) + 4 * (g & 1);
         const int mrow0 = em0 + wm * (16 * MT) + li;
         if (OUTK == 1) {
 #pragma unroll
@@ -422,7 +442,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
         // written and read by the same wave: an LDS wait, no barrier.
         constexpr int RS = 144;                        // staged row stride (bytes): 128 + 16 keeps 16-byte alignment
         uint8_t* const st = a_ring + (PERSIST ? 2 * APAIR : 0) + wave * (16 * RS);
-        _Float16* const orow = reinterpret_cast<_Float16*>(out) + en0 + wn * 64 + (lane & 7) * 8;
+        _Float16* const orow = reinterpret_cast<_Float16*>(out) + en0 + wn * 64 + (lane_e & 7) * 8;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const float sa = (float)sa_h[mt];
@@ -438,13 +458,35 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(s[r], (float)ws4[cl][r], sa);
                 }
-                *reinterpret_cast<h4*>(st + li * RS + (32 * (g >> 1) + 8 * cl + 4 * (g & 1)) * 2) = o;
+                if (ACT) {     // lanes 0-31: gate, lanes 32-63: up of the same (token, channel) -> silu_and_mul's arithmetic
+                    const v2u ob = __builtin_bit_cast(v2u, o);
+                    // one swap hands every lane the pair it finishes: r[0] = (x of lanes 0-31 | y of lanes 0-31) = gate elements
+                    // 0, 1 for the lower half, 2, 3 for the upper; r[1] = (x | y of lanes 32-63) = the matching up elements
+                    const auto sw = __builtin_amdgcn_permlane32_swap(ob.x, ob.y, false, false);
+                    const h2 gt = __builtin_bit_cast(h2, (u32)sw[0]), up = __builtin_bit_cast(h2, (u32)sw[1]);
+                    const int hh = g >> 1;
+                    h2 a;
+                    a[0] = (_Float16)((float)qs_silu_h((float)gt[0]) * (float)up[0]);
+                    a[1] = (_Float16)((float)qs_silu_h((float)gt[1]) * (float)up[1]);
+                    *reinterpret_cast<h2*>(st + li * RS + (8 * cl + 4 * (g & 1) + 2 * hh) * 2) = a;
+                } else {
+                    *reinterpret_cast<h4*>(st + li * RS + (32 * (g >> 1) + 8 * cl + 4 * (g & 1)) * 2) = o;
+                }
+            }
+            if (ACT) {         // 16 tokens x 32 channels of this wave: 64-byte row pieces (four waves complete a 256-byte row)
+                const int r = lane_e >> 2;
+                const int m = em0 + wm * (16 * MT) + 16 * mt + r;
+                const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane_e & 3) * 16);
+                if (m < M)
+                    *reinterpret_cast<v4u*>(reinterpret_cast<_Float16*>(out) + (size_t)m * (N / 2) + (en0 / 64 + wn) * 32 +
+                                            (lane_e & 3) * 8) = v;
+                continue;
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int r = i * 8 + (lane >> 3);
+                const int r = i * 8 + (lane_e >> 3);
                 const int m = em0 + wm * (16 * MT) + 16 * mt + r;
-                const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane & 7) * 16);
+                const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane_e & 7) * 16);
                 if (m < M) *reinterpret_cast<v4u*>(orow + (size_t)m * N) = v;
             }
         }
@@ -473,7 +515,7 @@ int launch_tiled(const int8_t* A, const uint8_t* W, const int8_t* zeros, const i
     }
     const int nbm = (M + BM - 1) / BM;
     const int ntiles = nbm * (N / BN);
-    constexpr bool persist = MT == 8 && OUTK == 0 && !(DBG & 2);
+    constexpr bool persist = MT == 8 && OUTK != 1 && !(DBG & 2);
     const int cus = qs_num_cus();
     const int pmode = g_tiled_order / 10;             // 0: one workgroup per CU, 1: one per tile, 2: three (tests)
     dim3 grid(persist && pmode != 1 && ntiles > (pmode == 2 ? 3 : cus) ? (pmode == 2 ? 3 : cus) : ntiles);
@@ -506,6 +548,8 @@ int qs_launch_gemm_tiled(int mode, int outk, const int8_t* A, const uint8_t* W, 
         }
 #undef QS_D
     }
+    if (mode == 0 && outk == 2) { if (big) QS_T(8, 0, 2); QS_T(4, 0, 2); }
+    if (mode == 1 && outk == 2) { if (big) QS_T(8, 1, 2); QS_T(4, 1, 2); }
     if (mode == 0 && outk == 0) { if (big) QS_T(8, 0, 0); QS_T(4, 0, 0); }
     if (mode == 0 && outk == 1) { if (big) QS_T(8, 0, 1); QS_T(4, 0, 1); }
     if (mode == 1 && outk == 0) { if (big) QS_T(8, 1, 0); QS_T(4, 1, 0); }

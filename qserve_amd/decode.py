@@ -8,7 +8,7 @@ It issues exactly the op sequence of the reference's model code for `is_prompt=F
     -> down GEMM -> residual add;   then rms_norm, fp16 lm_head, greedy sampling.
 
 With `fuse_pairs=True` (default) the adjacent pairs (attention, quant of its output), (residual add, layer norm) and
-(silu_and_mul, quant) are issued as one launch each (qserve_amd/fused.py) - same arithmetic, same intermediate fp16 roundings, bit-identical tensors
+(gate_up GEMM, silu_and_mul) are issued as one launch each (qserve_amd/fused.py) - same arithmetic, same intermediate fp16 roundings, bit-identical tensors
 (tests/test_fused_gpu.py, tests/test_decode_gpu.py); `fuse_pairs=False` issues the reference's ops one by one.
 
 Weights are synthetic (random packed nibbles / scales of the right shapes, distinct per layer so nothing is
@@ -97,6 +97,17 @@ class W4A8Linear:
                                        out)
         if self.bias is not None and not self.defer_bias:
             out += self.bias
+
+    def silu_mul(self, x, input_scales, input_sum, out_act, tmp):
+        """gate_up projection + silu_and_mul as one op (qserve_amd.fused.gemm_silu_and_mul_*): out_act [T, n/2].  Only for
+        a stacked gate_up weight without bias (the bias would have to be added between the two ops)."""
+        assert self.bias is None
+        if self.group_size == -1:
+            fusedmod.gemm_silu_and_mul_per_chn(x, self.qweight, self.s1_scales, input_scales, self.s1_szeros, input_sum,
+                                               out_act, tmp)
+        else:
+            fusedmod.gemm_silu_and_mul_per_group(x, self.qweight, self.s2_zeros, self.s2_scales, self.s1_scales,
+                                                 input_scales, out_act, tmp)
 
 
 class DecodeEngine:
@@ -232,7 +243,7 @@ class DecodeEngine:
         qkv = torch.empty((T, self.qkv_n), dtype=f16, device=dev)
         proj = torch.empty((T, self.hid), dtype=f16, device=dev)
         gate_up = torch.empty((T, 2 * self.inter), dtype=f16, device=dev)
-        mlp_act = None if fuse else torch.empty((T, self.inter), dtype=f16, device=dev)
+        mlp_act = torch.empty((T, self.inter), dtype=f16, device=dev)
         seq = torch.full((B,), prompt_len, dtype=torch.int32, device=dev)
         cu = torch.arange(0, B + 1, device=dev, dtype=torch.int32) * prompt_len
         pad = fused_attention.compute_padding_offsets(cu, prompt_len, T)
@@ -272,11 +283,15 @@ class DecodeEngine:
             if L["o"].defer_bias and L["o"].bias is not None:
                 proj += L["o"].bias
             add_norm_quant(h, proj, L["ln2"])
-            L["gate_up"](qa, q_scale, q_sum, gate_up)
-            if fuse:
+            if fuse and L["gate_up"].bias is None:     # gate_up GEMM with the silu * mul epilogue, then the quantiser
+                L["gate_up"].silu_mul(qa, q_scale, q_sum, mlp_act, gate_up)
+            else:
+                L["gate_up"](qa, q_scale, q_sum, gate_up)
+            if fuse and L["gate_up"].bias is not None:
                 fusedmod.silu_and_mul_quant(q_mlp, gate_up, q_scale, sums)
             else:
-                activation_ops.silu_and_mul(mlp_act, gate_up)
+                if not fuse:
+                    activation_ops.silu_and_mul(mlp_act, gate_up)
                 if fuse_sum:
                     fused_kernels.invoke_quant_fuse_sum(q_mlp, mlp_act, q_sum, q_scale)
                 else:
@@ -352,11 +367,15 @@ class DecodeEngine:
                 if L["o"].defer_bias and L["o"].bias is not None:
                     res += L["o"].bias                    # once, after the reduce
             add_norm_quant(h, res, L["ln2"])
-            L["gate_up"](qa, self.q_scale, self.q_sum, self.gate_up_buf)
-            if fuse:
+            if fuse and L["gate_up"].bias is None:     # gate_up GEMM with the silu * mul epilogue, then the quantiser
+                L["gate_up"].silu_mul(qa, self.q_scale, self.q_sum, self.mlp_act, self.gate_up_buf)
+            else:
+                L["gate_up"](qa, self.q_scale, self.q_sum, self.gate_up_buf)
+            if fuse and L["gate_up"].bias is not None:
                 fusedmod.silu_and_mul_quant(self.q_mlp, self.gate_up_buf, self.q_scale, sums)
             else:
-                activation_ops.silu_and_mul(self.mlp_act, self.gate_up_buf)
+                if not fuse:
+                    activation_ops.silu_and_mul(self.mlp_act, self.gate_up_buf)
                 if fuse_sum:
                     fused_kernels.invoke_quant_fuse_sum(self.q_mlp, self.mlp_act, self.q_sum, self.q_scale)
                 else:

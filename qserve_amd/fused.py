@@ -6,6 +6,7 @@ they exist because at decode batch sizes each row kernel is a fixed ~5 us latenc
     add_residual_rms_norm_general(_fuse_sum)  ==  hidden += delta ; layernorm_ops.rms_norm_general(_fuse_sum)(hidden)
     silu_and_mul_quant(_fuse_sum)             ==  activation_ops.silu_and_mul ; fused_kernels.invoke_quant(_fuse_sum)
     single_query_attention_quant(_fuse_sum)   ==  fused_attention.single_query_attention ; fused_kernels.invoke_quant(_fuse_sum)
+    gemm_silu_and_mul_per_chn / _per_group    ==  qgemm_w4a8_per_*.gemm_forward_cuda(gate_up) ; activation_ops.silu_and_mul
 """
 import torch
 
@@ -44,6 +45,39 @@ def silu_and_mul_quant(out, input, scale, input_sum=None):
     with guard(out):
         check(lib.qs_silu_and_mul_quant(ptr(out), ptr(input), ptr(input_sum) if input_sum is not None else 0, ptr(scale),
                                         input.numel() // (2 * d), d, stream()), "fused.silu_and_mul_quant")
+
+
+def gemm_silu_and_mul_per_chn(in_feats, kernel, wscales, ascales, w_szs, a_ssums, out_act, tmp=None):
+    """out_act fp16 [M, N/2] = silu_and_mul(per-channel W4A8 GEMM of the stacked gate_up weight `kernel` [N, K/2]) - one
+    launch where the GEMM kernel has the activation epilogue, two through `tmp` (fp16 [M, N]) otherwise; bit-identical."""
+    _gemm_silu(False, in_feats, kernel, (wscales, ascales, w_szs, a_ssums), out_act, tmp)
+
+
+def gemm_silu_and_mul_per_group(in_feats, kernel, zeros, scales_i8, wscales, ascales, out_act, tmp=None):
+    """Per-group (g128) form of `gemm_silu_and_mul_per_chn`."""
+    _gemm_silu(True, in_feats, kernel, (zeros, scales_i8, wscales, ascales), out_act, tmp)
+
+
+def _gemm_silu(per_group, in_feats, kernel, rest, out_act, tmp):
+    expect(in_feats, torch.int8, "in_feats")
+    expect(kernel, torch.int8, "kernel")
+    expect(out_act, torch.float16, "out_act")
+    for i, t in enumerate(rest):
+        expect(t, torch.int8 if per_group and i < 2 else torch.float16, f"operand {i}")
+    K = in_feats.size(-1)
+    M, N = in_feats.numel() // K, kernel.size(0)
+    if kernel.size(1) * 2 != K:
+        raise RuntimeError(f"gemm_silu_and_mul: kernel {tuple(kernel.shape)} does not match K={K}")
+    if out_act.numel() != M * (N // 2):
+        raise RuntimeError(f"gemm_silu_and_mul: out_act has {out_act.numel()} elements, expected {M} x {N // 2}")
+    if tmp is not None:
+        expect(tmp, torch.float16, "tmp")
+        if tmp.numel() < M * N:
+            raise RuntimeError(f"gemm_silu_and_mul: tmp has {tmp.numel()} elements, needs {M} x {N}")
+    fn = lib.qs_w4a8_per_group_gemm_silu_mul if per_group else lib.qs_w4a8_per_chn_gemm_silu_mul
+    with guard(out_act):
+        check(fn(ptr(in_feats), ptr(kernel), *[ptr(t) for t in rest], ptr(out_act), ptr(tmp) if tmp is not None else 0,
+                 M, N, K, stream()), "fused.gemm_silu_and_mul")
 
 
 def single_query_attention_quant(q, k, v, kv_pointers, length_per_sample, quant_out, quant_scale, memory_max_seqlen,

@@ -90,6 +90,20 @@ def qs_w4a8_per_group_gemm(in_feats, kernel, zeros, scales_i8, wscales, ascales,
     return 0
 
 
+def qs_w4a8_per_chn_gemm_silu_mul(in_feats, kernel, wscales, ascales, w_szs, a_ssums, out_act, tmp, M, N, K, stream):
+    y = np.empty((M, N), np.float16)
+    qs_w4a8_per_chn_gemm(in_feats, kernel, wscales, ascales, w_szs, a_ssums, y.ctypes.data, M, N, K, stream)
+    _arr(out_act, (M, N // 2), np.float16)[:] = ofused.silu_and_mul(y)
+    return 0
+
+
+def qs_w4a8_per_group_gemm_silu_mul(in_feats, kernel, zeros, scales_i8, wscales, ascales, out_act, tmp, M, N, K, stream):
+    y = np.empty((M, N), np.float16)
+    qs_w4a8_per_group_gemm(in_feats, kernel, zeros, scales_i8, wscales, ascales, y.ctypes.data, M, N, K, stream)
+    _arr(out_act, (M, N // 2), np.float16)[:] = ofused.silu_and_mul(y)
+    return 0
+
+
 def qs_invoke_quant(out, inp, input_sum, scale, T, hidden, stream):
     CALLS.append(("qs_invoke_quant", T, hidden, bool(input_sum)))
     x = _arr(inp, (T, hidden), np.float16)
@@ -227,7 +241,8 @@ def qs_flash_attn_varlen_fwd(q, k, v, out, cu_q, cu_k, batch, H, Hkv, head_dim, 
 
 
 SYMBOLS = {f.__name__: f for f in (
-    qs_w4a8_per_chn_gemm, qs_w4a8_per_group_gemm, qs_invoke_quant, qs_rms_norm_general, qs_rms_norm, qs_silu_and_mul,
+    qs_w4a8_per_chn_gemm, qs_w4a8_per_group_gemm, qs_w4a8_per_chn_gemm_silu_mul, qs_w4a8_per_group_gemm_silu_mul,
+    qs_invoke_quant, qs_rms_norm_general, qs_rms_norm, qs_silu_and_mul,
     qs_residual_add, qs_argmax_rows, qs_add_residual_rms_norm_general, qs_silu_and_mul_quant, qs_compute_padding_offsets,
     qs_apply_bias_rope_update_kv_cache, qs_single_query_attention, qs_single_query_attention_quant,
     qs_flash_attn_varlen_fwd)}

@@ -123,6 +123,101 @@ def test_tiled_workgroup_walks_several_tiles(gpu, mode, M, N, K):
     assert np.array_equal(outs[0].view(np.uint16), outs[1].view(np.uint16))
 
 
+# gate_up GEMM + silu_and_mul in one launch (qserve_amd.fused.gemm_silu_and_mul_*): (variant, M, N, K); N stacks
+# [gate | up].  -1 = the dispatcher's own choice; 41xx ring geometries; 42xx K-sliced (no activation epilogue: two
+# launches through tmp); 3001 / 3002 tiled; 3220 tiled with three workgroups walking the tiles
+GATE_UP = [(4111, 16, 128, 1024), (4121, 23, 256, 1024), (4141, 50, 256, 2048), (4122, 32, 256, 512),
+           (4142, 64, 512, 1024), (4144, 100, 512, 1024), (4144, 128, 1024, 2048), (4222, 20, 256, 1024),
+           (3001, 300, 512, 384), (3002, 513, 1024, 512), (3220, 1000, 1536, 512), (-1, 64, 1792, 1024),
+           (-1, 7, 256, 128)]
+
+
+@pytest.mark.parametrize("variant,M,N,K", GATE_UP)
+@pytest.mark.parametrize("mode", ["per_channel", "per_group"])
+def test_gate_up_silu_mul_vs_oracle_and_op_pair(gpu, variant, M, N, K, mode):
+    """One call == plain GEMM entry followed by activation_ops.silu_and_mul, bit for bit; against the oracle within the
+    two fp16 ulps the exponential's library leaves (tests/test_fused_gpu.py::test_rms_norm_and_silu)."""
+    import qserve_backend.activation_ops as act
+    import qserve_backend.qgemm_w4a8_per_chn as opc
+    import qserve_backend.qgemm_w4a8_per_group as opg
+    from oracle import fused as ofused
+    from qserve_amd import _lib, fused as fz
+    if mode == "per_channel":
+        pr = synth.per_channel_problem(M, N, K, seed=M + N)
+        _, y_ref = w4a8.gemm_per_chn(pr["A"], pr["qweight"], pr["wscales"], pr["ascales"], pr["w_szs"], pr["a_ssums"])
+        args = [dev(pr[k]) for k in ("A", "qweight", "wscales", "ascales", "w_szs", "a_ssums")]
+        plain, fusedop = opc.gemm_forward_cuda, fz.gemm_silu_and_mul_per_chn
+    else:
+        pr = synth.per_group_problem(M, N, K, seed=M + N)
+        _, y_ref = w4a8.gemm_per_group(pr["A"], pr["qweight"], pr["s2_zeros"], pr["s2_scales"], pr["wscales"], pr["ascales"])
+        args = [dev(pr[k]) for k in ("A", "qweight", "s2_zeros", "s2_scales", "wscales", "ascales")]
+        plain, fusedop = opg.gemm_forward_cuda, fz.gemm_silu_and_mul_per_group
+    y = torch.empty((M, N), dtype=torch.float16, device=gpu)
+    pair = torch.empty((M, N // 2), dtype=torch.float16, device=gpu)
+    plain(*args, y)
+    act.silu_and_mul(pair, y)
+    outs = []
+    try:
+        if variant == 3220:
+            _lib.lib.qs_set_gemm_variant(3001)
+        _lib.lib.qs_set_gemm_variant(variant)
+        for two_launches in (0, 1):
+            _lib.lib.qs_set_gemm_variant(3300 + two_launches)
+            out = torch.full((M + 1, N // 2), float("nan"), dtype=torch.float16, device=gpu)
+            tmp = torch.empty((M, N), dtype=torch.float16, device=gpu)
+            fusedop(*args, out[:M], tmp)
+            assert torch.isnan(out[M:]).all(), "rows beyond M were written"
+            outs.append(out[:M].cpu().numpy())
+        if variant // 100 != 42 and not (variant == -1 and K < 1024):    # the one-launch form needs no scratch
+            _lib.lib.qs_set_gemm_variant(3300)
+            out = torch.full((M, N // 2), float("nan"), dtype=torch.float16, device=gpu)
+            fusedop(*args, out, None)
+            outs.append(out.cpu().numpy())
+    finally:
+        _lib.lib.qs_set_gemm_variant(3300)
+        _lib.lib.qs_set_gemm_variant(3200)
+        _lib.lib.qs_set_gemm_variant(-1)
+    want = pair.cpu().numpy()
+    for o in outs:
+        assert np.array_equal(o.view(np.uint16), want.view(np.uint16))
+    assert ulp_diff_f16(want, ofused.silu_and_mul(y_ref)).max() <= 2
+
+
+def test_gate_up_silu_mul_model_shapes_equal_op_pair(gpu):
+    """Llama-3-8B gate_up at decode (ring kernel, two and four units) and prompt (tiled kernel, many tiles per workgroup)
+    sizes, per-channel and g128: the one-launch form against the op pair on the device."""
+    import qserve_backend.activation_ops as act
+    import qserve_backend.qgemm_w4a8_per_chn as opc
+    import qserve_backend.qgemm_w4a8_per_group as opg
+    from qserve_amd import fused as fz
+    N, K = 28672, 4096
+    g = torch.Generator(device=gpu).manual_seed(11)
+    W = torch.randint(-128, 128, (N, K // 2), dtype=torch.int8, device=gpu, generator=g)
+    ws = (torch.rand((N,), device=gpu, generator=g) * 0.004 + 0.001).half()
+    wz = (torch.randint(0, 16, (N,), device=gpu, generator=g).half() * ws).half()
+    s2 = torch.randint(1, 9, (K // 128, N), dtype=torch.int8, device=gpu, generator=g)
+    z2 = (-(torch.randint(0, 16, (K // 128, N), device=gpu, generator=g).to(torch.int16) * s2.to(torch.int16))).to(torch.int8)
+    for M in (64, 128, 3000):
+        A = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=gpu, generator=g)
+        sa = (torch.rand((M,), device=gpu, generator=g) * 0.02 + 0.005).half()
+        ss = (sa.float() * A.float().sum(1)).half()
+        y = torch.empty((M, N), dtype=torch.float16, device=gpu)
+        pair = torch.empty((M, N // 2), dtype=torch.float16, device=gpu)
+        out = torch.empty((M, N // 2), dtype=torch.float16, device=gpu)
+        for per_group in (False, True):
+            if per_group:
+                opg.gemm_forward_cuda(A, W, z2, s2, ws, sa, y)
+            else:
+                opc.gemm_forward_cuda(A, W, ws, sa, wz, ss, y)
+            act.silu_and_mul(pair, y)
+            out.fill_(float("nan"))
+            if per_group:
+                fz.gemm_silu_and_mul_per_group(A, W, z2, s2, ws, sa, out, None)
+            else:
+                fz.gemm_silu_and_mul_per_chn(A, W, ws, sa, wz, ss, out, None)
+            assert torch.equal(out.view(torch.int16), pair.view(torch.int16)), (M, per_group)
+
+
 def test_tiled_kernel_equals_decode_kernel(gpu):
     """Same problem through both code paths (variant 3000 = tiled kernel off, 3001 = forced with the 128-token tile)."""
     import qserve_backend.qgemm_w4a8_per_group as op
