@@ -225,9 +225,17 @@ def kernel_bench(eng, args, torch, contexts):
              ("down", eng.q_mlp, eng.proj_out)]
     for name, x, out in specs:
         lin0 = eng.layers[0][name]
-        us = time_kernel(lambda i: eng.layers[i % nl][name](x, eng.q_scale, eng.q_sum, out), 4 * nl, torch)
         by = gemm_bytes(B, lin0.n, lin0.k, eng.group_size)
-        res.append(dict(kernel=f"w4a8_gemm[{name} M={B} N={lin0.n} K={lin0.k}]", family="w4a8_gemm", us=us, bytes=by,
+        label = name
+        if name == "gate_up" and eng.fuse_pairs and lin0.bias is None:
+            # what the step launches: the GEMM with the silu * mul epilogue (writes [M, N/2] instead of [M, N])
+            us = time_kernel(lambda i: eng.layers[i % nl][name].silu_mul(x, eng.q_scale, eng.q_sum, eng.mlp_act, out),
+                             4 * nl, torch)
+            by -= B * lin0.n
+            label = "gate_up+silu*mul"
+        else:
+            us = time_kernel(lambda i: eng.layers[i % nl][name](x, eng.q_scale, eng.q_sum, out), 4 * nl, torch)
+        res.append(dict(kernel=f"w4a8_gemm[{label} M={B} N={lin0.n} K={lin0.k}]", family="w4a8_gemm", us=us, bytes=by,
                         gbs=by / us / 1e3, tops=2.0 * B * lin0.n * lin0.k / us / 1e6, per_step=nl))
     q, k, v = eng.qkv_buf.split([eng.H * 128, eng.Hkv * 128, eng.Hkv * 128], dim=-1)
     q, k, v = q.reshape(B, eng.H, 128), k.reshape(B, eng.Hkv, 128), v.reshape(B, eng.Hkv, 128)
@@ -597,8 +605,8 @@ def main():
                                     if graphed and world > 1 and not args.tp_full_graph and direct is None else graphed),
                        "layers": cfg["layers"],
                        "op_sequence": "reference ops one by one" if args.op_by_op else
-                       "reference ops; (residual add, layer norm) and (silu_and_mul, quant) issued as bit-identical "
-                       "fused pairs (qserve_amd/fused.py)",
+                       "reference ops; (residual add, layer norm), (gate_up GEMM, silu_and_mul) and (attention, quant) "
+                       "issued as bit-identical fused pairs (qserve_amd/fused.py)",
                        **extra},
             "roofline": roof,
             "roofline_family": roof_family,

@@ -68,7 +68,7 @@ int qs_w4a8_per_group_gemm(const int8_t* in_feats, const int8_t* kernel, const i
                            int M, int N, int K, qs_stream_t stream);
 
 /* gate_up GEMM + silu_and_mul in one launch (engine-side fusion, like the pairs further down; no reference op of its
- * own: the MLP of llama_w4a8_unpad.py:262-271 issues gate_up_proj, then activation_ops.silu_and_mul).
+ * own: LlamaMLP.forward, llama_w4a8_unpad.py:69-93, issues gate_up_proj, then SiluAndMulQuant = silu_and_mul ; invoke_quant).
  *   kernel   the stacked gate_up weight [N, K/2], rows 0 .. N/2-1 = gate, N/2 .. N-1 = up (load_weights' row
  *            concatenation), consumed unchanged;   out_act half [M, N/2];
  *   out_act[m, c] = half(float(silu_h(Y[m, c])) * float(Y[m, N/2 + c]))  with Y = the fp16 result of the plain GEMM entry

@@ -22,7 +22,7 @@ for rep in range(2):
     for i in range(nl):
         L = eng.layers[i]
         L["qkv"](eng.q_act, eng.q_scale, eng.q_sum, eng.qkv_buf)
-        L["gate_up"](eng.q_act, eng.q_scale, eng.q_sum, eng.gate_up_buf)
+        L["gate_up"].silu_mul(eng.q_act, eng.q_scale, eng.q_sum, eng.mlp_act, eng.gate_up_buf)   # what the step launches
         L["down"](eng.q_mlp, eng.q_scale, eng.q_sum, eng.proj_out)
         fa.single_query_attention(q, k, v, eng.tables[i], eng.lengths, None, 8192, 64, eng.size_per_token,
                                   eng.max_len, 128, eng.cfg["rope_theta"], True, eng.int4, True)
