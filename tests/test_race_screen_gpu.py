@@ -82,3 +82,50 @@ def test_repeated_runs_are_identical_and_exact(gpu, M, N, K, mode):
             run_act(act)
             assert torch.equal(act.view(torch.int16), act0.view(torch.int16)), f"silu * mul run {r} differs"
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,H,Hkv,L,int4", [(64, 32, 8, 1033, True), (8, 32, 8, 4000, True), (64, 32, 8, 1033, False),
+                                             (8, 32, 8, 7680, False), (3, 8, 2, 130, True)])
+def test_decode_attention_repeats_are_identical(gpu, B, H, Hkv, L, int4):
+    """The decode attention launch (LDS-DMA page pipeline with counted waits, service-wave flag, split-KV partials, the
+    per-sequence arrival ticket of the fused quantiser): same inputs, REPS launches under a thrashing side stream - fp16
+    output, int8 row, scale, sum and every cache byte identical to the first launch (whose correctness is
+    tests/test_attention_gpu.py's subject)."""
+    from test_attention_gpu import ROPE, DevPools
+    from qserve_amd import fused
+    g = torch.Generator(device=gpu).manual_seed(B + H + L)
+    mb = (L + 63) // 64 + 1
+    dhb = 64 if int4 else 128
+    nblocks = B * mb
+    pools = DevPools(nblocks, Hkv, int4, gpu, fill=0)
+    nd = Hkv * 64 * dhb
+    for p in (pools.k, pools.v):
+        p[:, :nd] = torch.randint(0, 256, (nblocks, nd), dtype=torch.uint8, device=gpu, generator=g)
+        p[:, nd:].view(torch.float16).copy_((torch.rand((nblocks, (pools.pb - nd) // 2), device=gpu, generator=g) * 0.5 + 0.05).half())
+    tables = torch.stack([torch.randperm(nblocks, generator=torch.Generator().manual_seed(1)).reshape(B, mb),
+                          torch.randperm(nblocks, generator=torch.Generator().manual_seed(2)).reshape(B, mb)], dim=1).numpy()
+    ptrs = pools.pointers(tables)
+    new = torch.randn((B, (H + 2 * Hkv) * 128), generator=g, device=gpu, dtype=torch.float16)
+    q, k, v = new.split([H * 128, Hkv * 128, Hkv * 128], dim=-1)
+    q, k, v = q.reshape(B, H, 128), k.reshape(B, Hkv, 128), v.reshape(B, Hkv, 128)
+    lens = torch.randint(max(1, L - 200), L + 1, (B,), generator=torch.Generator().manual_seed(3)).to(torch.int32).to(gpu)
+    lens[0] = L
+    side = torch.cuda.Stream(device=gpu)
+    bufs = [torch.empty((64 << 20,), dtype=torch.uint8, device=gpu) for _ in range(3)]
+    first = None
+    for r in range(REPS + 1):
+        if r % 3 != 2:
+            thrash(side, bufs, 2 + r % 4)
+        qq = torch.full((B, H * 128), 55, dtype=torch.int8, device=gpu)
+        sc = torch.full((B,), 5.0, dtype=torch.float16, device=gpu)
+        sm = torch.full((B,), 7.0, dtype=torch.float16, device=gpu)
+        out = fused.single_query_attention_quant(q, k, v, ptrs, lens, qq, sc, 8192, 64, Hkv * dhb, L, 128, ROPE, True, int4,
+                                                 True, quant_sum=sm)
+        cur = (out.view(torch.int16).clone(), qq, sc.view(torch.int16).clone(), sm.view(torch.int16).clone(),
+               pools.k.clone(), pools.v.clone())
+        if first is None:
+            first = cur
+        else:
+            for a, b, what in zip(cur, first, ("output", "int8 row", "scale", "sum", "k pages", "v pages")):
+                assert torch.equal(a, b), f"launch {r}: {what} differs"
+    torch.cuda.synchronize()
