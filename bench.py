@@ -520,7 +520,11 @@ def main():
             torch.cuda.synchronize()
             extra.update(direct_all_reduce_us=round(e0.elapsed_time(e1) * 1e3 / 50, 2),
                          direct_all_reduce_timeouts=bool(direct.error()))
-        extra.update(step_collectives=collective_note or "torch.distributed all-reduce (--collective rccl)")
+        extra.update(step_collectives=collective_note or "torch.distributed all-reduce (--collective rccl)",
+                     all_reduces_per_step=2 * cfg["layers"] + int(eng.vocab_parallel),
+                     lm_head=("vocabulary-parallel: every rank multiplies its V/N rows, the ranks' greedy candidates meet in "
+                              "one more (32-byte-per-sequence-and-rank) sum all-reduce" if eng.vocab_parallel
+                              else "replicated on every rank"))
 
     # ---- per-kernel timing + roofline ---------------------------------------------------------------------------------
     roof, roof_family, kernels = None, None, None

@@ -171,6 +171,11 @@ def _tp_case(device, group_size, bias, world=2, prompt_len=70, steps=2):
         ref.append(single.final.clone())
         outs += run_tp_lockstep(ranks, 1)
         assert torch.equal(ranks[0].tokens, ranks[1].tokens)
+        # vocabulary-parallel greedy head: the token every rank ends with is the first maximum over the concatenation of
+        # the ranks' shard logits (= the whole row, shard r owning the r-th vocabulary range)
+        assert all(e.vocab_parallel and e.lm_head.size(0) == CFG["vocab"] // world for e in ranks)
+        full = torch.cat([torch.matmul(e.final, e.lm_head.t()) for e in ranks], dim=1).float()
+        assert torch.equal(ranks[0].tokens.cpu(), full.argmax(dim=1).cpu())
         for e in ranks:                       # greedy tokens may flip on near-ties: keep the runs on the same sequence
             e.tokens.copy_(single.tokens)
     for s in range(steps):
@@ -197,6 +202,49 @@ def test_tp2_matches_tp1_host_simulator(built_lib, monkeypatch, group_size, bias
 @pytest.mark.parametrize("group_size,bias", [(-1, False), (128, False), (-1, True)])
 def test_tp2_matches_tp1_on_device(gpu, group_size, bias):
     _tp_case("cuda:0", group_size, bias)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_vocab_parallel_head_first_maximum_and_ties(built_lib, monkeypatch, world):
+    """The candidate exchange on its own: ties inside a shard and across shards resolve to the lowest vocabulary index,
+    indices above 2048 * 2047 / below 2048 survive the fp16 split, and a replicated head (vocab_parallel=False) gives the
+    same tokens."""
+    import _fake_abi
+    from qserve_amd import decode as D
+    _fake_abi.install(monkeypatch)
+    cfg = dict(D.TINY, vocab=4096 * world, layers=1, heads=8, kv_heads=4, hidden=1024)
+    B = 6
+    engs = [D.DecodeEngine(cfg, B, 16, 4, device="cpu", seed=5, tp_rank=r, tp_world=world) for r in range(world)]
+    rep = D.DecodeEngine(cfg, B, 16, 4, device="cpu", seed=5, tp_rank=0, tp_world=world, vocab_parallel=False)
+    assert not rep.vocab_parallel and rep.lm_head.size(0) == cfg["vocab"]
+    g = torch.Generator().manual_seed(3)
+    final = torch.randn((B, cfg["hidden"]), generator=g).half()
+    head = torch.zeros((cfg["vocab"], cfg["hidden"]), dtype=torch.float16)
+    head[:, 0] = (torch.randn((cfg["vocab"],), generator=g) * 0.1).half()
+    final[:, 0] = 1.0
+    final[:, 1:] = 0                                   # logits[b, v] = head[v, 0]: identical rows, ties are easy to plant
+    top = float(head[:, 0].float().max()) + 1.0
+    planted = [5, 4096 * world - 1, 4096 + 7, 2049, 4096 * (world - 1), 100]
+    for e in engs + [rep]:
+        e.final.copy_(final)
+    # one planted maximum per run, twice (at v and at a higher index) so that the first must win
+    for v in planted:
+        h = head.clone()
+        h[v, 0] = top
+        h[min(v + 4096, cfg["vocab"] - 1), 0] = top
+        for r, e in enumerate(engs):
+            n = cfg["vocab"] // world
+            e.lm_head.copy_(h[r * n:(r + 1) * n])
+        parts = [e._head_local() for e in engs]
+        total = parts[0].clone()
+        for p_ in parts[1:]:
+            total += p_
+        for e, p_ in zip(engs, parts):
+            p_.copy_(total)
+            e._head_finish(e.head_cand_res)
+            assert torch.equal(e.tokens, torch.full((B,), v, dtype=torch.int64)), (v, e.tokens)
+        logits = torch.matmul(rep.final, h.t())
+        assert int(logits[0].float().argmax()) == v
 
 
 def test_column_parallel_shards_are_exact_slices():
