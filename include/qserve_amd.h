@@ -202,6 +202,10 @@ int qs_residual_add(void* a, const void* b, int64_t numel, qs_stream_t stream);
 /* greedy sampling helper (the reference's sampler is torch: argmax over the fp16 logits, layers/sampler.py): out[r] = index
  * of the first maximum of row r of x (fp16 [rows, n], row stride in elements, 16-byte aligned rows; NaN-free). */
 int qs_argmax_rows(const void* x, int64_t* out, int rows, int n, int64_t row_stride, qs_stream_t stream);
+/* A/B and tests: -1 = heuristic (few long rows are split over up to 8 workgroups per row, candidates meeting in a
+ * device-scope atomic max; needs a library-owned 96 KiB scratch that is never allocated during stream capture),
+ * 1 = one workgroup per row, >= 2 = forced split. */
+void qs_debug_argmax_split(int split);
 
 /* Pair fusions for the decode loop (no reference counterpart; each is BIT-IDENTICAL to the two calls it replaces and
  * exists because at decode batch sizes every one of these row kernels is a fixed ~5 us latency chain):

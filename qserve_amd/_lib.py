@@ -38,6 +38,7 @@ SIGNATURES = {
     "qs_silu_and_mul": (_i, [_vp, _vp, _i, _i, _vp]),
     "qs_residual_add": (_i, [_vp, _vp, _i64, _vp]),
     "qs_argmax_rows": (_i, [_vp, _vp, _i, _i, _i64, _vp]),
+    "qs_debug_argmax_split": (None, [_i]),
     "qs_add_residual_rms_norm_general": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "qs_silu_and_mul_quant": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "qs_debug_wave_reduce_selftest": (_i, [_vp, _vp, _i, _vp]),

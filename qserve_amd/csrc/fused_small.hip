@@ -520,13 +520,134 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const _Float16* __res
         if (lane == 0) out[blockIdx.x] = bi == 0x7fffffff ? 0 : bi;
     }
 }
+// Few long rows (the greedy sampler of a 64-sequence step: 64 rows x 128 256 logits) leave 3/4 of the CUs idle and
+// make the row's 16 waves VALU-bound: SPLIT workgroups per row, each reducing a contiguous range of 16-byte chunks; the
+// candidates meet in a 64-bit key (orderable value bits << 32 | ~index: the maximum key is the first maximum) by a
+// device-scope atomic max, an arrival ticket tells the last workgroup of a row to decode the key and to put key and
+// ticket back to zero (nothing for the host to reset between launches or graph replays).
+template <int MAXC>
+__global__ __launch_bounds__(1024) void argmax_rows_split_kernel(const _Float16* __restrict__ x, int64_t* __restrict__ out,
+                                                                  int n, int64_t row_stride,
+                                                                  unsigned long long* __restrict__ keys,
+                                                                  unsigned* __restrict__ tickets) {
+    const int r = blockIdx.x, part = blockIdx.y, nsplit = gridDim.y;
+    const _Float16* row = x + (size_t)r * row_stride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nchunk = n >> 3;
+    const int per = (nchunk + nsplit - 1) / nsplit;
+    const int c_lo = part * per, c_hi = min(nchunk, c_lo + per);
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c0 = c_lo; c0 < c_hi; c0 += MAXC * 1024) {
+        h8 v[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {               // unconditional (clamped) loads, see argmax_rows_kernel
+            const int ch = c0 + tid + c * 1024;
+            v[c] = load8(row + (size_t)(ch < c_hi ? ch : c_hi - 1) * 8);
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = c0 + tid + c * 1024;
+            if (ch < c_hi) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) argmax_pick(bv, bi, (float)v[c][e], ch * 8 + e);
+            }
+        }
+    }
+    if (part == nsplit - 1)
+        for (int i = (nchunk << 3) + tid; i < n; i += 1024) argmax_pick(bv, bi, (float)row[i], i);   // n % 8 tail
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = __shfl_xor(bv, m, 64);
+        const int oi = __shfl_xor(bi, m, 64);
+        argmax_pick(bv, bi, ov, oi);
+    }
+    __shared__ float s_v[16];
+    __shared__ int s_i[16];
+    if (lane == 0) {
+        s_v[wave] = bv;
+        s_i[wave] = bi;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    bv = lane < 16 ? s_v[lane] : -INFINITY;
+    bi = lane < 16 ? s_i[lane] : 0x7fffffff;
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) {
+        const float ov = __shfl_xor(bv, m, 64);
+        const int oi = __shfl_xor(bi, m, 64);
+        argmax_pick(bv, bi, ov, oi);
+    }
+    if (lane != 0) return;
+    u32 u = __builtin_bit_cast(u32, bv);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                 // monotone in the float order, never 0
+    const unsigned long long key = ((unsigned long long)u << 32) | (0xFFFFFFFFu - (u32)bi);
+    (void)__hip_atomic_fetch_max(keys + r, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // returns: performed
+    const unsigned t = __hip_atomic_fetch_add(tickets + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t != (unsigned)(nsplit - 1)) return;
+    const unsigned long long k = __hip_atomic_exchange(keys + r, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(tickets + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 idx = 0xFFFFFFFFu - (u32)(k & 0xFFFFFFFFu);
+    out[r] = idx == 0x7fffffffu ? 0 : (int64_t)idx;
+}
+
+// per-device keys / tickets of the split form (zero between launches); never allocated while a stream is capturing
+struct ArgmaxWs {
+    unsigned long long* keys = nullptr;
+    unsigned* tickets = nullptr;
+    bool tried = false;
+};
+constexpr int ARGMAX_WS_ROWS = 8192;
+ArgmaxWs* argmax_ws(hipStream_t stream) {
+    static ArgmaxWs ws[QS_MAX_DEVICES];
+    ArgmaxWs& w = ws[qs_device_slot()];
+    if (!w.tried) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return nullptr;                            // first use inside a capture: one workgroup per row this time
+        }
+        w.tried = true;
+        void* a = nullptr;
+        if (hipMalloc(&a, ARGMAX_WS_ROWS * 12) == hipSuccess && hipMemset(a, 0, ARGMAX_WS_ROWS * 12) == hipSuccess) {
+            w.keys = reinterpret_cast<unsigned long long*>(a);
+            w.tickets = reinterpret_cast<unsigned*>(w.keys + ARGMAX_WS_ROWS);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    return w.keys ? &w : nullptr;
+}
 }  // namespace
+
+int g_argmax_split = -1;   // qs_debug_argmax_split: -1 heuristic, 1 one workgroup per row, >= 2 forced split (tests, A/B)
+extern "C" void qs_debug_argmax_split(int split) { g_argmax_split = split; }
 
 extern "C" int qs_argmax_rows(const void* x, int64_t* out, int rows, int n, int64_t row_stride, qs_stream_t stream) {
     QS_REQUIRE(x && out, "argmax_rows: null pointer");
     QS_REQUIRE(n >= 8 && row_stride >= n && row_stride % 8 == 0, "argmax_rows: n=%d (>= 8), row stride %lld (must be >= n, multiple of 8)",
                n, (long long)row_stride);
     if (rows <= 0) return QS_OK;
+    // split rows over several workgroups while the grid stays within about one round of the chip and every part keeps
+    // at least 2 chunks per thread
+    int split = 1;
+    if (g_argmax_split >= 2) split = g_argmax_split;
+    else if (g_argmax_split < 0)
+        while (split < 8 && rows * split * 2 <= qs_num_cus() && (n >> 3) / (split * 2) >= 2048) split *= 2;
+    if (split > 1 && rows <= ARGMAX_WS_ROWS) {
+        if (ArgmaxWs* w = argmax_ws((hipStream_t)stream)) {
+            const int per = ((n >> 3) + split - 1) / split, pc = (per + 1023) / 1024;
+            auto launch_s = [&](auto k) {
+                hipLaunchKernelGGL(k, dim3(rows, split), dim3(1024), 0, (hipStream_t)stream, (const _Float16*)x, out, n,
+                                   row_stride, w->keys, w->tickets);
+            };
+            if (pc <= 2) launch_s(argmax_rows_split_kernel<2>);
+            else if (pc <= 4) launch_s(argmax_rows_split_kernel<4>);
+            else if (pc <= 8) launch_s(argmax_rows_split_kernel<8>);
+            else launch_s(argmax_rows_split_kernel<16>);
+            return qs_launch_status("argmax_rows");
+        }
+    }
     const int chunks = ((n >> 3) + 1023) / 1024;
     auto launch = [&](auto k) {
         hipLaunchKernelGGL(k, dim3(rows), dim3(1024), 0, (hipStream_t)stream, (const _Float16*)x, out, n, row_stride);

@@ -280,7 +280,28 @@ def test_argmax_rows_is_first_maximum(gpu, rows, n, pad):
     if n >= 8:
         x[0, [n - 1, n // 2, 3]] = 50.0                      # ties: the first one counts
     xd = dev(x)
-    out = torch.full((rows,), -7, dtype=torch.int64, device=gpu)
-    argmax_rows_(xd[:, :n], out)
-    torch.cuda.synchronize()
-    assert np.array_equal(out.cpu().numpy(), np.argmax(x[:, :n].astype(np.float32), axis=1))
+    want = np.argmax(x[:, :n].astype(np.float32), axis=1)
+    from qserve_amd import _lib
+    try:
+        for split in (-1, 1, 2, 3, 8):                      # heuristic / one workgroup per row / rows split over workgroups
+            _lib.lib.qs_debug_argmax_split(split)
+            for rep in range(3):                            # the split form's keys and tickets reset themselves
+                out = torch.full((rows,), -7, dtype=torch.int64, device=gpu)
+                argmax_rows_(xd[:, :n], out)
+                torch.cuda.synchronize()
+                assert np.array_equal(out.cpu().numpy(), want), (split, rep)
+        _lib.lib.qs_debug_argmax_split(4)
+        out = torch.full((rows,), -7, dtype=torch.int64, device=gpu)
+        s_ = torch.cuda.Stream()
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s_):
+                argmax_rows_(xd[:, :n], out)
+        for rep in range(3):
+            out.fill_(-7)
+            g.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want), ("graph", rep)
+    finally:
+        _lib.lib.qs_debug_argmax_split(-1)
