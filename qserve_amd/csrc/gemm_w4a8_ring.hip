@@ -259,11 +259,19 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
         v4i a[4];
         v4i b[MT];
     };
+    // per-group: separate address registers keep these four 8-byte reads from being merged into ds_read2_b64 (half rate
+    // and, on this image, two-way conflicts; gemm_w4a8_tiled.hip has the measurement)
+    int w_rd_e[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        w_rd_e[e] = w_rd + e * 256;
+        if (MODE == 1) asm volatile("" : "+v"(w_rd_e[e]));
+    }
     auto read_raw = [&](int slot) -> Raw {
         const uint8_t* s = ring + slot * GSTAGE;
         Raw q;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) q.r[e] = *reinterpret_cast<const v2u*>(s + w_rd + e * 256);
+        for (int e = 0; e < 4; ++e) q.r[e] = *reinterpret_cast<const v2u*>(s + w_rd_e[e]);
         q.sdw = 0;
         q.zdw = 0;
         if (MODE == 1) {
