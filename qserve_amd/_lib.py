@@ -6,7 +6,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqserve_amd.so")
+# QS_AMD_LIBRARY: measurement scripts point this at the -DQS_TIMING build (qserve_amd/libqserve_amd_timing.so, same ABI
+# plus ablation switches); the product, the tests and bench.py never set it
+LIB_PATH = os.environ.get("QS_AMD_LIBRARY") or os.path.join(_HERE, "libqserve_amd.so")
 
 # name -> (restype, argtypes); must list every symbol of include/qserve_amd.h (tests/test_abi.py checks that)
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -19,6 +21,12 @@ SIGNATURES = {
     "qs_w4a8_per_chn_gemm_acc": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_w4a8_per_chn_gemm_silu_mul": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_w4a8_per_group_gemm_silu_mul": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "qs_w4a8_per_chn_gemm_add_norm_quant": (_i, [_vp] * 12 + [_f, _i, _i, _i, _vp]),
+    "qs_w4a8_per_group_gemm_add_norm_quant": (_i, [_vp] * 12 + [_f, _i, _i, _i, _vp]),
+    "qs_w4a8_per_chn_gemm_silu_mul_quant": (_i, [_vp] * 11 + [_i, _i, _i, _vp]),
+    "qs_w4a8_per_group_gemm_silu_mul_quant": (_i, [_vp] * 11 + [_i, _i, _i, _vp]),
+    "qs_fused_tail_status": (_i, [C.POINTER(C.c_int)]),
+    "qs_debug_tail_launches": (C.c_long, []),
     "qs_w4a8_per_group_gemm_acc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_w8a8_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_set_gemm_variant": (None, [_i]),

@@ -47,7 +47,14 @@ def _compile(src, force, extra):
     return obj, True
 
 
-def build(force=False, verbose=True, extra=()):
+def build(force=False, verbose=True, extra=(), timing=False):
+    """timing=True: the measurement build (-DQS_TIMING: ablation switches that turn kernel parts off, timeline traces) ->
+    libqserve_amd_timing.so from its own object directory; never loaded by the product (qserve_amd/_lib.py loads it only when
+    QS_AMD_LIBRARY names it - scripts/)."""
+    global BUILD, LIB
+    if timing:
+        BUILD, LIB = os.path.join(HERE, "_build_timing"), os.path.join(HERE, "libqserve_amd_timing.so")
+        extra = list(extra) + ["-DQS_TIMING"]
     os.makedirs(BUILD, exist_ok=True)
     extra = list(extra) + os.environ.get("QS_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DQS_RING_TRACE (timing tools)
     with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
@@ -72,7 +79,8 @@ if __name__ == "__main__":
     ap.add_argument("--debug-asm", action="store_true",
                     help="keep the gfx950 assembly of every kernel next to the objects (qserve_amd/_build/*.s) and print "
                          "the per-kernel register / LDS / scratch usage (implies --force)")
+    ap.add_argument("--timing", action="store_true", help="build libqserve_amd_timing.so (-DQS_TIMING) instead")
     a = ap.parse_args()
     extra = ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"] if a.debug_asm else []
-    build(force=a.force or a.debug_asm, extra=extra)
+    build(force=a.force or a.debug_asm, extra=extra, timing=a.timing)
     sys.exit(0)

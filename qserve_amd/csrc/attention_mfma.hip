@@ -102,7 +102,8 @@ __device__ __forceinline__ u32 and_or(u32 x, u32 m, u32 c) {
 
 typedef __attribute__((address_space(3))) const uint8_t* lds_u8;   // 32-bit LDS address (keeps ds_read, not flat_load)
 
-// EXP: timing / ablation switches (qs_set_attention_variant(200 + EXP), G = 4 only; default 0 = the product kernel):
+// EXP: timing / ablation switches (libraries built with -DQS_TIMING only: qs_set_attention_variant(200 + EXP), G = 4 only;
+// the shipped library instantiates EXP = 0 and ignores the request):
 //   1 = page DMA WITHOUT the non-temporal hint (default: nt - every KV byte is read once per step; measured -4 % at
 //       L = 1033 ... -12 % at L = 4096), 2 = no compute (DMA + waits only: results are wrong by design),
 //   4 = skip phase A (RoPE / new token: wrong by design), 8 = fetch the last page in full (default: only the rows of
@@ -947,7 +948,9 @@ unsigned* qs_attn_quant_counters(hipStream_t st, int batch) {
         return nullptr;
     }
     void* p = nullptr;
-    if (hipMalloc(&p, 65536 * sizeof(unsigned)) != hipSuccess || hipMemset(p, 0, 65536 * sizeof(unsigned)) != hipSuccess) {
+    // (the memset runs on the NULL stream: synchronise, or a launch on a non-blocking stream could overtake it)
+    if (hipMalloc(&p, 65536 * sizeof(unsigned)) != hipSuccess || hipMemset(p, 0, 65536 * sizeof(unsigned)) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
@@ -1012,6 +1015,7 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
         hipLaunchKernelGGL((decode_attention_mfma_kernel<4, E>), grid, dim3(NWT * 64), 0, st, q, k, v, kvp, len, out, H,  \
                            Hkv, qs, kvs, mb, timestep, base, tab, tab_len, nsplit, ws, qout, qscale, qsum, qcnt);      \
         return qs_launch_status("single_query_attention")
+#ifdef QS_TIMING   // ablation / trace instantiations (some are wrong by design): not in the shipped library
     if (exp_flags & 32) {                     // timeline trace: stamps go to the (otherwise unused) split workspace
         ws = qs_split_workspace((size_t)blocks * NWT * 16 * 8, st);
         if (!ws) exp_flags = 0;
@@ -1020,6 +1024,7 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
         switch (exp_flags) {
             QS_LAUNCH_EXP(1);
             QS_LAUNCH_EXP(2);
+            QS_LAUNCH_EXP(4);
             QS_LAUNCH_EXP(6);
             QS_LAUNCH_EXP(8);
             QS_LAUNCH_EXP(9);
@@ -1027,6 +1032,7 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
             default: break;
         }
     }
+#endif
     switch (G) {
         case 1: QS_LAUNCH_G(1); break;
         case 2: QS_LAUNCH_G(2); break;

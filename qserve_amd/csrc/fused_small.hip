@@ -9,6 +9,7 @@
 // HBM-bound row kernels: one 256-thread workgroup per token, 16-byte (8 x fp16) accesses, wave64 shuffles +
 // one LDS hop for the block reductions.  hidden % 8 == 0.
 #include "common.h"
+#include "row_ops.h"
 
 namespace {
 
@@ -62,7 +63,7 @@ __device__ __forceinline__ void block_reduce_max_sum(float& mx, float& sum, floa
 }
 // rows wider than this are handled by 1024-thread workgroups (same rule in invoke_quant and silu_and_mul_quant, so the
 // two associate their fp32 statistics identically)
-constexpr int WIDE_ROW = 4096;
+constexpr int WIDE_ROW = qs_row::WIDE_ROW;
 
 __device__ __forceinline__ h8 load8(const _Float16* p) { return *reinterpret_cast<const h8*>(p); }
 
@@ -83,51 +84,13 @@ template <int NC, int NT>
 __global__ __launch_bounds__(NT) void quant_kernel(int8_t* __restrict__ out, const _Float16* __restrict__ in,
                                                     __half* __restrict__ sum_out, __half* __restrict__ scale_out,
                                                     int hidden) {
-    __shared__ float sm[2][NT / 64];
+    __shared__ float sm[2 * (NT / 64)];
     const size_t base = (size_t)blockIdx.x * hidden;
-    h8 v[NC];
-    float amax = 0.f, sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {                     // all requests first (see add_residual_norm_quant_kernel)
-        const int i = (c * NT + threadIdx.x) * 8;
-        if (i < hidden) v[c] = load8(in + base + i);
-    }
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int i = (c * NT + threadIdx.x) * 8;
-        if (i < hidden) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float f = (float)v[c][j];
-                sum += f;
-                amax = fmaxf(amax, fabsf(f));
-            }
-        }
-    }
-    block_reduce_max_sum<NT>(amax, sum, sm[0], sm[1], sum_out != nullptr);
-    
-    if (threadIdx.x == 0) {
-        scale_out[blockIdx.x] = __float2half_rn(amax / 127.0f);          // fused_kernels.cu:72
-        if (sum_out) sum_out[blockIdx.x] = __float2half_rn(sum);         // :121
-    }
-    const float mul = 127.0f / amax;                                     // :78 (unrounded fp32 amax)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int i = (c * NT + threadIdx.x) * 8;
-        if (i < hidden) {
-            float f[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = (float)v[c][j];
-            store_q8(out + base + i, f, mul);
-        }
-    }
+    qs_row::quant_row<NC, NT / 64, NT / 64, false>(out + base, in + base, sum_out ? sum_out + blockIdx.x : nullptr,
+                                                   scale_out + blockIdx.x, hidden, sm, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float ln_val(float x, float mean, float rstd, float g) {
-#pragma clang fp contract(off)
-    return (x - mean) * rstd * g;                                        // layernorm_kernels.cu:23
-}
 
 template <int NC>
 __global__ __launch_bounds__(TPB) void general_norm_quant_kernel(int8_t* __restrict__ out,
@@ -136,66 +99,11 @@ __global__ __launch_bounds__(TPB) void general_norm_quant_kernel(int8_t* __restr
                                                                  __half* __restrict__ sum_out,
                                                                  __half* __restrict__ scale_out, float eps,
                                                                  int hidden) {
-    __shared__ float sm[4][TPB / 64];
+    __shared__ float sm[4 * (TPB / 64)];
     const size_t base = (size_t)blockIdx.x * hidden;
-    h8 v[NC], g[NC];
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {                     // all requests first (see add_residual_norm_quant_kernel)
-        const int i = (c * TPB + threadIdx.x) * 8;
-        if (i < hidden) {
-            v[c] = load8(in + base + i);
-            g[c] = load8(gamma + i);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int i = (c * TPB + threadIdx.x) * 8;
-        if (i < hidden) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s += (float)v[c][j];
-        }
-    }
-    const float mean = block_reduce_once(s, sm[0], 0) / hidden;                  // :248
-    float vs = 0.f;
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-        if ((c * TPB + threadIdx.x) * 8 < hidden) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float d = (float)v[c][j] - mean;
-                vs += d * d;
-            }
-        }
-    const float rstd_e = 1.0f / sqrtf(block_reduce_once(vs, sm[1], 0) / hidden + eps);   // :271 (rsqrtf there)
-    float amax = (float)(_Float16)1e-6f, sum = 0.f;                      // :285-286 (amax, sum start values)
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-        if ((c * TPB + threadIdx.x) * 8 < hidden) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const _Float16 hv = (_Float16)ln_val((float)v[c][j], mean, rstd_e, (float)g[c][j]);   // cast to half, :292
-                amax = fmaxf(amax, fabsf((float)hv));
-                sum += (float)hv;
-            }
-        }
-    block_reduce_max_sum(amax, sum, sm[2], sm[3], sum_out != nullptr);
-    
-    const float mul = 127.f / amax;                                      // :308
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int i = (c * TPB + threadIdx.x) * 8;
-        if (i < hidden) {
-            float f[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = ln_val((float)v[c][j], mean, rstd_e, (float)g[c][j]);   // fp32, :315
-            store_q8(out + base + i, f, mul);
-        }
-    }
-    if (threadIdx.x == 0) {
-        scale_out[blockIdx.x] = __float2half_rn(amax / 127.f);           // :322
-        if (sum_out) sum_out[blockIdx.x] = __float2half_rn(sum);         // :323
-    }
+    qs_row::norm_quant_row<NC, TPB / 64, TPB / 64, false, false>(
+        out + base, const_cast<_Float16*>(in) + base, nullptr, gamma, sum_out ? sum_out + blockIdx.x : nullptr,
+        scale_out + blockIdx.x, eps, hidden, sm, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -264,71 +172,11 @@ __global__ __launch_bounds__(TPB) void add_residual_norm_quant_kernel(int8_t* __
                                                                       __half* __restrict__ sum_out,
                                                                       __half* __restrict__ scale_out, float eps,
                                                                       int hidden) {
-    __shared__ float sm[4][TPB / 64];
+    __shared__ float sm[4 * (TPB / 64)];
     const size_t base = (size_t)blockIdx.x * hidden;
-    h8 v[NC], g[NC], dl[NC];
-    float s = 0.f;
-    // every load of the row is requested before the first one is used (with load and use in one loop body the second
-    // chunk's requests left only after the first chunk's data had arrived: two memory round trips instead of one)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int i = (c * TPB + threadIdx.x) * 8;
-        if (i < hidden) {
-            v[c] = load8(hidden_io + base + i);
-            dl[c] = load8(delta + base + i);
-            g[c] = load8(gamma + i);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int i = (c * TPB + threadIdx.x) * 8;
-        if (i < hidden) {
-            v[c] = v[c] + dl[c];                                             // residual_add_kernel's fp16 add
-            *reinterpret_cast<h8*>(hidden_io + base + i) = v[c];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s += (float)v[c][j];
-        }
-    }
-    const float mean = block_reduce_once(s, sm[0], 0) / hidden;
-    float vs = 0.f;
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-        if ((c * TPB + threadIdx.x) * 8 < hidden) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float d = (float)v[c][j] - mean;
-                vs += d * d;
-            }
-        }
-    const float rstd_e = 1.0f / sqrtf(block_reduce_once(vs, sm[1], 0) / hidden + eps);
-    float amax = (float)(_Float16)1e-6f, sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-        if ((c * TPB + threadIdx.x) * 8 < hidden) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const _Float16 hv = (_Float16)ln_val((float)v[c][j], mean, rstd_e, (float)g[c][j]);
-                amax = fmaxf(amax, fabsf((float)hv));
-                sum += (float)hv;
-            }
-        }
-    block_reduce_max_sum(amax, sum, sm[2], sm[3], sum_out != nullptr);
-    
-    const float mul = 127.f / amax;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int i = (c * TPB + threadIdx.x) * 8;
-        if (i < hidden) {
-            float f[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = ln_val((float)v[c][j], mean, rstd_e, (float)g[c][j]);
-            store_q8(out + base + i, f, mul);
-        }
-    }
-    if (threadIdx.x == 0) {
-        scale_out[blockIdx.x] = __float2half_rn(amax / 127.f);
-        if (sum_out) sum_out[blockIdx.x] = __float2half_rn(sum);
-    }
+    qs_row::norm_quant_row<NC, TPB / 64, TPB / 64, true, false>(
+        out + base, hidden_io + base, delta + base, gamma, sum_out ? sum_out + blockIdx.x : nullptr,
+        scale_out + blockIdx.x, eps, hidden, sm, (int)threadIdx.x);
 }
 
 //   silu_mul_quant : act = silu_and_mul(input) rounded to fp16 (never written) ; invoke_quant(_fuse_sum)(act)
@@ -582,7 +430,12 @@ __global__ __launch_bounds__(1024) void argmax_rows_split_kernel(const _Float16*
     u32 u = __builtin_bit_cast(u32, bv);
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                 // monotone in the float order, never 0
     const unsigned long long key = ((unsigned long long)u << 32) | (0xFFFFFFFFu - (u32)bi);
-    (void)__hip_atomic_fetch_max(keys + r, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // returns: performed
+    // The ticket must not overtake the key: keys[r] and tickets[r] are different addresses (possibly different L2 channels)
+    // and relaxed atomics are not ordered among themselves.  A RETURNING atomic has been performed at the device-coherent
+    // level once its value is back, so the maximum's return value is consumed (the compiler waits for it) before the
+    // ticket is drawn; the last arriver's exchange then sees every part's maximum.
+    const unsigned long long prev = __hip_atomic_fetch_max(keys + r, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"((u32)prev), "v"((u32)(prev >> 32)) : "memory");
     const unsigned t = __hip_atomic_fetch_add(tickets + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t != (unsigned)(nsplit - 1)) return;
     const unsigned long long k = __hip_atomic_exchange(keys + r, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -609,7 +462,9 @@ ArgmaxWs* argmax_ws(hipStream_t stream) {
         }
         w.tried = true;
         void* a = nullptr;
-        if (hipMalloc(&a, ARGMAX_WS_ROWS * 12) == hipSuccess && hipMemset(a, 0, ARGMAX_WS_ROWS * 12) == hipSuccess) {
+        // (the memset runs on the NULL stream: synchronise, or a launch on a non-blocking stream could overtake it)
+        if (hipMalloc(&a, ARGMAX_WS_ROWS * 12) == hipSuccess && hipMemset(a, 0, ARGMAX_WS_ROWS * 12) == hipSuccess &&
+            hipDeviceSynchronize() == hipSuccess) {
             w.keys = reinterpret_cast<unsigned long long*>(a);
             w.tickets = reinterpret_cast<unsigned*>(w.keys + ARGMAX_WS_ROWS);
         } else {

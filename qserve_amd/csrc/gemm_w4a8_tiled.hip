@@ -551,7 +551,8 @@ int qs_launch_gemm_tiled(int mode, int outk, const int8_t* A, const uint8_t* W, 
 #define QS_T(MTV, MODEV, OUTV) \
     return launch_tiled<MTV, MODEV, OUTV>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, stream)
     const bool big = mtile == 0 ? M > 128 : mtile == 8;
-    if (mode == 0 && outk == 0 && big && g_tiled_dbg) {   // timing experiments only (results are wrong by design)
+#ifdef QS_TIMING   // timing experiments (results are wrong by design): not in the shipped library
+    if (mode == 0 && outk == 0 && big && g_tiled_dbg) {
 #define QS_D(D) case D: return launch_tiled<8, 0, 0, D>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, stream)
         switch (g_tiled_dbg) {
             QS_D(1); QS_D(2); QS_D(3); QS_D(4); QS_D(6); QS_D(8); QS_D(10); QS_D(14);
@@ -559,6 +560,7 @@ int qs_launch_gemm_tiled(int mode, int outk, const int8_t* A, const uint8_t* W, 
         }
 #undef QS_D
     }
+#endif
     if (mode == 0 && outk == 2) { if (big) QS_T(8, 0, 2); QS_T(4, 0, 2); }
     if (mode == 1 && outk == 2) { if (big) QS_T(8, 1, 2); QS_T(4, 1, 2); }
     if (mode == 0 && outk == 0) { if (big) QS_T(8, 0, 0); QS_T(4, 0, 0); }

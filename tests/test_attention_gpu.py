@@ -85,10 +85,10 @@ def run_case(gpu, B, H, Hkv, lengths, int4, seed):
     assert bad == 0, (f"{bad} outputs out of tolerance; max abs err {ek.max():.2e} (kernel-order oracle) / "
                       f"{ef.max():.2e} (fp32 oracle)")
     long_rows = pr["lengths"] >= 64        # realistic contexts: plain 1e-3 against the exact de-quantisation,
-    if long_rows.any():                    # and 1e-3 + the modes' own spread against the fp16-order restatements
+    if long_rows.any():                    # the same plain 1e-3 against the reference-order ("kernel") and fp32 restatements
         assert ee[long_rows].max() <= TOL, f"max abs err vs exact oracle {ee[long_rows].max():.2e}"
-        spread = np.abs(refs[:2] - refs[2]).max(0)[long_rows]
-        assert (ek[long_rows] <= TOL + spread).all() and (ef[long_rows] <= TOL + spread).all()
+        assert ek[long_rows].max() <= TOL, f"max abs err vs reference-order oracle {ek[long_rows].max():.2e}"
+        assert ef[long_rows].max() <= TOL, f"max abs err vs fp32 oracle {ef[long_rows].max():.2e}"
     return ek.max(), ef.max()
 
 
@@ -338,3 +338,105 @@ def test_attention_quant_fusion_is_bit_identical_to_the_pair(gpu, B, H, Hkv, L, 
         assert torch.equal(q2, q1), "int8 row differs"
         assert torch.equal(m2.view(torch.int16), m1.view(torch.int16)), "row sum differs (or was touched without being asked for)"
         assert torch.equal(p2.k, p1.k) and torch.equal(p2.v, p1.v), "cache pages differ"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Parity against the REFERENCE-ORDER restatement at BASELINE sizes.  The oracle's "kernel" mode
+# follows the reference's own arithmetic (fp16 hfma2 de-quantisation, fp16 partial dot products, probabilities rounded to
+# fp16, fp16 tree reduction: decoderMaskedMultiheadAttentionTemplate.hpp:450-467, 1474-1624, 1794-1845, 1901-1977,
+# 2163-2187).  The HIP kernels compute exact math on the cache integers; north_star's bar is 1e-3 between the two.  Every
+# case goes through the production entry of the decode step (attention + fused quantiser), writes max |err| against the
+# three oracle modes into gpurun_out/round3_attention_parity.json (copied to profiles/), then asserts the plain 1e-3.
+# ---------------------------------------------------------------------------------------------------------------------
+_PARITY_RECORD = {}
+
+
+def _record_parity(name, entry):
+    import json
+    import os
+    _PARITY_RECORD[name] = entry
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "round3_attention_parity.json"), "w") as f:
+            json.dump(dict(tolerance=TOL, note="max |HIP fp16 output - oracle| over the sampled sequences x all heads x 128 "
+                                              "dims; oracle modes: kernel = the reference's own precisions / order, fp32 = "
+                                              "fp16-rounded cache values + fp64 math, exact = un-rounded de-quantisation",
+                           cases=_PARITY_RECORD), f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def reference_order_case(gpu, name, B, L, int4, sample, H=32, Hkv=8, seed=3):
+    import qserve_backend.fused_attention as fa
+    from qserve_amd import fused
+    g = torch.Generator(device=gpu).manual_seed(seed)
+    mb = (L + 63) // 64
+    nblocks = B * mb
+    dhb = 64 if int4 else 128
+    spt = Hkv * dhb
+    pools = DevPools(nblocks, Hkv, int4, gpu, fill=0)
+    tables = torch.stack([torch.randperm(nblocks, generator=torch.Generator().manual_seed(seed + 1)).reshape(B, mb),
+                          torch.randperm(nblocks, generator=torch.Generator().manual_seed(seed + 2)).reshape(B, mb)], dim=1)
+    ptrs = pools.pointers(tables.numpy())
+    T = B * (L - 1)
+    qkv = torch.randn((T, (H + 2 * Hkv) * 128), generator=g, device=gpu, dtype=torch.float16)
+    seq = torch.full((B,), L - 1, dtype=torch.int32, device=gpu)
+    cu = torch.arange(0, B + 1, dtype=torch.int32, device=gpu) * (L - 1)
+    pad = fa.compute_padding_offsets(cu, L - 1, T)
+    fa.apply_bias_rope_update_kv_cache(qkv, seq, pad, ptrs, H, Hkv, L - 1, 64, spt, 128, ROPE, 8192, True, int4, True)
+    del qkv
+    torch.cuda.synchronize()
+    k_host, v_host = pools.k.cpu().numpy().copy(), pools.v.cpu().numpy().copy()     # the cache BEFORE the decode step
+    new = torch.randn((B, (H + 2 * Hkv) * 128), generator=g, device=gpu, dtype=torch.float16)
+    q, k, v = new.split([H * 128, Hkv * 128, Hkv * 128], dim=-1)
+    q, k, v = q.reshape(B, H, 128), k.reshape(B, Hkv, 128), v.reshape(B, Hkv, 128)
+    lens = torch.full((B,), L, dtype=torch.int32, device=gpu)
+    qo = torch.empty((B, H * 128), dtype=torch.int8, device=gpu)
+    qs = torch.empty((B,), dtype=torch.float16, device=gpu)
+    qm = torch.empty((B,), dtype=torch.float16, device=gpu)
+    out = fused.single_query_attention_quant(q, k, v, ptrs, lens, qo, qs, 8192, 64, spt, L, 128, ROPE, True, int4, True,
+                                             quant_sum=qm)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().astype(np.float32)
+    sample = [s for s in sample if s < B]
+    qn, kn, vn = (t.cpu().numpy() for t in (q, k, v))
+    tb = tables.numpy()
+    errs = {}
+    for mode in ("kernel", "fp32", "exact"):
+        pool = kvattn.PagePool(nblocks, Hkv, 128, int4, fill=0)
+        pool.k[:], pool.v[:] = k_host, v_host
+        ref = kvattn.decode_attention(qn[sample], kn[sample], vn[sample], tb[sample], np.full(len(sample), L, np.int32),
+                                      pool, ROPE, mode)
+        errs[mode] = float(np.abs(o[sample] - ref.astype(np.float32)).max())
+        if mode == "kernel":     # cache bytes of the sampled sequences' new token == the oracle's
+            kd, vd = pools.k.cpu().numpy(), pools.v.cpu().numpy()
+            for s in sample:
+                bk, bv = tb[s, 0, (L - 1) // 64], tb[s, 1, (L - 1) // 64]
+                assert np.array_equal(kd[bk], pool.k[bk]) and np.array_equal(vd[bv], pool.v[bv]), "new-token cache bytes"
+    from qserve_amd import _lib
+    import ctypes
+    plan = (ctypes.c_int * 3)()
+    _lib.lib.qs_attention_plan(B, H, Hkv, mb, L, int(int4), plan)
+    _record_parity(name, dict(batch=B, context=L, kv="KV4" if int4 else "KV8", heads=H, kv_heads=Hkv,
+                              sampled_sequences=sample, kernel_family=int(plan[0]), kv_splits=int(plan[1]),
+                              entry="qs_single_query_attention_quant", max_abs_err_vs_kernel_order=errs["kernel"],
+                              max_abs_err_vs_fp32=errs["fp32"], max_abs_err_vs_exact=errs["exact"],
+                              max_abs_output=float(np.abs(o[sample]).max())))
+    assert errs["kernel"] <= TOL, f"max |err| vs the reference-order oracle {errs['kernel']:.3e} > 1e-3"
+    assert errs["fp32"] <= TOL and errs["exact"] <= TOL, errs
+    return errs
+
+
+@pytest.mark.parametrize("L", [1024, 1280, 1535])
+def test_config2_matches_reference_order_oracle(gpu, L):
+    """BASELINE config 2 (bs = 64, H = 32 / Hkv = 8, KV4) at the start / middle / end of the generation: four sampled
+    sequences x 32 heads against oracle mode "kernel", plain 1e-3."""
+    reference_order_case(gpu, f"config2_L{L}", 64, L, True, sample=[0, 21, 42, 63], seed=L)
+
+
+@pytest.mark.parametrize("int4", [False, True], ids=["kv8", "kv4"])
+def test_config5_matches_reference_order_oracle(gpu, int4):
+    """BASELINE config 5 (bs = 8, L = 8191, KV8) and its KV4 twin, the dispatcher's own split-KV launch + merge."""
+    reference_order_case(gpu, f"config5_L8191_{'kv4' if int4 else 'kv8'}", 8, 8191, int4, sample=[5], seed=8191 + int4)
