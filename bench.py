@@ -66,9 +66,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the context sweep and the eager / op-by-op timings")
     ap.add_argument("--op-by-op", action="store_true",
                     help="issue the reference's ops one by one (no fused pairs) in the timed step")
-    ap.add_argument("--no-tails", action="store_true",
-                    help="round-2 op sequence: fused pairs, but the row kernels between the GEMMs as their own launches "
-                         "(8 launches per layer instead of 5)")
+    ap.add_argument("--tails", action="store_true",
+                    help="A/B: run the row kernels between the GEMMs as tails of the GEMM launches (5 launches per layer "
+                         "instead of 8; bit-identical, measured slower on MI355X - DESIGN.md)")
     ap.add_argument("--gemm-variant", type=int, default=-1, help="A/B: qs_set_gemm_variant code (include/qserve_amd.h)")
     ap.add_argument("--attn-variant", type=int, default=0, help="A/B: qs_set_attention_variant code")
     ap.add_argument("--tp-full-graph", action="store_true",
@@ -406,7 +406,7 @@ def main():
         direct, collective_note = direct_allreduce_or_none(args.batch * cfg["hidden"], rank, world, dev, mode)
     eng = D.DecodeEngine(cfg, args.batch, args.prompt_len, args.max_new, group_size=args.group_size,
                          int4_kv=not args.kv8, device=dev, tp_rank=rank, tp_world=world,
-                         fuse_pairs=not args.op_by_op, direct_allreduce=direct, fuse_tails=not args.no_tails)
+                         fuse_pairs=not args.op_by_op, direct_allreduce=direct, fuse_tails=args.tails)
     # the whole cache of the generation (prompt + max_new - 1 positions) is written by the prefill writer up front, so
     # that any context of the run (start / mid / end) reads real quantised pages; `lengths` selects the context
     full_ctx = args.prompt_len + args.max_new - 1

@@ -107,7 +107,9 @@ typedef __attribute__((address_space(3))) const uint8_t* lds_u8;   // 32-bit LDS
 //   1 = page DMA WITHOUT the non-temporal hint (default: nt - every KV byte is read once per step; measured -4 % at
 //       L = 1033 ... -12 % at L = 4096), 2 = no compute (DMA + waits only: results are wrong by design),
 //   4 = skip phase A (RoPE / new token: wrong by design), 8 = fetch the last page in full (default: only the rows of
-//       valid tokens), 32 = timeline trace (s_memtime stamps into the split workspace, scripts/trace_attn.py)
+//       valid tokens), 32 = timeline trace (s_memtime stamps into the split workspace, scripts/trace_attn.py),
+//   64 = no new-token cache write / own score at the end (wrong), 128 = RoPE without the dependent table load (wrong),
+//   256 = the service wave owns no pages (correct results)
 template <int G, int EXP = 0>
 __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
@@ -140,7 +142,10 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     const int64_t* vtab = ktab + max_blocks;
     // first-round page addresses are requested together with the length (they do not depend on it when this workgroup
     // starts at page 0): one memory round trip less on the launch -> first bytes chain
-    const bool spec = (nsplit == 1 || blockIdx.z == 0) && wave < max_blocks;
+    // (timing builds: EXP & 256 = the service wave owns no pages, the other seven take them round-robin)
+    constexpr int PS = (EXP & 256) ? NW - 1 : NW;                     // page stride of a wave
+    const bool pages_here = PS == NW || wave != SVC;
+    const bool spec = (nsplit == 1 || blockIdx.z == 0) && wave < max_blocks && pages_here;
     int64_t kpage0 = 0, vpage0 = 0;
     if (spec) {
         kpage0 = ktab[wave];
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     // and its own score follow on the service wave after its pages, off everybody's critical path.
     // (A ninth, page-less wave was tried first: 576-thread workgroups no longer fit twice on a CU - 26 vs 20 us.)
     const int blk = tl >> 6, slot = tl & 63;
-    const bool has_page = p_begin + wave < p_end;
+    const bool has_page = p_begin + wave < p_end && pages_here;
     if (tid == SVC * 64) s_flag = 0;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // start-of-kernel barrier (raw: the service wave's loads stay in flight)
     auto first_round = [&]() {
@@ -297,7 +302,10 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         if constexpr (!(EXP & 4)) {
             // ordinary loads: this wave's queue carries nothing else, the compiler's own counted waits are right here
             RopeCS cs;
-            if (rope_tab && tl < rope_tab_len) {
+            if constexpr (EXP & 128) {                 // timing: no dependent table load (identity rotation: wrong by design)
+                cs.c = 1.f;
+                cs.s = 0.f;
+            } else if (rope_tab && tl < rope_tab_len) {
                 const float2 t = rope_tab[(size_t)tl * 64 + lane];   // same double-evaluated, float-rounded values
                 cs.c = t.x;
                 cs.s = t.y;
@@ -371,20 +379,20 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     for (int e = 0; e < 8; ++e) acc[e] = (v4f){0.f, 0.f, 0.f, 0.f};
     float m_run = -3.0e38f, l_part = 0.f, corr = 0.f, psum = 0.f;   // psum = sum of P' (removes the V operand offsets)
 
-    for (int p = p_begin + wave; p < p_end; p += NW) {
+    for (int p = pages_here ? p_begin + wave : p_end; p < p_end; p += PS) {
         // K(p) landed?  Outstanding younger VMEM ops at this point: the 5 of V(p).
         asm volatile("s_waitcnt vmcnt(5) ; QS_LOOP_BEGIN" ::: "memory");
-        stamp(5 + 2 * min(2, (p - p_begin) / NW));
-        const bool more = p + NW < p_end;
+        stamp(5 + 2 * min(2, (p - p_begin) / PS));
+        const bool more = p + PS < p_end;
         const int valid = min(PAGE_TOK, tl - p * PAGE_TOK);
         const bool full = valid == PAGE_TOK;   // wave-uniform: only the last page needs masking
         int64_t kpage_next = 0, vpage_next = 0;
-        if (more) next_pages(p + NW, kpage_next, vpage_next);
+        if (more) next_pages(p + PS, kpage_next, vpage_next);
         if constexpr (EXP & 2) {               // timing experiment: memory side only
-            if (more) dma_k(kpage_next, min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
+            if (more) dma_k(kpage_next, min(PAGE_TOK, tl - (p + PS) * PAGE_TOK));
             if (more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (more) dma_v(vpage_next, min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
+            if (more) dma_v(vpage_next, min(PAGE_TOK, tl - (p + PS) * PAGE_TOK));
             continue;
         }
 
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
             }
             // K buffer consumed -> request K(p+NW)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (more) dma_k(kpage_next, min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
+            if (more) dma_k(kpage_next, min(PAGE_TOK, tl - (p + PS) * PAGE_TOK));
             float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
             if constexpr (GP == 4) {
                 mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx),
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
             }
             // K buffer consumed -> request K(p+NW)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (more) dma_k(kpage_next, min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
+            if (more) dma_k(kpage_next, min(PAGE_TOK, tl - (p + PS) * PAGE_TOK));
             float mx = sc8[0];
 #pragma unroll
             for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc8[j]);
@@ -628,8 +636,8 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0) ; QS_LOOP_END" ::: "memory");
-        stamp(6 + 2 * min(2, (p - p_begin) / NW));
-        if (more) dma_v(vpage_next, min(PAGE_TOK, tl - (p + NW) * PAGE_TOK));
+        stamp(6 + 2 * min(2, (p - p_begin) / PS));
+        if (more) dma_v(vpage_next, min(PAGE_TOK, tl - (p + PS) * PAGE_TOK));
     }
 
     // ---- per-wave partials -> LDS.  Lane (head li, tg) holds out dims 8*(4tg + r) + e in acc[e][r] ---------------
@@ -658,7 +666,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     // ---- service wave, off every critical path: the new token's cache write (split 0) and its own score -------------------
     // (placed here, after the code the page waves share with it: pending stores of the service wave at a control-flow
     // merge in front of the page loop would make the compiler put a vmcnt(0) there - which drains the page waves' DMA)
-    if constexpr (!(EXP & 4)) {
+    if constexpr (!(EXP & 4) && !(EXP & 64)) {   // (EXP & 64: timing, the new token's cache write and own score skipped)
         if (wave == SVC) {
             if (z == 0) {
                 uint8_t* pgk = reinterpret_cast<uint8_t*>(ktab[blk]);
@@ -1029,6 +1037,12 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
             QS_LAUNCH_EXP(8);
             QS_LAUNCH_EXP(9);
             QS_LAUNCH_EXP(32);
+            QS_LAUNCH_EXP(64);
+            QS_LAUNCH_EXP(128);
+            QS_LAUNCH_EXP(192);
+            QS_LAUNCH_EXP(256);
+            QS_LAUNCH_EXP(320);
+            QS_LAUNCH_EXP(448);
             default: break;
         }
     }

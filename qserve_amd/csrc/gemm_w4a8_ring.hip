@@ -704,7 +704,7 @@ __device__ __forceinline__ int ring_body(const int8_t* __restrict__ A, const uin
 //   TAIL 2: invoke_quant(_fuse_sum) of the [M, N/2] activation row    (quant_kernel<NC, NT>; ACT launches)
 template <int MT, int WN, int OUTK, int TAIL>
 __device__ __forceinline__ void ring_tail(int fin_units, const void* out, int M, int N, int mblocks, int ksplit,
-                                          const QsRingTail& t, uint8_t* smem) {
+                                          const QsRingTail& t, uint8_t* smem, int flags) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores are acknowledged
@@ -720,6 +720,10 @@ __device__ __forceinline__ void ring_tail(int fin_units, const void* out, int M,
         int p = 0;
 #pragma unroll
         for (int w = 0; w < 8; ++w) p += s_i[w];
+        if (flags & 8) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if (p) __hip_atomic_fetch_add(word, (unsigned)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const int P = (N / (64 * WN)) * ksplit;            // workgroups per token block
@@ -742,6 +746,7 @@ __device__ __forceinline__ void ring_tail(int fin_units, const void* out, int M,
                 }
             }
             s_i[8] = 1;
+            if (flags & 4) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
     };
@@ -795,7 +800,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
     const int fin = ring_body<MT, WN, MODE, OUTK, KSPLIT, TAIL != 0>(A, W, zeros, scales8, wscales, ascales, wszs, assums,
                                                                      out, M, N, K, mblocks, ns, ksplit_arg, slabs, counters,
                                                                      flags, smem);
-    if constexpr (TAIL != 0) ring_tail<MT, WN, OUTK, TAIL>(fin, out, M, N, mblocks, KSPLIT ? ksplit_arg : 1, tail, smem);
+    if constexpr (TAIL != 0) ring_tail<MT, WN, OUTK, TAIL>(fin, out, M, N, mblocks, KSPLIT ? ksplit_arg : 1, tail, smem, flags);
 }
 
 template <int MT, int WN, int MODE, int OUTK, bool KSPLIT, int TAIL = 0>

@@ -23,11 +23,23 @@ constexpr int WIDE_ROW = 4096;
 
 __device__ __forceinline__ h8 load8(const _Float16* p) { return *reinterpret_cast<const h8*>(p); }
 
-// 16-byte load that bypasses the caches (sc0 sc1): rows another workgroup of the SAME launch published with write-through
-// stores (the fence-free seam of gemm_w4a8_ring.hip / attention_mfma.hip).  The destination is valid after wait_sc().
-__device__ __forceinline__ void load8_sc(v4u& dst, const _Float16* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(dst) : "v"(p) : "memory");
-}
+// 16-byte loads that bypass the caches (sc0 sc1): rows another workgroup of the SAME launch published with write-through
+// stores (the fence-free seam of gemm_w4a8_ring.hip / attention_mfma.hip).  Buffer loads through the BUILTIN (aux 17 =
+// sc0 | sc1): the compiler counts them and waits before the first use.  (An inline-asm load would be invisible to it: the
+// first version of this file had one, and hipcc copied its destination registers before the data had landed -
+// cdna_hip_programming.md 5.7 item 1.)  `row` must be wave-uniform.
+struct ScRow {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ ScRow(const _Float16* row, int elems) {
+        const uint64_t a = (uint64_t)(uintptr_t)row;
+        const uint64_t u = ((uint64_t)(u32)__builtin_amdgcn_readfirstlane((u32)(a >> 32)) << 32) |
+                           (uint64_t)(u32)__builtin_amdgcn_readfirstlane((u32)a);
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(u), 0, elems * 2, 0x00020000);
+    }
+    __device__ __forceinline__ v4u load8(int elem) const {
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, elem * 2, 0, 17);
+    }
+};
 
 __device__ __forceinline__ float ln_val(float x, float mean, float rstd, float g) {
 #pragma clang fp contract(off)
@@ -91,6 +103,7 @@ template <int NC, int NVW, int PW, bool SC, class Hook = NoHook>
 __device__ __forceinline__ void quant_row(int8_t* __restrict__ out, const _Float16* __restrict__ in,
                                           __half* __restrict__ sum_out, __half* __restrict__ scale_out, int hidden,
                                           float* sm, int tid, Hook ready = Hook()) {
+#pragma clang fp contract(off)
     constexpr int VPW = NVW / PW, NT = 64 * NVW;
     static_assert(NVW % PW == 0, "virtual waves must split evenly over the physical waves");
     const int wave = tid >> 6, lane = tid & 63;
@@ -98,27 +111,17 @@ __device__ __forceinline__ void quant_row(int8_t* __restrict__ out, const _Float
     ready();
     v4u raw[VPW][NC];
     if (active) {
+        const ScRow sc(in, SC ? hidden : 0);
 #pragma unroll
         for (int j = 0; j < VPW; ++j)
 #pragma unroll
             for (int c = 0; c < NC; ++c) {                 // all requests first: one memory round trip
                 const int i = (c * NT + tid + j * 64 * PW) * 8;
                 if (i < hidden) {
-                    if (SC) load8_sc(raw[j][c], in + i);
+                    if (SC) raw[j][c] = sc.load8(i);
                     else raw[j][c] = __builtin_bit_cast(v4u, load8(in + i));
                 }
             }
-        if (SC) {
-#pragma unroll
-            for (int j = 0; j < VPW; ++j)
-#pragma unroll
-                for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(raw[j][c]));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int j = 0; j < VPW; ++j)
-#pragma unroll
-                for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(raw[j][c]));   // values exist only after the wait
-        }
     }
     float amax[VPW], sum[VPW];
 #pragma unroll
@@ -174,6 +177,11 @@ __device__ __forceinline__ void norm_quant_row(int8_t* __restrict__ out, _Float1
                                                const _Float16* __restrict__ delta, const _Float16* __restrict__ gamma,
                                                __half* __restrict__ sum_out, __half* __restrict__ scale_out, float eps,
                                                int hidden, float* sm, int tid, Hook ready = Hook()) {
+    // No FMA contraction anywhere in the statistics: `vs += d * d` summed over a row may be fused as fma(d1, d1, round(d0 * d0))
+    // or as fma(d0, d0, round(d1 * d1)) - both are legal contractions and hipcc picks differently from one instantiation to
+    // the next (seen: the 256-thread kernel vs the same code inlined into a GEMM tail differed in one row sum by one fp16
+    // ulp).  Separate roundings are also what the numpy oracle computes.
+#pragma clang fp contract(off)
     constexpr int VPW = NVW / PW, NT = 64 * NVW;
     static_assert(NVW % PW == 0, "virtual waves must split evenly over the physical waves");
     const int wave = tid >> 6, lane = tid & 63;
@@ -196,27 +204,17 @@ __device__ __forceinline__ void norm_quant_row(int8_t* __restrict__ out, _Float1
     }
     ready();
     if (ADD && active) {
+        const ScRow sc(delta, SC ? hidden : 0);
 #pragma unroll
         for (int j = 0; j < VPW; ++j)
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int i = (c * NT + tid + j * 64 * PW) * 8;
                 if (i < hidden) {
-                    if (SC) load8_sc(dl[j][c], delta + i);
+                    if (SC) dl[j][c] = sc.load8(i);
                     else dl[j][c] = __builtin_bit_cast(v4u, load8(delta + i));
                 }
             }
-        if (SC) {
-#pragma unroll
-            for (int j = 0; j < VPW; ++j)
-#pragma unroll
-                for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(dl[j][c]));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int j = 0; j < VPW; ++j)
-#pragma unroll
-                for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(dl[j][c]));
-        }
     }
     float s[VPW];
 #pragma unroll

@@ -7,8 +7,8 @@ It issues exactly the op sequence of the reference's model code for `is_prompt=F
     -> residual add -> rms_norm_general_fuse_sum -> gate_up GEMM -> silu_and_mul -> invoke_quant_fuse_sum
     -> down GEMM -> residual add;   then rms_norm, fp16 lm_head, greedy sampling.
 
-With `fuse_tails=True` (default at world size 1, round 3) the row kernels between the GEMMs additionally run as tails of the
-GEMM launches (5 launches per layer: qkv GEMM, attention + quant, o_proj + add + norm + quant, gate_up + silu * mul + quant,
+With `fuse_tails=True` (round 3; off by default: measured slower, see DecodeEngine.__init__) the row kernels between the
+GEMMs additionally run as tails of the GEMM launches (5 launches per layer: qkv GEMM, attention + quant, o_proj + add + norm + quant, gate_up + silu * mul + quant,
 down_proj + add + norm + quant) - still the same arithmetic and bit-identical tensors (tests/test_gemm_tail_gpu.py).
 With `fuse_pairs=True` (default) the adjacent pairs (attention, quant of its output), (residual add, layer norm) and
 (gate_up GEMM, silu_and_mul) are issued as one launch each (qserve_amd/fused.py) - same arithmetic, same intermediate fp16 roundings, bit-identical tensors
@@ -137,17 +137,20 @@ class W4A8Linear:
 class DecodeEngine:
     def __init__(self, cfg, batch, prompt_len, max_new, group_size=-1, int4_kv=True, device="cuda:0", seed=0,
                  tp_rank=0, tp_world=1, with_lm_head=True, fuse_pairs=True, weights=None, vocab_parallel=True,
-                 direct_allreduce=None, fuse_tails=True):
+                 direct_allreduce=None, fuse_tails=False):
         """weights: None = synthetic random-quantised tensors of the right shapes; otherwise this rank's tensors as
         qserve_amd.loader.load_llama_w4a8 returns them (checkpoint path)."""
         self.cfg, self.B, self.dev = cfg, batch, torch.device(device)
         # fuse_pairs: issue (residual add + layer norm) and (silu_and_mul + quant) as one launch each
         # (qserve_amd/fused.py: bit-identical to the op pairs; False = the reference's exact op-by-op sequence)
         self.fuse_pairs = fuse_pairs
-        # fuse_tails (round 3): the row kernels between the GEMMs run as tails of the GEMM launches (o_proj / down_proj +
-        # residual add + norm + quant, gate_up + silu * mul + quant; qserve_amd/fused.py gemm_*_quant): 5 launches per layer
-        # instead of 8, bit-identical tensors.  Needs fuse_pairs; not under tensor parallelism (the all-reduce sits between
-        # the row-parallel GEMM and the residual add).
+        # fuse_tails (round 3, OFF by default): the row kernels between the GEMMs run as tails of the GEMM launches (o_proj /
+        # down_proj + residual add + norm + quant, gate_up + silu * mul + quant; qserve_amd/fused.py gemm_*_quant): 5 launches
+        # per layer instead of 8, bit-identical tensors - and MEASURED SLOWER on MI355X (in-run A/B, profiles/round3_a_*:
+        # 19.5 k vs 21.6 k tokens/s; every tail costs 7.5-9 us against 4.9 us + a 0.45 us gap for the row kernel it
+        # replaces: the all-to-all seam inside a launch - write-through stores, acknowledgement, device-scope ticket, poll,
+        # cache-bypassing re-read - is four dependent memory round trips, a kernel boundary is cheaper).  Needs fuse_pairs;
+        # not under tensor parallelism (the all-reduce sits between the row-parallel GEMM and the residual add).
         self.fuse_tails = bool(fuse_tails and fuse_pairs and tp_world == 1)
         self.tp_rank, self.tp_world = tp_rank, tp_world
         self.group_size, self.int4 = group_size, int4_kv

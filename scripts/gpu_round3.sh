@@ -15,7 +15,7 @@ for w in $WHAT; do
 case $w in
 tests)
   echo "=== pytest -m gpu"
-  timeout 1500 python -m pytest tests -q -m gpu --timeout 600 --tb=short -x > gpurun_out/pytest_gpu_$TAG.log 2>&1
+  timeout 1500 python -m pytest tests -q -m gpu --timeout 600 --tb=short > gpurun_out/pytest_gpu_$TAG.log 2>&1
   grep -E "^(E   |FAILED|ERROR)|passed|failed" gpurun_out/pytest_gpu_$TAG.log | cut -c1-300 | sort | uniq -c | head -30
   echo "=== smoke"
   timeout 600 python __graft_entry__.py smoke 2>&1 | tail -3 ;;
@@ -23,12 +23,12 @@ bench)
   echo "=== bench"
   timeout 1200 python bench.py 2> gpurun_out/bench_$TAG.err > gpurun_out/bench_$TAG.json
   cut -c1-600 gpurun_out/bench_$TAG.json
-  echo "=== bench, round-2 op sequence (A/B in the same call)"
-  timeout 600 python bench.py --no-tails --no-cpu-baseline --no-prefill --no-extras 2>/dev/null > gpurun_out/bench_${TAG}_notails.json
-  cut -c1-300 gpurun_out/bench_${TAG}_notails.json
+  echo "=== bench with the row-op tails (A/B in the same call)"
+  timeout 600 python bench.py --tails --no-cpu-baseline --no-prefill --no-extras 2>/dev/null > gpurun_out/bench_${TAG}_tails.json
+  cut -c1-300 gpurun_out/bench_${TAG}_tails.json
   python - <<PY
 import json
-for f in ("gpurun_out/bench_$TAG.json", "gpurun_out/bench_${TAG}_notails.json"):
+for f in ("gpurun_out/bench_$TAG.json", "gpurun_out/bench_${TAG}_tails.json"):
     try:
         d = json.load(open(f))
         print(f, d["value"], d["ms_per_step"], [(k["kernel"].split("[")[1].split(" ")[0], k["us"]) for k in d["kernels"]])
