@@ -200,21 +200,6 @@ int qs_single_query_attention_quant(const void* q, const void* k, const void* v,
                                     float rotary_base, int neox_rotary_style, int int4_kv_cache, int kv_cache_with_zeros,
                                     qs_stream_t stream);
 
-/* The same op for q and k that ALREADY carry RoPE for position length - 1 (written by qs_w4a8_*_gemm_rope below - RoPE as
- * part of the qkv projection's epilogue instead of the attention kernel's prologue; no reference counterpart).  v is the raw
- * new token as above.  The new token's rotated k and raw v are quantised into the cache, attention runs over cache + new
- * token.  quant_out / quant_scale / quant_sum (all NULL: no quantiser) receive invoke_quant(_fuse_sum) of the output as in
- * qs_single_query_attention_quant.  out, the cache bytes and the quantiser's results are BIT-IDENTICAL to the un-rotated
- * entry points on the un-rotated tensors.  Only the KV4 matrix-core kernel has this form: QS_ENOSUP for KV8, page tables
- * wider than 192 entries, group sizes above 4 or qs_set_attention_variant(1) (callers then keep RoPE inside the attention op). */
-int qs_single_query_attention_rotated(const void* q, const void* k, const void* v, const int64_t* kv_pointers,
-                                      const int32_t* length_per_sample, void* out, int8_t* quant_out, void* quant_sum,
-                                      void* quant_scale, int batch, int num_heads, int num_kv_heads, int head_dim,
-                                      int64_t q_stride0, int64_t kv_stride0, int max_blocks, int memory_max_seqlen,
-                                      int tokens_per_block, int size_per_token, int timestep, int rotary_embedding_dim,
-                                      float rotary_base, int neox_rotary_style, int int4_kv_cache, int kv_cache_with_zeros,
-                                      qs_stream_t stream);
-
 /* Kernel selection for A/B tests: 0 = matrix-core kernels (KV4 and KV8) with the split-KV heuristic [default],
  * 1 = VALU kernels, 2 = prefill writer without the RoPE table, 100 + n = matrix-core kernels with exactly n KV splits.
  * (200 + bits: ablation / trace instantiations of the KV4 kernel, QS_TIMING builds only; ignored by the shipped library.) */

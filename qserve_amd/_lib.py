@@ -37,8 +37,6 @@ SIGNATURES = {
                                        _i, _f, _i, _i, _i, _vp]),
     "qs_single_query_attention_quant": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _i,
                                              _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
-    "qs_single_query_attention_rotated": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _i,
-                                               _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
     "qs_apply_bias_rope_update_kv_cache": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i,
                                                 _i, _i, _vp]),
     "qs_compute_padding_offsets": (_i, [_vp, _vp, _i, _i, _vp]),

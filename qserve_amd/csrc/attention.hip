@@ -623,7 +623,7 @@ const float2* qs_rope_table(float base, int max_pos, hipStream_t st, int* len_ou
 // KV4 fast path on the matrix cores (attention_mfma.hip)
 int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
                           const int64_t* kvp, const int* len, _Float16* out, int H, int Hkv, int64_t qs, int64_t kvs,
-                          int mb, int timestep, float base, int max_pos, int force_split, bool prerotated);
+                          int mb, int timestep, float base, int max_pos, int force_split);
 // KV8 twin (attention_mfma8.hip)
 int qs_launch_decode_mfma8(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
                            const int64_t* kvp, const int* len, _Float16* out, int H, int Hkv, int64_t qs, int64_t kvs,
@@ -633,14 +633,13 @@ int qs_launch_decode_mfma8(int G, dim3 grid, hipStream_t st, const _Float16* q, 
 static int g_attn_variant = 0;
 extern "C" void qs_set_attention_variant(int variant) { g_attn_variant = variant; }
 
-// prerotated: q and the new token's k already carry RoPE for position length - 1 (qs_w4a8_*_gemm_rope wrote them); only
-// the KV4 matrix-core kernel has that form (QS_ENOSUP otherwise: the caller then keeps RoPE inside the attention op)
-static int attention_impl(const void* q, const void* k, const void* v, const int64_t* kv_pointers,
-                          const int32_t* length_per_sample, void* out, int batch, int num_heads, int num_kv_heads,
-                          int head_dim, int64_t q_stride0, int64_t kv_stride0, int max_blocks, int memory_max_seqlen,
-                          int tokens_per_block, int size_per_token, int timestep, int rotary_embedding_dim,
-                          float rotary_base, int neox_rotary_style, int int4_kv_cache, int kv_cache_with_zeros,
-                          qs_stream_t stream, bool prerotated) {
+extern "C" int qs_single_query_attention(const void* q, const void* k, const void* v, const int64_t* kv_pointers,
+                                         const int32_t* length_per_sample, void* out, int batch, int num_heads,
+                                         int num_kv_heads, int head_dim, int64_t q_stride0, int64_t kv_stride0,
+                                         int max_blocks, int memory_max_seqlen, int tokens_per_block,
+                                         int size_per_token, int timestep, int rotary_embedding_dim, float rotary_base,
+                                         int neox_rotary_style, int int4_kv_cache, int kv_cache_with_zeros,
+                                         qs_stream_t stream) {
     QS_REQUIRE(q && k && v && kv_pointers && out, "single_query_attention: null pointer");
     QS_REQUIRE(batch >= 0 && num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
                "single_query_attention: bad head counts H=%d Hkv=%d", num_heads, num_kv_heads);
@@ -660,16 +659,11 @@ static int attention_impl(const void* q, const void* k, const void* v, const int
     hipStream_t st = (hipStream_t)stream;
     // the matrix-core kernel caches a sequence's page addresses in LDS (192 pages = 12288 tokens per sequence); longer
     // page tables take the VALU kernel
-    if (int4_kv_cache && g_attn_variant != 1 && max_blocks <= 192 && G <= 8)
+    if (int4_kv_cache && g_attn_variant != 1 && max_blocks <= 192)
         return qs_launch_decode_mfma(G, grid, st, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
                                      kv_pointers, length_per_sample, (_Float16*)out, num_heads, num_kv_heads,
                                      q_stride0, kv_stride0, max_blocks, timestep, rotary_base, memory_max_seqlen,
-                                     g_attn_variant >= 100 ? g_attn_variant - 100 : 0, prerotated);
-    if (prerotated) {
-        qs_set_error("single_query_attention_rotated: only the KV4 matrix-core kernel takes pre-rotated q / k (KV4, page "
-                     "tables of <= 192 entries, group size <= 4)");
-        return QS_ENOSUP;
-    }
+                                     g_attn_variant >= 100 ? g_attn_variant - 100 : 0);
     if (!int4_kv_cache && g_attn_variant != 1 && max_blocks <= 192)
         return qs_launch_decode_mfma8(G, grid, st, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
                                       kv_pointers, length_per_sample, (_Float16*)out, num_heads, num_kv_heads,
@@ -682,42 +676,6 @@ static int attention_impl(const void* q, const void* k, const void* v, const int
     return launch_decode<false>(G, grid, st, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v, kv_pointers,
                                 length_per_sample, (_Float16*)out, num_heads, num_kv_heads, q_stride0, kv_stride0,
                                 max_blocks, timestep, rotary_base);
-}
-
-extern "C" int qs_single_query_attention(const void* q, const void* k, const void* v, const int64_t* kv_pointers,
-                                         const int32_t* length_per_sample, void* out, int batch, int num_heads,
-                                         int num_kv_heads, int head_dim, int64_t q_stride0, int64_t kv_stride0,
-                                         int max_blocks, int memory_max_seqlen, int tokens_per_block,
-                                         int size_per_token, int timestep, int rotary_embedding_dim, float rotary_base,
-                                         int neox_rotary_style, int int4_kv_cache, int kv_cache_with_zeros,
-                                         qs_stream_t stream) {
-    return attention_impl(q, k, v, kv_pointers, length_per_sample, out, batch, num_heads, num_kv_heads, head_dim, q_stride0,
-                          kv_stride0, max_blocks, memory_max_seqlen, tokens_per_block, size_per_token, timestep,
-                          rotary_embedding_dim, rotary_base, neox_rotary_style, int4_kv_cache, kv_cache_with_zeros, stream,
-                          false);
-}
-
-// The same op for q / k that ALREADY carry RoPE (qs_w4a8_*_gemm_rope): attention over the cache + the new token, the new
-// token's rotated k and raw v quantised into the cache, optionally followed by invoke_quant(_fuse_sum) of the output
-// (quant_out NULL: no quantiser).  Bit-identical to the un-rotated call on the un-rotated tensors.
-extern "C" int qs_single_query_attention_rotated(const void* q, const void* k, const void* v, const int64_t* kv_pointers,
-                                                 const int32_t* length_per_sample, void* out, int8_t* quant_out,
-                                                 void* quant_sum, void* quant_scale, int batch, int num_heads,
-                                                 int num_kv_heads, int head_dim, int64_t q_stride0, int64_t kv_stride0,
-                                                 int max_blocks, int memory_max_seqlen, int tokens_per_block,
-                                                 int size_per_token, int timestep, int rotary_embedding_dim,
-                                                 float rotary_base, int neox_rotary_style, int int4_kv_cache,
-                                                 int kv_cache_with_zeros, qs_stream_t stream) {
-    QS_REQUIRE(!quant_out || quant_scale, "single_query_attention_rotated: quant_out without quant_scale");
-    if (quant_out) g_qs_attn_quant = {quant_out, quant_scale, quant_sum, 0};
-    const int rc = attention_impl(q, k, v, kv_pointers, length_per_sample, out, batch, num_heads, num_kv_heads, head_dim,
-                                  q_stride0, kv_stride0, max_blocks, memory_max_seqlen, tokens_per_block, size_per_token,
-                                  timestep, rotary_embedding_dim, rotary_base, neox_rotary_style, int4_kv_cache,
-                                  kv_cache_with_zeros, stream, true);
-    const int done = g_qs_attn_quant.done;
-    g_qs_attn_quant = {nullptr, nullptr, nullptr, 0};
-    if (rc != QS_OK || !quant_out || done || batch == 0) return rc;
-    return qs_invoke_quant(quant_out, out, quant_sum, quant_scale, batch, num_heads * head_dim, stream);
 }
 
 thread_local QsAttnPlan g_qs_attn_plan = {0, 0, 0, 0};

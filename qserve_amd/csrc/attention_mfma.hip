@@ -110,12 +110,7 @@ typedef __attribute__((address_space(3))) const uint8_t* lds_u8;   // 32-bit LDS
 //       valid tokens), 32 = timeline trace (s_memtime stamps into the split workspace, scripts/trace_attn.py),
 //   64 = no new-token cache write / own score at the end (wrong), 128 = RoPE without the dependent table load (wrong),
 //   256 = the service wave owns no pages (correct results)
-// PRE (qs_single_query_attention_rotated*): q and the new token's k arrive ALREADY rotated (the qkv GEMM's epilogue applied
-//   RoPE, gemm_w4a8_ring.hip OUTK 3).  No service wave, no flag, no start barrier: every wave fetches the group's q rows by
-//   LDS-DMA (same bytes to the same place from all eight waves - each waits for its own copy only), builds the Q.K^T operand
-//   image itself and starts on its pages; the new token's k / v travel the same way to the last wave, which quantises
-//   them into the cache and computes the token's own score after its pages.  The page loop is the same code.
-template <int G, int EXP = 0, bool PRE = false>
+template <int G, int EXP = 0>
 __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
     const int64_t* __restrict__ kv_pointers, const int* __restrict__ lengths, _Float16* __restrict__ out,
@@ -127,7 +122,6 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     __shared__ __attribute__((aligned(16))) _Float16 s_q[G][DH];                // rotated q of the G heads
     __shared__ __attribute__((aligned(16))) _Float16 s_qp[16][DH];              // Q.K^T B operand (see below)
     __shared__ __attribute__((aligned(16))) _Float16 s_knew[DH];
-    __shared__ __attribute__((aligned(16))) _Float16 s_vnew[PRE ? DH : 8];      // PRE: the new token's raw v
     __shared__ float s_cur[16];
     __shared__ float s_m[NW][G], s_l[NW][G];
     __shared__ int s_flag;                                                      // service wave -> page waves: operands ready
@@ -170,7 +164,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     h2 vnew_pair = {0, 0};                 // the new token's raw v (two elements per lane)
 #pragma unroll
     for (int h = 0; h < G; ++h) qlo[h] = qhi[h] = 0;
-    if (!PRE && wave == SVC) {
+    if (wave == SVC) {
         asm volatile("s_setprio 3");       // (asm without a memory clobber: the builtin counts as a possible store and
                                            //  turns every later page-table lookup into a vector load)
         if constexpr (!(EXP & 4)) {
@@ -231,12 +225,6 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(g), "s"(ldst) : "memory");
     };
-    auto dma16_keep = [&](const uint8_t* g, uint8_t* l) {   // default cache policy: rows that all waves of the workgroup fetch
-        u32 keep;
-        const u32 ldst = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)(lptr_t)l);
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(g), "s"(ldst) : "memory");
-    };
     auto dma4 = [&](const void* g, const void* l) {       // per-lane source, 4 B per lane: 256 B per wave instruction
         u32 keep;
         const u32 ldst = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)(lptr_t)l);   // provably wave-uniform for the "s" operand
@@ -288,10 +276,8 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     // (A ninth, page-less wave was tried first: 576-thread workgroups no longer fit twice on a CU - 26 vs 20 us.)
     const int blk = tl >> 6, slot = tl & 63;
     const bool has_page = p_begin + wave < p_end && pages_here;
-    if constexpr (!PRE) {
-        if (tid == SVC * 64) s_flag = 0;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // start-of-kernel barrier (raw: the service wave's loads stay in flight)
-    }
+    if (tid == SVC * 64) s_flag = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // start-of-kernel barrier (raw: the service wave's loads stay in flight)
     auto first_round = [&]() {
         if (has_page) {
             // page addresses: requested together with the length for split 0 (scalar loads, before any asm statement:
@@ -307,39 +293,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         }
         stamp(2);
     };
-    h8 qBr[4];                                                      // PRE: the wave's own copy of the Q.K^T B operand
-#pragma unroll
-    for (int w = 0; w < 4; ++w) qBr[w] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
-    if constexpr (PRE) {
-        // q rows of the group (G x 256 B, contiguous) -> s_q; the last wave: the new token's k (rotated) and v as well.
-        // These are the OLDEST entries of the wave's vector-memory queue: "all but the ten page requests of the first
-        // round have landed" (vmcnt 10) says they are in.
-        {
-            const uint8_t* qsrc = reinterpret_cast<const uint8_t*>(qb);
-            uint8_t* qdst = reinterpret_cast<uint8_t*>(&s_q[0][0]);
-#pragma unroll
-            for (int e = 0; e < (G * 16 + 63) / 64; ++e)
-                if (e * 64 + lane < G * 16) dma16_keep(qsrc + (e * 64 + lane) * 16, qdst + e * 1024);
-            if (wave == SVC) {
-                if (lane < 16) dma16_keep(reinterpret_cast<const uint8_t*>(kb) + lane * 16, reinterpret_cast<uint8_t*>(&s_knew[0]));
-                if (lane < 16) dma16_keep(reinterpret_cast<const uint8_t*>(vb) + lane * 16, reinterpret_cast<uint8_t*>(&s_vnew[0]));
-            }
-        }
-        first_round();
-        if (has_page) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // the Q.K^T B operand of lane (head li, kg = tg), MFMA w: dims 32tg + 8w + {0,4,1,5,2,6,3,7}, hi-nibble positions
-        // carry q/16 - kept in REGISTERS for the whole page loop (eight waves writing an LDS image of it at once, 16-way
-        // bank-conflicted, measured slower than the service wave they replace)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            h8 x = {0, 0, 0, 0, 0, 0, 0, 0};                       // heads >= G: zero rows of the operand
-            if (li < G) x = *reinterpret_cast<const h8*>(&s_q[li][32 * tg + 8 * w]);
-            const _Float16 s16 = (_Float16)0.0625f;
-            qBr[w] = (h8){x[0], x[4], x[1] * s16, x[5] * s16, x[2], x[6], x[3] * s16, x[7] * s16};
-        }
-        stamp(4);
-    } else if (wave != SVC) {
+    if (wave != SVC) {
         first_round();
         while (*(volatile __attribute__((address_space(3))) int*)(&s_flag) == 0) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
@@ -403,17 +357,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         float se = 0.f, so = 0.f;   // sums over lo-form / hi-form operand positions of this lane's 32 dims
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            h8 x;
-            if constexpr (PRE) {     // (lanes li >= G: the operand of head li % GP, as in the LDS form; zero rows for heads >= G)
-                x = (h8){0, 0, 0, 0, 0, 0, 0, 0};
-                if ((li & (GP - 1)) < G) {
-                    const h8 y = *reinterpret_cast<const h8*>(&s_q[li & (GP - 1)][32 * tg + 8 * w]);
-                    const _Float16 s16 = (_Float16)0.0625f;
-                    x = (h8){y[0], y[4], y[1] * s16, y[5] * s16, y[2], y[6], y[3] * s16, y[7] * s16};
-                }
-            } else {
-                x = *reinterpret_cast<const h8*>(&s_qp[li & (GP - 1)][32 * tg + 8 * w]);
-            }
+            const h8 x = *reinterpret_cast<const h8*>(&s_qp[li & (GP - 1)][32 * tg + 8 * w]);
             se += (float)x[0] + (float)x[1] + (float)x[4] + (float)x[5];
             so += (float)x[2] + (float)x[3] + (float)x[6] + (float)x[7];
         }
@@ -468,10 +412,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         v4f craw[4];   // craw[t][r] = raw dot (offsets already cancelled) of token 16t + 4tg + r with head li
         h8 qB[4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            if constexpr (PRE) qB[w] = qBr[w];
-            else qB[w] = *(const __attribute__((address_space(3))) h8*)(ql + 16 * w);
-        }
+        for (int w = 0; w < 4; ++w) qB[w] = *(const __attribute__((address_space(3))) h8*)(ql + 16 * w);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const v4u raw = *(const __attribute__((address_space(3))) v4u*)(kl + 16 * t * DHB);
@@ -734,9 +675,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
                                   sck + hkv * PAGE_TOK + slot, sck + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
                 uint8_t* pgv = reinterpret_cast<uint8_t*>(vtab[blk]);
                 __half* scv = reinterpret_cast<__half*>(pgv + (size_t)num_kv_heads * PAGE_TOK * DHB);
-                const _Float16 vn0 = PRE ? s_vnew[(2 * lane) & (PRE ? DH - 1 : 7)] : vnew_pair[0];
-                const _Float16 vn1 = PRE ? s_vnew[(2 * lane + 1) & (PRE ? DH - 1 : 7)] : vnew_pair[1];
-                wave_quant_store4(vn0, vn1, pgv + ((size_t)hkv * PAGE_TOK + slot) * DHB,
+                wave_quant_store4(vnew_pair[0], vnew_pair[1], pgv + ((size_t)hkv * PAGE_TOK + slot) * DHB,
                                   scv + hkv * PAGE_TOK + slot, scv + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
             }
 #pragma unroll
@@ -1030,13 +969,9 @@ unsigned* qs_attn_quant_counters(hipStream_t st, int batch) {
 // called from attention.hip's dispatcher for KV4.  force_split: 0 = heuristic, n > 0 = exactly n splits (tests)
 int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
                           const int64_t* kvp, const int* len, _Float16* out, int H, int Hkv, int64_t qs, int64_t kvs,
-                          int mb, int timestep, float base, int max_pos, int force_split, bool prerotated) {
+                          int mb, int timestep, float base, int max_pos, int force_split) {
     if (G < 1 || G > 8) {
         qs_set_error("single_query_attention: num_heads/num_kv_heads = %d not in 1..8", G);
-        return QS_ENOSUP;
-    }
-    if (prerotated && G > 4) {              // (the operand registers of the pre-rotated form do not fit beside two lane groups)
-        qs_set_error("single_query_attention_rotated: group sizes above 4 have no pre-rotated form");
         return QS_ENOSUP;
     }
     int exp_flags = 0;                      // qs_set_attention_variant(200 + EXP): ablation builds of the G = 4 kernel
@@ -1080,16 +1015,9 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
         qsum = reinterpret_cast<__half*>(g_qs_attn_quant.qsum);
         g_qs_attn_quant.done = 1;
     }
-#define QS_LAUNCH_G(GG)                                                                                                  \
-    do {                                                                                                                 \
-        if (prerotated)                                                                                                  \
-            hipLaunchKernelGGL((decode_attention_mfma_kernel<(GG <= 4 ? GG : 4), 0, true>), grid, dim3(NWT * 64), 0, st, q, k,  \
-                               v, kvp, len, out, H, Hkv, qs, kvs, mb, timestep, base, tab, tab_len, nsplit, ws, qout, qscale, \
-                               qsum, qcnt);                                                                              \
-        else                                                                                                             \
-            hipLaunchKernelGGL((decode_attention_mfma_kernel<GG>), grid, dim3(NWT * 64), 0, st, q, k, v, kvp, len, out, H,   \
-                               Hkv, qs, kvs, mb, timestep, base, tab, tab_len, nsplit, ws, qout, qscale, qsum, qcnt);       \
-    } while (0)
+#define QS_LAUNCH_G(GG)                                                                                             \
+    hipLaunchKernelGGL((decode_attention_mfma_kernel<GG>), grid, dim3(NWT * 64), 0, st, q, k, v, kvp, len, out, H, Hkv, \
+                       qs, kvs, mb, timestep, base, tab, tab_len, nsplit, ws, qout, qscale, qsum, qcnt)
 #define QS_LAUNCH_EXP(E)                                                                                              \
     case E:                                                                                                            \
         hipLaunchKernelGGL((decode_attention_mfma_kernel<4, E>), grid, dim3(NWT * 64), 0, st, q, k, v, kvp, len, out, H,  \
@@ -1100,7 +1028,7 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
         ws = qs_split_workspace((size_t)blocks * NWT * 16 * 8, st);
         if (!ws) exp_flags = 0;
     }
-    if (G == 4 && exp_flags > 0 && nsplit == 1 && !prerotated) {
+    if (G == 4 && exp_flags > 0 && nsplit == 1) {
         switch (exp_flags) {
             QS_LAUNCH_EXP(1);
             QS_LAUNCH_EXP(2);

@@ -121,39 +121,6 @@ def single_query_attention_quant(q, k, v, kv_pointers, length_per_sample, quant_
     return out
 
 
-def single_query_attention_rotated(q, k, v, kv_pointers, length_per_sample, memory_max_seqlen, tokens_per_block,
-                                   size_per_token, timestep, rotary_embedding_dim, rotary_base, neox_rotary_style,
-                                   int4_kv_cache, kv_cache_with_zeros, quant_out=None, quant_scale=None, quant_sum=None):
-    """single_query_attention for q / k that already carry RoPE for position length - 1 (gemm_rope_* wrote them); with
-    quant_out / quant_scale (/ quant_sum) also invoke_quant(_fuse_sum) of the output, as single_query_attention_quant.
-    Bit-identical to the un-rotated ops on the un-rotated tensors; KV4 matrix-core kernel only (RuntimeError otherwise)."""
-    for n, t in (("q", q), ("k", k), ("v", v)):
-        expect(t, torch.float16, n, contiguous=False)
-    expect(kv_pointers, torch.int64, "kv_pointers")
-    if quant_out is not None:
-        expect(quant_out, torch.int8, "quant_out")
-        expect(quant_scale, torch.float16, "quant_scale")
-    if quant_sum is not None:
-        expect(quant_sum, torch.float16, "quant_sum")
-    batch = kv_pointers.size(0)
-    nheads, nheads_kv, headdim = q.size(1), k.size(1), k.size(-1)
-    if not (k.stride(2) == 1 and k.stride(1) == headdim and v.stride(2) == 1 and v.stride(1) == headdim):
-        raise RuntimeError("k and v must have stride(2) == 1 and stride(1) == head_dim")
-    if not (q.stride(2) == 1 and q.stride(1) == headdim):
-        raise RuntimeError("q must have stride(2) == 1 and stride(1) == head_dim")
-    if length_per_sample is not None:
-        expect(length_per_sample, torch.int32, "length_per_sample")
-    out = torch.empty((q.size(0), nheads, headdim), dtype=q.dtype, device=q.device)
-    with guard(q):
-        check(lib.qs_single_query_attention_rotated(
-            ptr(q), ptr(k), ptr(v), ptr(kv_pointers), ptr(length_per_sample), ptr(out), ptr(quant_out), ptr(quant_sum),
-            ptr(quant_scale), batch, nheads, nheads_kv, headdim, q.stride(0), k.stride(0), kv_pointers.size(-1),
-            int(memory_max_seqlen), int(tokens_per_block), int(size_per_token), int(timestep), int(rotary_embedding_dim),
-            float(rotary_base), int(bool(neox_rotary_style)), int(bool(int4_kv_cache)), int(bool(kv_cache_with_zeros)),
-            stream()), "fused.single_query_attention_rotated")
-    return out
-
-
 def _gemm_common(per_group, in_feats, kernel, rest):
     expect(in_feats, torch.int8, "in_feats")
     expect(kernel, torch.int8, "kernel")

@@ -64,11 +64,6 @@ for L in LS:
     bytes_ = B * (L - 1) * Hkv * (2 * dhb + 8)
     row = []
     for var in VARS:
-        if var == 9000:      # the pre-rotated entry (q / k taken as they are: timing only)
-            from qserve_amd import fused
-            us = timeit(lambda i: fused.single_query_attention_rotated(q, k, v, tables[i % NL], lens, 8192, 64, Hkv * dhb, L, 128, 5e5, True, int4, True), reps=16)
-            row.append(f"rotated entry: {us:7.2f} us {bytes_ / us / 1e3:7.0f} GB/s")
-            continue
         lib.qs_set_attention_variant(var)
         us = timeit(lambda i: fa.single_query_attention(q, k, v, tables[i % NL], lens, None, 8192, 64, Hkv * dhb, L, 128, 5e5, True, int4, True), reps=16)
         row.append(f"variant {var}: {us:7.2f} us {bytes_ / us / 1e3:7.0f} GB/s")

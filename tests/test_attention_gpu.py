@@ -450,90 +450,3 @@ def test_config2_matches_reference_order_oracle(gpu, L):
 def test_config5_matches_reference_order_oracle(gpu, int4):
     """BASELINE config 5 (bs = 8, L = 8191, KV8) and its KV4 twin, the dispatcher's own split-KV launch + merge."""
     reference_order_case(gpu, f"config5_L8191_{'kv4' if int4 else 'kv8'}", 8, 8191, int4, sample=[5], seed=8191 + int4)
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-# Pre-rotated entry (qs_single_query_attention_rotated): RoPE applied by the producer of q / k (the qkv GEMM's epilogue,
-# tests/test_gemm_rope_gpu.py) instead of the attention kernel.  Here the rotation comes from the prefill writer run
-# without a cache (kv_pointers = None: RoPE in place only), so the attention side is pinned on its own: output, cache
-# bytes and the fused quantiser's results must equal the un-rotated entry points' bit for bit.
-# ---------------------------------------------------------------------------------------------------------------------
-def rotate_new_tokens(gpu, new, lens, H, Hkv, int4):
-    """new fp16 [B, (H+2Hkv)*128] -> copy with q and k rotated for position lens[b] - 1 (prefill writer, no cache)."""
-    import qserve_backend.fused_attention as fa
-    B = new.size(0)
-    maxl = int(lens.max())
-    rot = new.clone()
-    pad = (torch.arange(B, device=gpu, dtype=torch.int32) * maxl + (lens - 1)) - torch.arange(B, device=gpu, dtype=torch.int32)
-    fa.apply_bias_rope_update_kv_cache(rot, lens, pad.to(torch.int32), None, H, Hkv, maxl, 64, Hkv * (64 if int4 else 128),
-                                       128, ROPE, 8192, True, int4, True)
-    return rot
-
-
-@pytest.mark.parametrize("with_quant", [False, True])
-@pytest.mark.parametrize("B,H,Hkv,L,ragged", [(64, 32, 8, 1033, False), (5, 8, 2, 300, True), (3, 8, 8, 130, True),
-                                              (2, 4, 2, 70, True), (4, 4, 1, 260, True), (3, 2, 1, 200, True),
-                                              (3, 3, 1, 129, True), (8, 32, 8, 4000, False), (2, 6, 2, 64, True)])
-def test_prerotated_attention_is_bit_identical(gpu, B, H, Hkv, L, ragged, with_quant):
-    import qserve_backend.fused_attention as fa
-    import qserve_backend.fused_kernels as fk
-    from qserve_amd import fused
-    g = torch.Generator(device=gpu).manual_seed(B + H + L)
-    mb = (L + 63) // 64 + 1
-    nblocks = B * mb
-    nd = Hkv * 64 * 64
-
-    def fresh():
-        pools = DevPools(nblocks, Hkv, True, gpu, fill=0)
-        g2 = torch.Generator(device=gpu).manual_seed(7)
-        for p in (pools.k, pools.v):
-            p[:, :nd] = torch.randint(0, 256, (nblocks, nd), dtype=torch.uint8, device=gpu, generator=g2)
-            p[:, nd:].view(torch.float16).copy_((torch.rand((nblocks, (pools.pb - nd) // 2), device=gpu, generator=g2) * 0.5 + 0.05).half())
-        return pools
-    tables = torch.stack([torch.randperm(nblocks, generator=torch.Generator().manual_seed(1)).reshape(B, mb),
-                          torch.randperm(nblocks, generator=torch.Generator().manual_seed(2)).reshape(B, mb)], dim=1).numpy()
-    new = torch.randn((B, (H + 2 * Hkv) * 128), generator=g, device=gpu, dtype=torch.float16)
-    if ragged:
-        lens = torch.randint(1, L + 1, (B,), generator=torch.Generator().manual_seed(3)).to(torch.int32).to(gpu)
-        lens[0] = L
-        lens[-1] = 1                       # no history at all
-    else:
-        lens = torch.full((B,), L, dtype=torch.int32, device=gpu)
-    args = (8192, 64, Hkv * 64, L, 128, ROPE, True, True, True)
-    q, k, v = new.split([H * 128, Hkv * 128, Hkv * 128], dim=-1)
-    p1 = fresh()
-    out1 = fa.single_query_attention(q.reshape(B, H, 128), k.reshape(B, Hkv, 128), v.reshape(B, Hkv, 128), p1.pointers(tables),
-                                     lens, None, *args)
-    q1 = torch.full((B, H * 128), 77, dtype=torch.int8, device=gpu)
-    s1 = torch.full((B,), 7.0, dtype=torch.float16, device=gpu)
-    m1 = torch.full((B,), 7.0, dtype=torch.float16, device=gpu)
-    if with_quant:
-        fk.invoke_quant_fuse_sum(q1, out1.reshape(B, -1), m1, s1)
-    rot = rotate_new_tokens(gpu, new, lens, H, Hkv, True)
-    qr, kr, vr = rot.split([H * 128, Hkv * 128, Hkv * 128], dim=-1)
-    assert torch.equal(vr, v)
-    for rep in range(2):
-        p2 = fresh()
-        q2 = torch.full((B, H * 128), 77, dtype=torch.int8, device=gpu)
-        s2 = torch.full((B,), 7.0, dtype=torch.float16, device=gpu)
-        m2 = torch.full((B,), 7.0, dtype=torch.float16, device=gpu)
-        out2 = fused.single_query_attention_rotated(
-            qr.reshape(B, H, 128), kr.reshape(B, Hkv, 128), vr.reshape(B, Hkv, 128), p2.pointers(tables), lens, *args,
-            quant_out=q2 if with_quant else None, quant_scale=s2 if with_quant else None, quant_sum=m2 if with_quant else None)
-        torch.cuda.synchronize()
-        assert torch.equal(out2.view(torch.int16), out1.view(torch.int16)), "attention output differs"
-        assert torch.equal(p2.k, p1.k) and torch.equal(p2.v, p1.v), "cache pages differ"
-        assert torch.equal(q2, q1) and torch.equal(s2.view(torch.int16), s1.view(torch.int16)), "quantiser output differs"
-        assert torch.equal(m2.view(torch.int16), m1.view(torch.int16)), "row sum differs"
-
-
-def test_prerotated_attention_rejects_what_it_cannot_do(gpu):
-    from qserve_amd import fused
-    B, H, Hkv = 2, 8, 2
-    new = torch.zeros((B, (H + 2 * Hkv) * 128), dtype=torch.float16, device=gpu)
-    q, k, v = new.split([H * 128, Hkv * 128, Hkv * 128], dim=-1)
-    ptrs = torch.zeros((B, 2, 4), dtype=torch.int64, device=gpu)
-    lens = torch.ones((B,), dtype=torch.int32, device=gpu)
-    with pytest.raises(RuntimeError):      # KV8: no pre-rotated form
-        fused.single_query_attention_rotated(q.reshape(B, H, 128), k.reshape(B, Hkv, 128), v.reshape(B, Hkv, 128), ptrs, lens,
-                                             8192, 64, Hkv * 128, 1, 128, ROPE, True, False, True)
