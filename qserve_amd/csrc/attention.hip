@@ -623,13 +623,14 @@ const float2* qs_rope_table(float base, int max_pos, hipStream_t st, int* len_ou
 // KV4 fast path on the matrix cores (attention_mfma.hip)
 int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
                           const int64_t* kvp, const int* len, _Float16* out, int H, int Hkv, int64_t qs, int64_t kvs,
-                          int mb, int timestep, float base, int max_pos, int force_split);
+                          int mb, int timestep, float base, int max_pos, int force_split, int kflags);
 // KV8 twin (attention_mfma8.hip)
 int qs_launch_decode_mfma8(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
                            const int64_t* kvp, const int* len, _Float16* out, int H, int Hkv, int64_t qs, int64_t kvs,
                            int mb, int timestep, float base, int max_pos, int force_split);
 // 0 = MFMA kernel for KV4 with the split-KV heuristic (default), 1 = VALU kernel everywhere, 2 = prefill writer in its
-// per-lane form (no RoPE table), 100 + n = MFMA kernel with exactly n KV splits (A/B tests)
+// per-lane form (no RoPE table), 3 = KV4 MFMA kernel whose service wave always owns pages (the round-2 form: A/B),
+// 100 + n = MFMA kernel with exactly n KV splits (A/B tests)
 static int g_attn_variant = 0;
 extern "C" void qs_set_attention_variant(int variant) { g_attn_variant = variant; }
 
@@ -663,7 +664,7 @@ extern "C" int qs_single_query_attention(const void* q, const void* k, const voi
         return qs_launch_decode_mfma(G, grid, st, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
                                      kv_pointers, length_per_sample, (_Float16*)out, num_heads, num_kv_heads,
                                      q_stride0, kv_stride0, max_blocks, timestep, rotary_base, memory_max_seqlen,
-                                     g_attn_variant >= 100 ? g_attn_variant - 100 : 0);
+                                     g_attn_variant >= 100 ? g_attn_variant - 100 : 0, g_attn_variant == 3 ? 1 : 0);
     if (!int4_kv_cache && g_attn_variant != 1 && max_blocks <= 192)
         return qs_launch_decode_mfma8(G, grid, st, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
                                       kv_pointers, length_per_sample, (_Float16*)out, num_heads, num_kv_heads,

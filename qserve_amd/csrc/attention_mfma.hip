@@ -116,7 +116,8 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     const int64_t* __restrict__ kv_pointers, const int* __restrict__ lengths, _Float16* __restrict__ out,
     int num_heads, int num_kv_heads, int64_t q_stride0, int64_t kv_stride0, int max_blocks, int timestep,
     float rope_base, const float2* __restrict__ rope_tab, int rope_tab_len, int nsplit, float* __restrict__ ws,
-    int8_t* __restrict__ qout, __half* __restrict__ qscale, __half* __restrict__ qrowsum, unsigned* __restrict__ qcounters) {
+    int8_t* __restrict__ qout, __half* __restrict__ qscale, __half* __restrict__ qrowsum, unsigned* __restrict__ qcounters,
+    int kflags) {
     __shared__ __attribute__((aligned(16))) uint8_t s_kv[2 * NW * PAGE_TOK * DHB];   // [K | V][wave][4 KiB]
     __shared__ __attribute__((aligned(16))) _Float16 s_meta[NW][4][PAGE_TOK];   // k scale, k zero, v scale, v zero
     __shared__ __attribute__((aligned(16))) _Float16 s_q[G][DH];                // rotated q of the G heads
@@ -142,10 +143,8 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     const int64_t* vtab = ktab + max_blocks;
     // first-round page addresses are requested together with the length (they do not depend on it when this workgroup
     // starts at page 0): one memory round trip less on the launch -> first bytes chain
-    // (timing builds: EXP & 256 = the service wave owns no pages, the other seven take them round-robin)
-    constexpr int PS = (EXP & 256) ? NW - 1 : NW;                     // page stride of a wave
-    const bool pages_here = PS == NW || wave != SVC;
-    const bool spec = (nsplit == 1 || blockIdx.z == 0) && wave < max_blocks && pages_here;
+    // (the service wave's speculative addresses are simply not used when it turns out to own no pages, see svc_free)
+    const bool spec = (nsplit == 1 || blockIdx.z == 0) && wave < max_blocks;
     int64_t kpage0 = 0, vpage0 = 0;
     if (spec) {
         kpage0 = ktab[wave];
@@ -275,9 +274,24 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     // and its own score follow on the service wave after its pages, off everybody's critical path.
     // (A ninth, page-less wave was tried first: 576-thread workgroups no longer fit twice on a CU - 26 vs 20 us.)
     const int blk = tl >> 6, slot = tl & 63;
+    // Page ownership.  The service wave starts its pages ~2 us after the others (operand build first) and then still has
+    // the new token's cache write and score to do: with its round-robin share of the pages it is the last wave to finish
+    // (timeline trace; EXP 256 / 64 ablations: 19.7 -> 17.9 us at 17 pages).  Whenever seven waves need no more rounds than
+    // eight would - ceil(n / 7) == ceil(n / 8): 1-7, 9-14, 17-21, 25-28, ... pages - it therefore owns NO pages, finishes the
+    // new token right after the operand build and waits at the merge; the other seven take the pages round-robin.
+    // (EXP & 256, timing builds: always.)
+    const int npg = p_end - p_begin;
+    // (kflags & 1, qs_set_attention_variant(3): never - the A/B reference)
+    const bool svc_free = (EXP & 256) ? true : (!(kflags & 1) && (npg + NW - 2) / (NW - 1) == (npg + NW - 1) / NW);
+    const int PS = svc_free ? NW - 1 : NW;                            // page stride of a wave
+    const bool pages_here = !svc_free || wave != SVC;
     const bool has_page = p_begin + wave < p_end && pages_here;
     if (tid == SVC * 64) s_flag = 0;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // start-of-kernel barrier (raw: the service wave's loads stay in flight)
+    // (tried in round 3 and dropped: requesting the K pages of ALL waves before any V page - a raw barrier between the two
+    // halves of the first round - so that the first Q.K^T does not queue behind other waves' V pages: +0.5-1.2 us at
+    // 640-1030 tokens, where the barrier itself is the delay, -0.7-1.3 us from 1535 tokens on; not a net gain over the
+    // benchmark's contexts)
     auto first_round = [&]() {
         if (has_page) {
             // page addresses: requested together with the length for split 0 (scalar loads, before any asm statement:
@@ -292,6 +306,26 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
             dma_v(vfirst, vt0);
         }
         stamp(2);
+    };
+    // the new token's cache write (split 0) and its own score: service wave, after its pages - or, when it owns none,
+    // straight after the operand build
+    auto new_token_work = [&]() {
+        if (z == 0) {
+            uint8_t* pgk = reinterpret_cast<uint8_t*>(ktab[blk]);
+            __half* sck = reinterpret_cast<__half*>(pgk + (size_t)num_kv_heads * PAGE_TOK * DHB);
+            wave_quant_store4(s_knew[2 * lane], s_knew[2 * lane + 1], pgk + ((size_t)hkv * PAGE_TOK + slot) * DHB,
+                              sck + hkv * PAGE_TOK + slot, sck + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
+            uint8_t* pgv = reinterpret_cast<uint8_t*>(vtab[blk]);
+            __half* scv = reinterpret_cast<__half*>(pgv + (size_t)num_kv_heads * PAGE_TOK * DHB);
+            wave_quant_store4(vnew_pair[0], vnew_pair[1], pgv + ((size_t)hkv * PAGE_TOK + slot) * DHB,
+                              scv + hkv * PAGE_TOK + slot, scv + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
+        }
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+            float d = (float)s_q[h][lane] * (float)s_knew[lane] + (float)s_q[h][64 + lane] * (float)s_knew[64 + lane];
+            d = wave_sum_dpp(d);
+            if (lane == 0) s_cur[h] = d * qk_scale;
+        }
     };
     if (wave != SVC) {
         first_round();
@@ -343,6 +377,9 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
             if (lane == 0) *(volatile __attribute__((address_space(3))) int*)(&s_flag) = 1;
             asm volatile("s_setprio 0");
             stamp(4);
+            if constexpr (!(EXP & 64)) {
+                if (svc_free) new_token_work();
+            }
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) *(volatile __attribute__((address_space(3))) int*)(&s_flag) = 1;
@@ -667,24 +704,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     // (placed here, after the code the page waves share with it: pending stores of the service wave at a control-flow
     // merge in front of the page loop would make the compiler put a vmcnt(0) there - which drains the page waves' DMA)
     if constexpr (!(EXP & 4) && !(EXP & 64)) {   // (EXP & 64: timing, the new token's cache write and own score skipped)
-        if (wave == SVC) {
-            if (z == 0) {
-                uint8_t* pgk = reinterpret_cast<uint8_t*>(ktab[blk]);
-                __half* sck = reinterpret_cast<__half*>(pgk + (size_t)num_kv_heads * PAGE_TOK * DHB);
-                wave_quant_store4(s_knew[2 * lane], s_knew[2 * lane + 1], pgk + ((size_t)hkv * PAGE_TOK + slot) * DHB,
-                                  sck + hkv * PAGE_TOK + slot, sck + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
-                uint8_t* pgv = reinterpret_cast<uint8_t*>(vtab[blk]);
-                __half* scv = reinterpret_cast<__half*>(pgv + (size_t)num_kv_heads * PAGE_TOK * DHB);
-                wave_quant_store4(vnew_pair[0], vnew_pair[1], pgv + ((size_t)hkv * PAGE_TOK + slot) * DHB,
-                                  scv + hkv * PAGE_TOK + slot, scv + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
-            }
-#pragma unroll
-            for (int h = 0; h < G; ++h) {
-                float d = (float)s_q[h][lane] * (float)s_knew[lane] + (float)s_q[h][64 + lane] * (float)s_knew[64 + lane];
-                d = wave_sum_dpp(d);
-                if (lane == 0) s_cur[h] = d * qk_scale;
-            }
-        }
+        if (wave == SVC && !svc_free) new_token_work();
     }
     // every LDS-DMA of this wave has landed (a wave without pages never waited for its first-round fetch, and the merge
     // area below aliases the page buffers)
@@ -969,7 +989,7 @@ unsigned* qs_attn_quant_counters(hipStream_t st, int batch) {
 // called from attention.hip's dispatcher for KV4.  force_split: 0 = heuristic, n > 0 = exactly n splits (tests)
 int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, const _Float16* k, const _Float16* v,
                           const int64_t* kvp, const int* len, _Float16* out, int H, int Hkv, int64_t qs, int64_t kvs,
-                          int mb, int timestep, float base, int max_pos, int force_split) {
+                          int mb, int timestep, float base, int max_pos, int force_split, int kflags) {
     if (G < 1 || G > 8) {
         qs_set_error("single_query_attention: num_heads/num_kv_heads = %d not in 1..8", G);
         return QS_ENOSUP;
@@ -1017,11 +1037,11 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
     }
 #define QS_LAUNCH_G(GG)                                                                                             \
     hipLaunchKernelGGL((decode_attention_mfma_kernel<GG>), grid, dim3(NWT * 64), 0, st, q, k, v, kvp, len, out, H, Hkv, \
-                       qs, kvs, mb, timestep, base, tab, tab_len, nsplit, ws, qout, qscale, qsum, qcnt)
+                       qs, kvs, mb, timestep, base, tab, tab_len, nsplit, ws, qout, qscale, qsum, qcnt, kflags)
 #define QS_LAUNCH_EXP(E)                                                                                              \
     case E:                                                                                                            \
         hipLaunchKernelGGL((decode_attention_mfma_kernel<4, E>), grid, dim3(NWT * 64), 0, st, q, k, v, kvp, len, out, H,  \
-                           Hkv, qs, kvs, mb, timestep, base, tab, tab_len, nsplit, ws, qout, qscale, qsum, qcnt);      \
+                           Hkv, qs, kvs, mb, timestep, base, tab, tab_len, nsplit, ws, qout, qscale, qsum, qcnt, kflags); \
         return qs_launch_status("single_query_attention")
 #ifdef QS_TIMING   // ablation / trace instantiations (some are wrong by design): not in the shipped library
     if (exp_flags & 32) {                     // timeline trace: stamps go to the (otherwise unused) split workspace
