@@ -97,11 +97,20 @@ def parse():
     return a
 
 
+SELF_CHECK_ITERS = 2000
+
+
 def direct_allreduce_or_none(numel, rank, world, dev, mode):
-    """The library's direct-access all-reduce, checked on this machine before it is trusted: every rank's result must be
-    bit-identical to the fp32 rank-order sum of the gathered inputs, no wait may time out and (mode "auto") it must not be
-    slower than the process group's all-reduce.  All ranks take the same decision.  -> (communicator | None, note)."""
-    import numpy as np
+    """The library's direct-access all-reduce, checked on THIS machine before it is trusted (its protocol assumes that an
+    acknowledged store to uncached peer memory is visible at the peer - unverified on xGMI until a run like this one says
+    so).  All of the following must hold on every rank, or the step runs on torch.distributed:
+      * SELF_CHECK_ITERS eager all-reduces with fresh random payloads of varying size, each verified ON THE DEVICE against
+        the fp32 rank-order sum of the inputs gathered through the process group (bit for bit; one host sync at the end);
+      * a hipGraph of 8 back-to-back all-reduces (each input derived from the previous output), replayed 64 times with
+        changing data, against the same chain through the process group - bit for bit;
+      * no bounded wait timed out;
+      * mode "auto": not slower than the process group's all-reduce.
+    All ranks take the same decision.  -> (communicator | None, note)."""
     import torch
     import torch.distributed as dist
     from qserve_amd import tp as TP
@@ -117,22 +126,60 @@ def direct_allreduce_or_none(numel, rank, world, dev, mode):
         return None, f"torch.distributed ({str(e)[:200]})"
     why = None
     try:
-        for it in range(6):
-            x = (np.random.default_rng(977 * it + rank).standard_normal(numel) * 2).astype(np.float16)
-            parts = [None] * world
-            dist.all_gather_object(parts, x)
-            acc = np.zeros(numel, np.float32)
-            for p in parts:
-                acc = acc + p.astype(np.float32)
-            comm.input((numel,)).copy_(torch.from_numpy(x))
-            torch.cuda.synchronize()
-            dist.barrier()
-            comm.all_reduce(numel)
-            timed_out = comm.error()                             # synchronises
-            good = (not timed_out) and np.array_equal(comm.output((numel,)).cpu().numpy(), acc.astype(np.float16))
-            if not agree(good):
-                why = "self-check failed: " + ("a wait timed out" if timed_out else "result differs from the rank-order fp32 sum")
+        unit = 8 * world
+        g = torch.Generator(device=dev).manual_seed(977 + rank)
+        bad = torch.zeros((), dtype=torch.int64, device=dev)
+        gathered = [torch.empty((numel,), dtype=torch.float16, device=dev) for _ in range(world)]
+
+        def rank_order_sum(parts, n):
+            acc = torch.zeros((n,), dtype=torch.float32, device=dev)
+            for p_ in parts:
+                acc = acc + p_[:n].float()
+            return acc.half()
+        import random
+        sizes = random.Random(4242)                              # the same size sequence on every rank
+        for it in range(SELF_CHECK_ITERS):
+            n = numel if it % 3 == 0 else sizes.randrange(1, numel // unit + 1) * unit
+            x = (torch.randn((numel,), device=dev, generator=g) * 2).half()
+            comm.input((numel,)).copy_(x)
+            dist.all_gather(gathered, x)
+            comm.all_reduce(n)
+            bad += (comm.output((numel,))[:n].view(torch.int16) != rank_order_sum(gathered, n).view(torch.int16)).sum()
+            if it % 400 == 399 and not agree(int(bad.item()) == 0 and not comm.error()):
+                why = f"self-check failed within {it + 1} eager all-reduces (bit mismatch or a timed-out wait)"
                 break
+        if why is None:                                          # graph replays: 8 dependent all-reduces per replay
+            chain = 8
+            seed = torch.empty((numel,), dtype=torch.float16, device=dev)
+
+            def run_chain(reduce_fn, src_buf, dst_of):
+                cur = seed
+                for _ in range(chain):
+                    src_buf.copy_(cur * 0.5 + 0.25)
+                    cur = reduce_fn()
+                return dst_of(cur)
+            ref = torch.empty((numel,), dtype=torch.float16, device=dev)
+            tmp = torch.empty((numel,), dtype=torch.float16, device=dev)
+
+            def ref_reduce():
+                dist.all_gather(gathered, tmp)
+                ref.copy_(rank_order_sum(gathered, numel))
+                return ref
+
+            def direct_reduce():
+                comm.all_reduce(numel)
+                return comm.output((numel,))
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                run_chain(direct_reduce, comm.input((numel,)), lambda c: c)
+            for rep in range(64):
+                seed.copy_((torch.randn((numel,), device=dev, generator=g)).half())
+                want = run_chain(ref_reduce, tmp, lambda c: c.clone())
+                graph.replay()
+                bad += (comm.output((numel,)).view(torch.int16) != want.view(torch.int16)).sum()
+            if not agree(int(bad.item()) == 0 and not comm.error()):
+                why = "self-check failed in the hipGraph replays (bit mismatch or a timed-out wait)"
         if why is None and mode == "auto":
             buf = torch.zeros((numel,), dtype=torch.float16, device=dev)
             times = []
@@ -151,12 +198,16 @@ def direct_allreduce_or_none(numel, rank, world, dev, mode):
             if not agree(times[1] <= times[0] and not comm.error()):
                 why = f"slower than the process group's all-reduce here ({times[1] * 1e3:.1f} vs {times[0] * 1e3:.1f} us on rank {rank})"
     except Exception as e:
-        why = f"self-check raised {str(e)[:200]}"
-        agree(False)
+        why = f"self-check raised {type(e).__name__}: {str(e)[:200]}"
+        try:
+            agree(False)
+        except Exception:
+            pass
     if why is not None:
         comm.close()
         return None, f"torch.distributed ({why})"
-    return comm, "library direct-access all-reduce (qs_comm_all_reduce_f16), start-up self-check passed"
+    return comm, (f"library direct-access all-reduce (qs_comm_all_reduce_f16); start-up self-check passed: {SELF_CHECK_ITERS} eager "
+                  f"all-reduces of varying size + 64 replays of an 8-deep hipGraph chain, bit-exact against the rank-order fp32 sum")
 
 
 def self_launch(args):
@@ -458,6 +509,7 @@ def main():
         dt = float(t.item())
     ms = dt / args.steps * 1e3
     extra = {}
+    eng.check()                         # bounded in-launch waits (direct all-reduce, row-op tails): raise if one gave up
     if eng.fuse_tails:
         from qserve_amd import fused as _fz
         tl0 = _lib.lib.qs_debug_tail_launches()
@@ -511,6 +563,30 @@ def main():
                 eng.fuse_pairs = True
                 eng.fuse_tails = tails_saved
                 eng.graph, eng.pieces = g_saved, p_saved
+
+    # ---- one rank's COMPUTE-ONLY share of the tensor-parallel step (N = 1 line only): what a real N-GPU run should take per
+    # step before communication - the prediction the driver's scaling run can be checked against --------------------------
+    if world == 1 and not args.no_extras and args.model == "llama3-8b" and not args.op_by_op:
+        share = {}
+        for tpw in (2, 4, 8):
+            try:
+                e2 = D.DecodeEngine(cfg, per_gpu_batch * tpw, args.prompt_len, args.max_new, group_size=args.group_size,
+                                    int4_kv=not args.kv8, device=dev, tp_rank=0, tp_world=tpw)
+                e2.prefill_cache(args.prompt_len + 16)
+                e2.lengths.fill_(start_len)
+                e2.capture(piecewise=False)          # no process group: the all-reduces are no-ops, one graph
+                e2.lengths.fill_(start_len)
+                for _ in range(3):
+                    e2.run()
+                share[f"tp{tpw}"] = round(time_steps(e2, 16, torch), 3)
+                del e2
+                torch.cuda.empty_cache()
+            except RuntimeError as e:
+                print(f"[bench] tp{tpw} rank share skipped: {str(e)[:200]}", file=sys.stderr)
+        extra["tp_rank_share_ms"] = share
+        extra["tp_rank_share_note"] = ("ms per step of ONE rank's shard at tp2 / tp4 / tp8 (weak scaling: 64 sequences per GPU) "
+                                       "with the collectives as no-ops, measured on this GPU: an N-GPU run adds 2 all-reduces "
+                                       "per layer + the greedy head's exchange on top; N > 1 itself is UNMEASURED here")
 
     # ---- the reference's end-to-end protocol, measured: prompt phase + (max_new - 1) decode steps ---------------------
     # (qserve_benchmark.py:48-67,108: the prompt step yields the first of `max_new` tokens; tokens / total wall time)

@@ -40,6 +40,9 @@ def residual_add_(a, b):
 def argmax_rows_(logits, out):
     """out[r] = argmax(logits[r]) (fp16 [rows, n] -> int64 [rows]); the greedy sampler of the benchmark step."""
     assert logits.dtype == torch.float16 and logits.dim() == 2 and logits.stride(1) == 1 and out.dtype == torch.int64
+    if logits.size(1) < 8 or logits.stride(0) % 8 != 0:      # shapes the kernel's 16-byte rows cannot take (e.g. V = 32001)
+        torch.argmax(logits, dim=1, out=out)
+        return
     _check(_lib.qs_argmax_rows(logits.data_ptr(), out.data_ptr(), logits.size(0), logits.size(1), logits.stride(0), stream()),
            "argmax_rows")
 
@@ -155,7 +158,10 @@ class DecodeEngine:
         self.tp_rank, self.tp_world = tp_rank, tp_world
         self.group_size, self.int4 = group_size, int4_kv
         H, Hkv = cfg["heads"], cfg["kv_heads"]
-        assert H % tp_world == 0 and Hkv % tp_world == 0 and cfg["inter"] % (tp_world * 128) == 0
+        # (more ranks than KV heads would need the loader's replicated-KV shards AND an engine that de-duplicates the
+        # replicated cache writes: the loader supports it, this engine does not - reject instead of mis-sizing the pools)
+        assert H % tp_world == 0 and Hkv % tp_world == 0 and cfg["inter"] % (tp_world * 128) == 0, \
+            f"tp_world={tp_world} must divide heads={H}, kv_heads={Hkv} and inter/128={cfg['inter'] // 128}"
         self.H, self.Hkv = H // tp_world, Hkv // tp_world
         hid, inter = cfg["hidden"], cfg["inter"] // tp_world
         self.hid, self.inter = hid, inter
@@ -239,7 +245,7 @@ class DecodeEngine:
         # every rank stream the whole 1 GB matrix for the global batch: 0.52 ms of a 3.8 ms step at N = 8.
         V = cfg["vocab"]
         self.vocab_parallel = bool(with_lm_head and tp_world > 1 and vocab_parallel and V % tp_world == 0 and
-                                   V // tp_world >= 8 and V < (1 << 22) and 8 * tp_world <= hid)
+                                   V // tp_world >= 8 and (V // tp_world) % 8 == 0 and V < (1 << 22) and 8 * tp_world <= hid)
         if self.vocab_parallel:
             self.v0 = tp_rank * (V // tp_world)
             self.lm_head = self.lm_head[self.v0:self.v0 + V // tp_world].contiguous()
@@ -536,6 +542,16 @@ class DecodeEngine:
         self.pieces = pieces
         self.graph = None
         return pieces
+
+    def check(self):
+        """Raise if a bounded in-launch wait gave up since the last call (the library's direct all-reduce waiting for a
+        peer, a GEMM row-op tail waiting for a workgroup): the tensors of that step are undefined.  Synchronises the
+        device - call it once per batch of steps, not per step."""
+        if self.ar is not None and self.ar.error():
+            raise RuntimeError("direct all-reduce: a wait for a peer rank timed out (ranks more than a few seconds apart, or "
+                               "a peer died); the communicators' epochs no longer match - re-create them")
+        if self.fuse_tails and fusedmod.fused_tail_gave_up():
+            raise RuntimeError("GEMM row-op tail: a wait for a workgroup of the same launch gave up")
 
     def run(self):
         if getattr(self, "pieces", None):
