@@ -465,26 +465,26 @@ def main():
     start_len = args.prompt_len + 1
     eng.lengths.fill_(start_len)
     graphed = False
+    full_graph = args.tp_full_graph
+    if full_graph and world > 1 and direct is None and backend != "nccl":
+        # a host-staged backend (gloo) synchronises inside the collective: capturing it can only fail, and a failed capture
+        # leaves this HIP context unusable (measured: every later call returns hipErrorStreamCaptureInvalidated) - refuse
+        if rank == 0:
+            print(f"[bench] --tp-full-graph ignored: the '{backend}' backend cannot be captured; piecewise graphs instead",
+                  file=sys.stderr)
+        full_graph = False
     if not args.no_graph:
         try:
-            eng.capture(piecewise=False if args.tp_full_graph else None)
+            eng.capture(piecewise=False if full_graph else None)
             graphed = True
-        except Exception as e:   # e.g. a collective refusing capture: fall back to eager launches
-            if rank == 0:
-                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {str(e).splitlines()[0]}); running eagerly",
-                      file=sys.stderr)
-            eng.graph = None
-            eng.pieces = None
-            # the invalidated capture leaves a stale HIP error behind that the next checked call would re-raise:
-            # drain it (measured with the gloo functional run, tests/test_bench_tp_gpu.py) before touching the engine
-            for _ in range(4):
-                try:
-                    torch.cuda.synchronize()
-                    eng.lengths.fill_(start_len)
-                    torch.cuda.synchronize()
-                    break
-                except Exception:
-                    continue
+        except Exception as e:
+            # A collective that refuses capture (an RCCL build without graph support) invalidates the capture, and HIP keeps
+            # returning hipErrorStreamCaptureInvalidated to this process afterwards: there is nothing to fall back to IN this
+            # process.  Say so and stop - every rank takes this path together (the capture is collective).
+            print(f"[bench] rank {rank}: hipGraph capture of the step failed ({type(e).__name__}: {str(e).splitlines()[0]}).  "
+                  f"{'Re-run without --tp-full-graph (piecewise graphs need no capturable collective).' if full_graph else 'Re-run with --no-graph.'}",
+                  file=sys.stderr)
+            os._exit(3)
     eng.lengths.fill_(start_len)
     assert args.warmup + args.steps + 1 <= args.max_new, "steps exceed the page budget (prompt_len + max_new)"
 
@@ -726,7 +726,7 @@ def main():
                        "global_batch": args.batch, "context_start": start_len + args.warmup,
                        "parallelism": f"tp{world}",
                        "hipgraph": ("piecewise (collectives issued eagerly between the pieces)"
-                                    if graphed and world > 1 and not args.tp_full_graph and direct is None else graphed),
+                                    if graphed and world > 1 and not full_graph and direct is None else graphed),
                        "layers": cfg["layers"],
                        "op_sequence": "reference ops one by one" if args.op_by_op else
                        ("reference ops; 5 launches per layer: qkv GEMM | attention + quant | o_proj GEMM + residual add + norm "

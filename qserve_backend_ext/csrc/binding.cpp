@@ -17,13 +17,16 @@
 // they exist as names and raise.
 #include <torch/extension.h>
 #include <ATen/hip/HIPContext.h>
-#include <c10/hip/HIPGuard.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include "qserve_amd.h"
 
 namespace {
 
-void* cur_stream() { return reinterpret_cast<void*>(c10::hip::getCurrentHIPStream().stream()); }
+// (PyTorch-ROCm presents HIP devices under the device type "cuda": the stream and guard types are the "masquerading" ones)
+void* cur_stream() { return reinterpret_cast<void*>(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()); }
+using DeviceGuard = c10::hip::OptionalHIPGuardMasqueradingAsCUDA;
 
 #define QS_CALL(expr)                                  \
     do {                                               \
@@ -43,7 +46,7 @@ void gemm_per_chn(torch::Tensor in_feats, torch::Tensor kernel, torch::Tensor ws
     need(in_feats, at::kChar, "in_feats"); need(kernel, at::kChar, "kernel"); need(out_feats, at::kHalf, "out_feats");
     need(wscales, at::kHalf, "wscales"); need(ascales, at::kHalf, "ascales"); need(w_szs, at::kHalf, "w_szs");
     need(a_ssums, at::kHalf, "a_ssums");
-    const c10::hip::OptionalHIPGuard guard(in_feats.device());
+    const DeviceGuard guard(in_feats.device());
     // shapes as the reference takes them (gemm_cuda.cu:604-613)
     QS_CALL(qs_w4a8_per_chn_gemm(in_feats.data_ptr<int8_t>(), kernel.data_ptr<int8_t>(), wscales.data_ptr(), ascales.data_ptr(),
                                  w_szs.data_ptr(), a_ssums.data_ptr(), out_feats.data_ptr(), (int)out_feats.size(-2),
@@ -54,7 +57,7 @@ void gemm_per_group(torch::Tensor in_feats, torch::Tensor kernel, torch::Tensor 
     need(in_feats, at::kChar, "in_feats"); need(kernel, at::kChar, "kernel"); need(zeros, at::kChar, "zeros");
     need(scales_i8, at::kChar, "scales_i8"); need(wscales, at::kHalf, "wscales"); need(ascales, at::kHalf, "ascales");
     need(out_feats, at::kHalf, "out_feats");
-    const c10::hip::OptionalHIPGuard guard(in_feats.device());
+    const DeviceGuard guard(in_feats.device());
     QS_CALL(qs_w4a8_per_group_gemm(in_feats.data_ptr<int8_t>(), kernel.data_ptr<int8_t>(), zeros.data_ptr<int8_t>(),
                                    scales_i8.data_ptr<int8_t>(), wscales.data_ptr(), ascales.data_ptr(), out_feats.data_ptr(),
                                    (int)out_feats.size(-2), (int)out_feats.size(-1), (int)in_feats.size(1), cur_stream()));
@@ -63,7 +66,7 @@ void gemm_w8a8(torch::Tensor in_feats, torch::Tensor kernel, torch::Tensor wscal
                torch::Tensor out_feats) {
     need(in_feats, at::kChar, "in_feats"); need(kernel, at::kChar, "kernel"); need(wscales, at::kHalf, "wscales");
     need(ascales, at::kHalf, "ascales"); need(out_feats, at::kHalf, "out_feats");
-    const c10::hip::OptionalHIPGuard guard(in_feats.device());
+    const DeviceGuard guard(in_feats.device());
     QS_CALL(qs_w8a8_gemm(in_feats.data_ptr<int8_t>(), kernel.data_ptr<int8_t>(), wscales.data_ptr(), ascales.data_ptr(),
                          out_feats.data_ptr(), (int)out_feats.size(-2), (int)out_feats.size(-1), (int)in_feats.size(1),
                          cur_stream()));
@@ -91,7 +94,7 @@ torch::Tensor single_query_attention(const torch::Tensor q, const torch::Tensor 
         lens = l.data_ptr<int32_t>();
     }
     TORCH_CHECK(!alibi_slopes_.has_value(), "alibi_slopes is not supported (the W4A8KV4 models never pass it)");
-    const c10::hip::OptionalHIPGuard guard(q.device());       // fused_attention.cpp:203
+    const DeviceGuard guard(q.device());       // fused_attention.cpp:203
     torch::Tensor out = torch::empty({q.size(0), nheads, headdim}, q.options());
     QS_CALL(qs_single_query_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), kv_pointers.data_ptr<int64_t>(), lens,
                                       out.data_ptr(), (int)batch, (int)nheads, (int)nheads_kv, (int)headdim, q.stride(0),
@@ -114,7 +117,7 @@ void apply_bias_rope_update_kv_cache(torch::Tensor qkv, const torch::Tensor seq_
         kvp = kv_pointers_.value().data_ptr<int64_t>();
         mb = (int)kv_pointers_.value().size(-1);
     }
-    const c10::hip::OptionalHIPGuard guard(qkv.device());
+    const DeviceGuard guard(qkv.device());
     QS_CALL(qs_apply_bias_rope_update_kv_cache(qkv.data_ptr(), seq_lens.data_ptr<int32_t>(), padding_offset.data_ptr<int32_t>(),
                                                kvp, (int)qkv.size(0), (int)seq_lens.size(0), mb, head_num, kv_head_num, seq_len,
                                                tokens_per_block, size_per_token, rotary_embedding_dim, rotary_embedding_base,
@@ -123,7 +126,7 @@ void apply_bias_rope_update_kv_cache(torch::Tensor qkv, const torch::Tensor seq_
 }
 torch::Tensor compute_padding_offsets(const torch::Tensor cu_seqlens, const int max_seqlen, const int tot_num_tokens) {
     need(cu_seqlens, at::kInt, "cu_seqlens");
-    const c10::hip::OptionalHIPGuard guard(cu_seqlens.device());
+    const DeviceGuard guard(cu_seqlens.device());
     torch::Tensor out = torch::empty({tot_num_tokens}, cu_seqlens.options());
     QS_CALL(qs_compute_padding_offsets(out.data_ptr<int32_t>(), cu_seqlens.data_ptr<int32_t>(), (int)cu_seqlens.size(0) - 1,
                                        max_seqlen, cur_stream()));
@@ -134,7 +137,7 @@ torch::Tensor compute_padding_offsets(const torch::Tensor cu_seqlens, const int 
 void invoke_quant(torch::Tensor& out, torch::Tensor& input, torch::Tensor& scale) {
     need(out, at::kChar, "out"); need(input, at::kHalf, "input"); need(scale, at::kHalf, "scale");
     const int hidden = (int)input.size(-1);
-    const c10::hip::OptionalHIPGuard guard(out.device());
+    const DeviceGuard guard(out.device());
     QS_CALL(qs_invoke_quant(out.data_ptr<int8_t>(), input.data_ptr(), nullptr, scale.data_ptr(), (int)(input.numel() / hidden),
                             hidden, cur_stream()));
 }
@@ -142,7 +145,7 @@ void invoke_quant_fuse_sum(torch::Tensor& out, torch::Tensor& input, torch::Tens
     need(out, at::kChar, "out"); need(input, at::kHalf, "input"); need(input_sum, at::kHalf, "input_sum");
     need(scale, at::kHalf, "scale");
     const int hidden = (int)input.size(-1);
-    const c10::hip::OptionalHIPGuard guard(out.device());
+    const DeviceGuard guard(out.device());
     QS_CALL(qs_invoke_quant(out.data_ptr<int8_t>(), input.data_ptr(), input_sum.data_ptr(), scale.data_ptr(),
                             (int)(input.numel() / hidden), hidden, cur_stream()));
 }
@@ -152,7 +155,7 @@ void rms_norm(torch::Tensor& out, torch::Tensor& input, torch::Tensor& weight, f
     TORCH_CHECK(!use_quant, "rms_norm(use_quant=True) belongs to the W8A8 path (out of scope)");
     need(out, at::kHalf, "out"); need(input, at::kHalf, "input"); need(weight, at::kHalf, "weight");
     const int hidden = (int)input.size(-1);
-    const c10::hip::OptionalHIPGuard guard(out.device());
+    const DeviceGuard guard(out.device());
     QS_CALL(qs_rms_norm(out.data_ptr(), input.data_ptr(), weight.data_ptr(), epsilon, (int)(input.numel() / hidden), hidden,
                         cur_stream()));
 }
@@ -162,7 +165,7 @@ void rms_norm_general(torch::Tensor& out, torch::Tensor& input, torch::Tensor& w
     need(out, at::kChar, "out"); need(input, at::kHalf, "input"); need(weight, at::kHalf, "weight");
     need(scaling, at::kHalf, "scaling");
     const int hidden = (int)input.size(-1);
-    const c10::hip::OptionalHIPGuard guard(out.device());
+    const DeviceGuard guard(out.device());
     QS_CALL(qs_rms_norm_general(out.data_ptr<int8_t>(), input.data_ptr(), weight.data_ptr(), nullptr, scaling.data_ptr(), epsilon,
                                 (int)(input.numel() / hidden), hidden, cur_stream()));
 }
@@ -172,7 +175,7 @@ void rms_norm_general_fuse_sum(torch::Tensor& out, torch::Tensor& input, torch::
     need(out, at::kChar, "out"); need(input, at::kHalf, "input"); need(weight, at::kHalf, "weight");
     need(input_sum, at::kHalf, "input_sum"); need(scaling, at::kHalf, "scaling");
     const int hidden = (int)input.size(-1);
-    const c10::hip::OptionalHIPGuard guard(out.device());
+    const DeviceGuard guard(out.device());
     QS_CALL(qs_rms_norm_general(out.data_ptr<int8_t>(), input.data_ptr(), weight.data_ptr(), input_sum.data_ptr(),
                                 scaling.data_ptr(), epsilon, (int)(input.numel() / hidden), hidden, cur_stream()));
 }
@@ -181,7 +184,7 @@ void rms_norm_general_fuse_sum(torch::Tensor& out, torch::Tensor& input, torch::
 void silu_and_mul(torch::Tensor& out, torch::Tensor& input) {
     need(out, at::kHalf, "out"); need(input, at::kHalf, "input");
     const int d = (int)input.size(-1) / 2;
-    const c10::hip::OptionalHIPGuard guard(out.device());
+    const DeviceGuard guard(out.device());
     QS_CALL(qs_silu_and_mul(out.data_ptr(), input.data_ptr(), (int)(input.numel() / input.size(-1)), d, cur_stream()));
 }
 

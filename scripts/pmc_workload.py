@@ -16,6 +16,7 @@ q, k, v = q.reshape(B, eng.H, 128), k.reshape(B, eng.Hkv, 128), v.reshape(B, eng
 eng.qkv_buf.normal_()
 eng.q_act.random_(-127, 128)
 eng.q_mlp.random_(-127, 128)
+eng.q_attn.random_(-127, 128)
 eng.q_scale.fill_(0.01)
 eng.q_sum.fill_(1.0)
 for rep in range(2):
@@ -24,6 +25,7 @@ for rep in range(2):
         L["qkv"](eng.q_act, eng.q_scale, eng.q_sum, eng.qkv_buf)
         L["gate_up"].silu_mul(eng.q_act, eng.q_scale, eng.q_sum, eng.mlp_act, eng.gate_up_buf)   # what the step launches
         L["down"](eng.q_mlp, eng.q_scale, eng.q_sum, eng.proj_out)
+        L["o"](eng.q_attn, eng.q_scale, eng.q_sum, eng.proj_out)
         fa.single_query_attention(q, k, v, eng.tables[i], eng.lengths, None, 8192, 64, eng.size_per_token,
                                   eng.max_len, 128, eng.cfg["rope_theta"], True, eng.int4, True)
 torch.cuda.synchronize()
