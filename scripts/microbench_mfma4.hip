@@ -141,6 +141,71 @@ static void go16(int* out, const char* what) {
     printf("%-86s %7.1f TOPS\n", what, run([&] { k16<VAR><<<blocks, 1024, 98304>>>(out, iters); }, ops));
 }
 
+
+// P: the shipped tile with the operand reads software-pipelined a whole round ahead (two operand sets, no wait in front of
+// an MFMA that the previous round did not already cover); Q: the same 12 reads per round issued but never consumed by the
+// MFMAs (operands stay constant): separates "a read costs issue / return-path time" from "the MFMAs wait for their read".
+template <int MODE>   // 0 = P, 1 = Q
+__global__ __launch_bounds__(512, 1) void k8p(int* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    v4i A[4], B0[8], B1[8];
+    for (int i = 0; i < 4; ++i) A[i] = (v4i){tid * 0x01010101 + i, 0x11121314 + i, 0x21222324 * (i + 1), 0x31323334 + tid};
+    for (int i = 0; i < 8; ++i) B0[i] = B1[i] = (v4i){0x0a0b0c0d + i, tid * 0x00010203 + i, 0x2a2b2c2d * (i + 1), 0x3a3b3c3d + tid};
+    for (int i = tid; i < 32768 / 4; i += 512) reinterpret_cast<int*>(smem)[i] = i * 0x01030507;
+    __syncthreads();
+    v4i acc[8][4];
+    for (int m = 0; m < 8; ++m)
+        for (int c = 0; c < 4; ++c) acc[m][c] = (v4i){0, 0, 0, 0};
+    unsigned raw[8];
+    for (int i = 0; i < 8; ++i) raw[i] = tid * 0x9E3779B9u + i;
+    v4i sink = {0, 0, 0, 0};
+    const unsigned char* lb = smem + (tid & 63) * 16 + (tid >> 6) * 2048;
+    auto round = [&](v4i (&Bc)[8], v4i (&Bn)[8], int it) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const v4i r = *reinterpret_cast<const v4i*>(lb + ((m + it) & 7) * 1024);
+            if (MODE == 0) Bn[m] = r;
+            else sink ^= r;
+            if (m < 4) {
+                const v2u w = *reinterpret_cast<const v2u*>(lb + 16384 + ((m + it) & 3) * 512);
+                if (MODE == 0) {
+                    raw[2 * m] ^= w.x;
+                    raw[2 * m + 1] ^= w.y;
+                } else {
+                    sink[0] ^= (int)w.x;
+                    sink[1] ^= (int)w.y;
+                }
+            }
+            if (m >= 2 && m < 6) {
+                const int c = m - 2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned x = raw[(2 * c + e) & 7];
+                    A[c][e] = (int)((e & 1) ? ((x >> 4) & 0x0F0F0F0Fu) : (x & 0x0F0F0F0Fu));
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[m][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[c], Bc[m], acc[m][c], 0, 0, 0);
+        }
+    };
+    for (int it = 0; it < iters; it += 2) {
+        round(B0, B1, it);
+        round(B1, B0, it + 1);
+    }
+    int s = sink[0] + sink[1] + sink[2] + sink[3];
+    for (int m = 0; m < 8; ++m)
+        for (int c = 0; c < 4; ++c) s += acc[m][c][0] + acc[m][c][1] + acc[m][c][2] + acc[m][c][3];
+    out[blockIdx.x * 512 + tid] = s;
+}
+template <int MODE>
+static void go8p(int* out, const char* what) {
+    const int iters = 2000, blocks = 256;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k8p<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    const double ops = (double)blocks * 8 * iters * 32 * (2.0 * 16 * 16 * 64);
+    printf("%-86s %7.1f TOPS\n", what, run([&] { k8p<MODE><<<blocks, 512, 98304>>>(out, iters); }, ops));
+}
+
 int main() {
     int* out;
     hipMalloc(&out, 2048 * 1024 * 4);
@@ -151,6 +216,8 @@ int main() {
         go8<3, true>(out, "  + barrier");
         go8<2, false>(out, "8 waves 128x64: unpack + 8 b128 reads only (weights not through LDS)");
         go8<3, false>(out, "  + barrier");
+        go8p<0>(out, "8 waves 128x64: unpack + 12 reads, operands read one round ahead (compiler-scheduled)");
+        go8p<1>(out, "8 waves 128x64: unpack + 12 reads issued but not consumed by the MFMAs");
         go16<0>(out, "16 waves (4/SIMD) 64x64: MFMA only");
         go16<1>(out, "  + unpack (32 VALU per 16 MFMA)");
         go16<2>(out, "  + 4 b128 + 4 b64 LDS reads");
