@@ -160,9 +160,12 @@ class DecodeEngine:
         H, Hkv = cfg["heads"], cfg["kv_heads"]
         # (more ranks than KV heads would need the loader's replicated-KV shards AND an engine that de-duplicates the
         # replicated cache writes: the loader supports it, this engine does not - reject instead of mis-sizing the pools)
-        assert H % tp_world == 0 and Hkv % tp_world == 0 and cfg["inter"] % (tp_world * 128) == 0, \
-            f"tp_world={tp_world} must divide heads={H}, kv_heads={Hkv} and inter/128={cfg['inter'] // 128}"
-        self.H, self.Hkv = H // tp_world, Hkv // tp_world
+        # KV heads: Hkv / tp per rank, or - beyond one rank per KV head - ONE head replicated over tp / Hkv neighbouring ranks
+        # (the loader's rule, qserve_amd/loader.py: rank r then holds KV head r // (tp / Hkv))
+        assert H % tp_world == 0 and (Hkv % tp_world == 0 or tp_world % Hkv == 0) and \
+            cfg["inter"] % (tp_world * 128) == 0, \
+            f"tp_world={tp_world} must divide heads={H}, divide or be a multiple of kv_heads={Hkv}, and divide inter/128={cfg['inter'] // 128}"
+        self.H, self.Hkv = H // tp_world, max(1, Hkv // tp_world)
         hid, inter = cfg["hidden"], cfg["inter"] // tp_world
         self.hid, self.inter = hid, inter
         self.qkv_n = (self.H + 2 * self.Hkv) * 128

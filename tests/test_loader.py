@@ -129,10 +129,10 @@ def run_tp_lockstep(engines, steps):
     return outs
 
 
-def _tp_case(device, group_size, bias, world=2, prompt_len=70, steps=2):
+def _tp_case(device, group_size, bias, world=2, prompt_len=70, steps=2, CFG=CFG):
     from qserve_amd import decode as D
     from qserve_amd import loader
-    sd = make_checkpoint(group_size, bias, seed=9)
+    sd = make_checkpoint(group_size, bias, seed=9, cfg=CFG)
     B = 3
     single = D.DecodeEngine(CFG, B, prompt_len, 8, group_size=group_size, device=device, with_lm_head=True,
                             weights=loader.load_llama_w4a8(sd, CFG, group_size, load_norm_weights=True))
@@ -144,7 +144,8 @@ def _tp_case(device, group_size, bias, world=2, prompt_len=70, steps=2):
     # so fill every engine's cache from the single engine's un-sharded prefill of the SAME tokens, per KV head
     tok = torch.randint(0, CFG["vocab"], (B * prompt_len,), generator=torch.Generator().manual_seed(1)).to(device)
     single.prefill(prompt_len, tokens=tok)
-    Hkv_r = CFG["kv_heads"] // world
+    Hkv_r = max(1, CFG["kv_heads"] // world)
+    kv_rep = max(1, world // CFG["kv_heads"])            # ranks per KV head beyond one head per rank (loader's rule)
     dhb = 64
     for li in range(CFG["layers"]):
         for which in (0, 1):
@@ -154,7 +155,7 @@ def _tp_case(device, group_size, bias, world=2, prompt_len=70, steps=2):
             sc = full[:, nd:nd + CFG["kv_heads"] * 128].reshape(-1, CFG["kv_heads"], 128)
             zr = full[:, nd + CFG["kv_heads"] * 128:].reshape(-1, CFG["kv_heads"], 128)
             for r, e in enumerate(ranks):
-                hs = slice(r * Hkv_r, (r + 1) * Hkv_r)
+                hs = slice((r // kv_rep) * Hkv_r, (r // kv_rep + 1) * Hkv_r)
                 page = torch.cat([data[:, hs].reshape(len(full), -1), sc[:, hs].reshape(len(full), -1),
                                   zr[:, hs].reshape(len(full), -1)], dim=1)
                 # same block permutation in every engine (seeded by `seed`), so page i <-> page i
@@ -170,7 +171,7 @@ def _tp_case(device, group_size, bias, world=2, prompt_len=70, steps=2):
         single.step()
         ref.append(single.final.clone())
         outs += run_tp_lockstep(ranks, 1)
-        assert torch.equal(ranks[0].tokens, ranks[1].tokens)
+        assert all(torch.equal(ranks[0].tokens, e.tokens) for e in ranks[1:])
         # vocabulary-parallel greedy head: the token every rank ends with is the first maximum over the concatenation of
         # the ranks' shard logits (= the whole row, shard r owning the r-th vocabulary range)
         assert all(e.vocab_parallel and e.lm_head.size(0) == CFG["vocab"] // world for e in ranks)
@@ -187,7 +188,7 @@ def _tp_case(device, group_size, bias, world=2, prompt_len=70, steps=2):
             # sharding mistake (e.g. ranks taking each other's o_proj / down_proj K slice) gives 50-100 %
             rel = ((a - b).norm() / b.norm()).item()
             assert rel <= 0.08, (s, r, rel)
-        assert torch.equal(outs[s][0], outs[s][1]), "ranks must hold identical hidden states after the reduce"
+        assert all(torch.equal(outs[s][0], o) for o in outs[s][1:]), "ranks must hold identical hidden states after the reduce"
     return single, ranks
 
 
@@ -196,6 +197,16 @@ def test_tp2_matches_tp1_host_simulator(built_lib, monkeypatch, group_size, bias
     import _fake_abi
     _fake_abi.install(monkeypatch)
     _tp_case("cpu", group_size, bias)
+
+
+def test_tp4_with_replicated_kv_heads_host_simulator(built_lib, monkeypatch):
+    """More ranks than KV heads (the reference's rule for that case, loader.py kv_rep): ranks 2h, 2h+1 hold KV head h; the
+    engine takes the loader's shards as they are."""
+    import _fake_abi
+    _fake_abi.install(monkeypatch)
+    cfg = dict(CFG, heads=4, kv_heads=2, hidden=512)
+    single, ranks = _tp_case("cpu", -1, False, world=4, CFG=cfg)
+    assert all(e.Hkv == 1 and e.H == 1 for e in ranks)
 
 
 @pytest.mark.gpu
