@@ -142,7 +142,7 @@ int qs_w8a8_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscal
  * libqserve_amd_timing.so, loaded by the measurement scripts through QS_AMD_LIBRARY) and are ignored otherwise:
  *   9xx / 1000 + 100*mtile + 10*S + NW ... split-K decode kernel geometries;  2000 / 2001 ... LDS-pair kernel off / forced;
  *   3000 ... tiled (prefill) kernel off, 3001 / 3002 ... forced with the 256- / 128-token tile;
- *   4000 ... ring (decode) kernel off, 4001 ... ring kernel without K slices,
+ *   4000 ... ring (decode) kernel off, 4001 ... ring kernel without K slices, 4002 ... cost model without the per-group term,
  *   4100 + 100*(k_slices-1) + 10*m_tiles + units ... forced ring geometry;
  *   5000 + bits ... A/B switches of the ring kernel (1: weight DMA without the non-temporal hint; 2: never take a row-op
  *                   tail; 256 * d: ring depth d; [QS_TIMING builds: 32 / 64 no MFMA / no operand reads]); sticky until reset

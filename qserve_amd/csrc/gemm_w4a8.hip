@@ -507,7 +507,10 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
                 const int mb = (mt_all + mt - 1) / mt;
                 if (ks > 1 && (long)mb * (N / (64 * wn)) > 256) continue;   // K slices are for under-filled grids only
                 const long blocks = (long)mb * (N / (64 * wn)) * ks;
-                const long cost = ((blocks + 255) / 256) * (16 * mt + 32 * wn) * (long)(K / ks) * (ks > 1 ? 11 : 10) / 10 +
+                // per-group: the level-2 dequant is VALU work per weight byte a workgroup streams (measured at M = 128, g128:
+                // qkv 16.0 us with (4,1) against 18.2 with the equal-bytes (2,2)) - charged as a quarter of the weight bytes
+                const long pg = MODE == 1 && g_variant != 4002 ? 8 * wn : 0;
+                const long cost = ((blocks + 255) / 256) * (16 * mt + 32 * wn + pg) * (long)(K / ks) * (ks > 1 ? 11 : 10) / 10 +
                                   seam(ks, mt);
                 if (best < 0 || cost < best) best = cost, bmt = mt, bwn = wn, bks = ks;
             }

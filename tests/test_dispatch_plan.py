@@ -69,6 +69,12 @@ def test_per_group_follows_the_same_model():
     assert gemm_plan(64, 4096, 14336, per_group=True) == ring(2, 2, 2, 4)
     assert gemm_plan(128, 28672, 4096, per_group=True) == ring(4, 4, 2)     # 224 workgroups, one round (41.0 vs 47.0 us)
     assert gemm_plan(2048, 4096, 4096, per_group=True)["family"] in ("tiled", "ring", "pair")
+    # the level-2 dequant is VALU work per streamed weight byte: at equal bytes per CU the geometry with fewer channels per
+    # workgroup wins per-group (g128 qkv at M = 128: 16.2 vs 18.3 us), while per-channel keeps (2,2) (12.1 vs 13.9 us)
+    assert gemm_plan(128, 6144, 4096, per_group=True) == ring(4, 1, 2)
+    assert gemm_plan(128, 6144, 4096) == ring(2, 2, 4)
+    assert gemm_plan(64, 6144, 4096, per_group=True) == ring(2, 1, 2)       # unchanged by the per-group term
+    assert gemm_plan(64, 28672, 4096, per_group=True) == ring(4, 2, 1)
 
 
 def test_rejected_shapes_raise():
