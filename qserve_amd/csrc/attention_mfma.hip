@@ -3,14 +3,20 @@
 // Same contract as decode_attention_kernel in attention.hip (reference: fused_attention.cpp:150-240,
 // decoderMaskedMultiheadAttentionTemplate.hpp:717-2222, ZINT4 variant); different mapping:
 //
-//   * one workgroup (NW = 8 wave64) per (sequence, KV head); every wave owns whole 64-token pages (page p -> wave
-//     p % NW) and runs QK -> online softmax -> PV on them WITHOUT any workgroup barrier; the partial (max, sum, out)
-//     triples are merged once at the end through LDS (flash-decoding inside the workgroup).  All G = H/Hkv query
-//     heads of the group are served from one read of the page (the reference re-reads it per query head).
-//   * page slices (4 KiB K + 4 KiB V + 2 x 256 B scales/zeros) travel HBM -> LDS by LDS-DMA (global_load_lds, 16 B per
-//     lane, lane-linear = fully coalesced) into wave-private buffers: no staging registers, completion tracked with
-//     counted s_waitcnt vmcnt.  K(p+NW) is requested when Q.K^T of page p is done, V(p+NW) when P.V is done.
-//   * Q.K^T on v_mfma_f32_16x16x32_f16: A = 16 tokens x 32 dims of the K page: lane (tok, kg) turns the 8 nibbles of a
+//   * one workgroup (NW = 8 wave64) per (sequence, KV head).  The cache is consumed in PIPELINE UNITS of 32 tokens (half a
+//     64-token page): unit j of the workgroup's range belongs to wave j % PS (PS = 7 or 8 page-owning waves); every wave
+//     runs QK -> online softmax -> PV on its units WITHOUT any workgroup barrier; the partial (max, sum, out) triples are
+//     merged once at the end through LDS (flash-decoding inside the workgroup).  All G = H/Hkv query heads of the group
+//     are served from one read of the unit (the reference re-reads it per query head).
+//     Round 4: units instead of whole pages.  With pages a wave's first request was 8.5 KiB, the first Q.K^T of the
+//     kernel started when 40 % of the launch was over (the first round = half of all bytes had to land first) and 17
+//     pages over 7 waves meant 3 page rounds for a mean of 2.43; with units a wave's first request is 4.25 KiB, compute
+//     starts with the first quarter of the bytes, and 33 units over 7 waves are 5 unit rounds = 2.5 page rounds.
+//   * a unit (2 KiB K + 2 KiB V + 4 x 64 B scales / zeros) travels HBM -> LDS by LDS-DMA (global_load_lds, 16 B per
+//     lane, lane-linear = fully coalesced) into wave-private two-slot rings: no staging registers, completion tracked
+//     with counted s_waitcnt vmcnt.  Request group A = (K meta, K data x 2), group B = (V meta, V data x 2); A(i+2) is
+//     requested when Q.K^T of unit i is done, B(i+2) when P.V is done.
+//   * Q.K^T on v_mfma_f32_16x16x32_f16: A = 16 tokens x 32 dims of the K unit: lane (tok, kg) turns the 8 nibbles of a
 //     dword into fp16 with the magic-number trick and feeds them IN OFFSET FORM (1024+n, 1024+16n) - the offsets are
 //     removed from the 16x16 result with a per-head constant, the per-token scale / zero point likewise:
 //         score = ksc[tok] * (c_raw - Qoff[head] - kzr[tok] * qsum[head]) / sqrt(128)
@@ -19,11 +25,12 @@
 //     v_perm_b32 pairs byte bb of two tokens (0x00BB00AA) and the two nibble masks give the fp16 pairs of dims 2bb and
 //     2bb+1 (offset form 1024 + n / 1024 + 16 n), i.e. the 8x8 transposition costs one perm per 4 elements.  B = P'^T with
 //     P' = fp16(p * vsc[tok]); the zero-point term sum_t P'_t vzr_t is subtracted from every output dim at the end.
-//   * softmax on compacted lanes: only G of the 16 result columns are heads, so the 4 score tiles of a page are moved
-//     (DPP row_shr, bank-masked) onto the idle lanes of their 16-lane row - 4 scores per lane for G <= 4 (tile t' on
-//     lanes G't' + h), 8 per lane for G = 5..8 (two lane groups) - the scale / zero-point / exp2 / P' work shrinks
-//     accordingly and the P' operands return with row_shl moves; scores live in the log2 domain; V operands stay in
-//     offset form like K and the offsets leave through sum(P') at the end.
+//   * softmax on compacted lanes: only G of the 16 result columns are heads, so the 2 score tiles of a unit are moved
+//     (DPP row_shr, bank-masked) onto the idle lanes of their 16-lane row: G <= 4 - lane li = h + 4 (2 t + rp) owns the
+//     scores r = 2 rp, 2 rp + 1 of tile t and head h (2 scores per lane, every lane busy for G = 4); G = 5..8 - lane
+//     li = h + 8 t owns the 4 scores of tile t.  The scale / zero-point / exp2 / P' work shrinks accordingly and the P'
+//     operands return with row_shl moves; scores live in the log2 domain; V operands stay in offset form like K and the
+//     offsets leave through sum(P') at the end.
 //   * cache integers are exact in fp16 and every accumulation is fp32: the result is the exact attention over the
 //     de-quantised cache up to fp16 rounding of q, P' and the output (parity bar 1e-3, tests/test_attention_gpu.py).
 #include "common.h"
@@ -33,10 +40,12 @@ namespace {
 constexpr int PAGE_TOK = 64;
 constexpr int DH = 128;
 constexpr int DHB = 64;        // KV4 bytes per token per head
-constexpr int NW = 8;          // waves per workgroup; all of them own pages
+constexpr int UT = 32;         // tokens per pipeline unit (half a page)
+constexpr int USB = UT * DHB;  // bytes of K (or V) data per unit and KV head
+constexpr int NW = 8;          // waves per workgroup; all of them may own units
 constexpr int NWT = NW;
-constexpr int SVC = NW - 1;    // the service wave (RoPE, operand build, new token) - the wave that owns the fewest pages
-constexpr int MAXP = 192;      // page-table entries cached in LDS per sequence (dispatcher: max_blocks <= MAXP)
+constexpr int SVC = NW - 1;    // the service wave (RoPE, operand build, new token) - the wave that owns the fewest units
+constexpr int MAXP = 192;      // longest page table this kernel is dispatched for (dispatcher: max_blocks <= MAXP)
 
 struct RopeCS {
     float c, s;
@@ -104,12 +113,10 @@ typedef __attribute__((address_space(3))) const uint8_t* lds_u8;   // 32-bit LDS
 
 // EXP: timing / ablation switches (libraries built with -DQS_TIMING only: qs_set_attention_variant(200 + EXP), G = 4 only;
 // the shipped library instantiates EXP = 0 and ignores the request):
-//   1 = page DMA WITHOUT the non-temporal hint (default: nt - every KV byte is read once per step; measured -4 % at
+//   1 = unit DMA WITHOUT the non-temporal hint (default: nt - every KV byte is read once per step; measured -4 % at
 //       L = 1033 ... -12 % at L = 4096), 2 = no compute (DMA + waits only: results are wrong by design),
-//   4 = skip phase A (RoPE / new token: wrong by design), 8 = fetch the last page in full (default: only the rows of
-//       valid tokens), 32 = timeline trace (s_memtime stamps into the split workspace, scripts/trace_attn.py),
-//   64 = no new-token cache write / own score at the end (wrong), 128 = RoPE without the dependent table load (wrong),
-//   256 = the service wave owns no pages (correct results)
+//   4 = skip phase A (RoPE / new token: wrong by design), 32 = timeline trace (s_memtime stamps into the split workspace,
+//       scripts/trace_attn.py)
 template <int G, int EXP = 0>
 __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     const _Float16* __restrict__ q, const _Float16* __restrict__ k, const _Float16* __restrict__ v,
@@ -118,14 +125,15 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     float rope_base, const float2* __restrict__ rope_tab, int rope_tab_len, int nsplit, float* __restrict__ ws,
     int8_t* __restrict__ qout, __half* __restrict__ qscale, __half* __restrict__ qrowsum, unsigned* __restrict__ qcounters,
     int kflags) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_kv[2 * NW * PAGE_TOK * DHB];   // [K | V][wave][4 KiB]
-    __shared__ __attribute__((aligned(16))) _Float16 s_meta[NW][4][PAGE_TOK];   // k scale, k zero, v scale, v zero
+    __shared__ __attribute__((aligned(16))) uint8_t s_kv[2 * NW * 2 * USB];     // [K | V][wave][slot 0 / 1][2 KiB]
+    __shared__ __attribute__((aligned(16))) _Float16 s_meta[NW][2][4][UT];      // [wave][slot]: k scale, k zero, v scale, v zero
     __shared__ __attribute__((aligned(16))) _Float16 s_q[G][DH];                // rotated q of the G heads
     __shared__ __attribute__((aligned(16))) _Float16 s_qp[16][DH];              // Q.K^T B operand (see below)
     __shared__ __attribute__((aligned(16))) _Float16 s_knew[DH];
+    __shared__ __attribute__((aligned(16))) _Float16 s_vnew[DH];                // the new token's raw v
     __shared__ float s_cur[16];
     __shared__ float s_m[NW][G], s_l[NW][G];
-    __shared__ int s_flag;                                                      // service wave -> page waves: operands ready
+    __shared__ int s_flag;                                                      // service wave -> unit waves: operands ready
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -139,65 +147,84 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         }
     };
     stamp(0);
+    // the rows of the new token (wave-uniform addresses: scalar bases of the service wave's entry requests below)
+    const _Float16* qb = q + (size_t)b * q_stride0 + (size_t)hkv * G * DH;
+    const _Float16* kb = k + (size_t)b * kv_stride0 + (size_t)hkv * DH;
+    const _Float16* vb = v + (size_t)b * kv_stride0 + (size_t)hkv * DH;
+    auto uni_ptr = [](const void* x) -> uint64_t {
+        return ((uint64_t)(u32)__builtin_amdgcn_readfirstlane((u32)((uint64_t)(uintptr_t)x >> 32)) << 32) |
+               (uint64_t)(u32)__builtin_amdgcn_readfirstlane((u32)(uint64_t)(uintptr_t)x);
+    };
+    const uint64_t qb_s = uni_ptr(qb), kb_s = uni_ptr(kb), vb_s = uni_ptr(vb);
     const int64_t* ktab = kv_pointers + (size_t)b * 2 * max_blocks;
     const int64_t* vtab = ktab + max_blocks;
-    // first-round page addresses are requested together with the length (they do not depend on it when this workgroup
-    // starts at page 0): one memory round trip less on the launch -> first bytes chain
-    // (the service wave's speculative addresses are simply not used when it turns out to own no pages, see svc_free)
-    const bool spec = (nsplit == 1 || blockIdx.z == 0) && wave < max_blocks;
-    int64_t kpage0 = 0, vpage0 = 0;
+    // The page addresses of a wave's first two units are requested together with the length (they do not depend on it
+    // when this workgroup starts at unit 0): one memory round trip less on the launch -> first bytes chain.  The wave's
+    // first unit is unit `wave` (page wave / 2); its second one is unit wave + 7 or wave + 8 - which of the two is known
+    // only with the length (page-ownership rule below), so both candidates are fetched.
+    // (the service wave's speculative addresses are simply not used when it turns out to own no units, see svc_free)
+    const bool spec = (nsplit == 1 || blockIdx.z == 0);
+    int64_t kpage0 = 0, vpage0 = 0, kpage7 = 0, vpage7 = 0, kpage8 = 0, vpage8 = 0;
     if (spec) {
-        kpage0 = ktab[wave];
-        vpage0 = vtab[wave];
+        const int p0 = wave >> 1, p7 = (wave + NW - 1) >> 1, p8 = (wave + NW) >> 1;
+        if (p0 < max_blocks) {
+            kpage0 = ktab[p0];
+            vpage0 = vtab[p0];
+        }
+        if (p7 < max_blocks) {
+            kpage7 = ktab[p7];
+            vpage7 = vtab[p7];
+        }
+        if (p8 < max_blocks) {
+            kpage8 = ktab[p8];
+            vpage8 = vtab[p8];
+        }
     }
     // (the length and the first-round page addresses are requested FIRST, as scalar loads: anything the compiler cannot
     // prove store-free in front of them - volatile asm, the loads of the service wave - would make them vector loads)
     const int tl = lengths ? lengths[b] - 1 : timestep;   // tlength, Template.hpp:901
     // service wave: q / k / v of the new token do not depend on the context length - requested at kernel entry, ahead of
-    // every page DMA of this CU in the memory pipeline (which serves requests in order: loads issued after the burst of
+    // every unit DMA of this CU in the memory pipeline (which serves requests in order: loads issued after the burst of
     // the first round would come back ~4 us later); raised issue priority until the operands are published
-    const _Float16* qb = q + (size_t)b * q_stride0 + (size_t)hkv * G * DH;
-    const _Float16* kb = k + (size_t)b * kv_stride0 + (size_t)hkv * DH;
-    const _Float16* vb = v + (size_t)b * kv_stride0 + (size_t)hkv * DH;
-    _Float16 qlo[G], qhi[G], klo = 0, khi = 0;
-    h2 vnew_pair = {0, 0};                 // the new token's raw v (two elements per lane)
-#pragma unroll
-    for (int h = 0; h < G; ++h) qlo[h] = qhi[h] = 0;
+    // (by LDS-DMA straight into s_q / s_knew / s_vnew: 256 B per instruction, no destination registers - register loads
+    // issued under `wave == SVC` here and consumed under the same test further down leave their registers "load pending"
+    // on the compiler's infeasible SVC -> non-SVC path, and its waitcnt pass then drains the unit waves' DMA queue - vmcnt(0) -
+    // wherever the shared code reuses one of them)
     if (wave == SVC) {
         asm volatile("s_setprio 3");       // (asm without a memory clobber: the builtin counts as a possible store and
                                            //  turns every later page-table lookup into a vector load)
         if constexpr (!(EXP & 4)) {
+            const u32 lane4 = (u32)lane * 4u;
+            auto glds4 = [&](uint64_t sb, const _Float16* dst) {
+                const u32 ld = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)(__attribute__((address_space(3))) const void*)dst);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1" ::"v"(lane4), "s"(sb), "s"(ld) : "memory");
+            };
 #pragma unroll
-            for (int h = 0; h < G; ++h) {
-                qlo[h] = qb[h * DH + lane];
-                qhi[h] = qb[h * DH + 64 + lane];
-            }
-            klo = kb[lane];
-            khi = kb[64 + lane];
-            vnew_pair = *reinterpret_cast<const h2*>(vb + 2 * lane);
+            for (int h = 0; h < G; ++h) glds4(qb_s + (uint64_t)(h * DH * 2), &s_q[h][0]);
+            glds4(kb_s, &s_knew[0]);
+            glds4(vb_s, &s_vnew[0]);
         }
     }
     if (tl < 0) return;
     stamp(1);
     const float inv_sqrt = 0.08838834764831845f;
     const float qk_scale = inv_sqrt * 1.4426950408889634f;   // scores live in the log2 domain: exp2 everywhere
-    constexpr int GP = G <= 1 ? 1 : G <= 2 ? 2 : G <= 4 ? 4 : 8;   // group size padded to a power of two (lane mapping)
-    constexpr bool COMPACT = (GP <= 4);                            // softmax on compacted lanes (see the page loop)
+    constexpr int GP = G <= 4 ? 4 : 8;   // lane scheme of the compacted softmax: heads padded to 4 or 8 (surplus head lanes idle)
     const int li = lane & 15, tg = lane >> 4;
-    uint8_t* const s_kw = s_kv + wave * (PAGE_TOK * DHB);                // this wave's K page buffer
-    uint8_t* const s_vw = s_kv + (NW + wave) * (PAGE_TOK * DHB);         // this wave's V page buffer
+    uint8_t* const s_kw = s_kv + wave * (2 * USB);                // this wave's K ring (2 slots)
+    uint8_t* const s_vw = s_kv + (NW + wave) * (2 * USB);         // this wave's V ring (2 slots)
 
-    // ---- page fetch by LDS-DMA ------------------------------------------------------------------------------------
-    const int npages = (tl + PAGE_TOK - 1) >> 6;
+    // ---- unit fetch by LDS-DMA ------------------------------------------------------------------------------------
+    const int nunits = (tl + UT - 1) >> 5;
     // split-KV (flash-decoding across workgroups, gridDim.z = nsplit > 1 when batch x kv-heads cannot fill the chip):
-    // this workgroup handles pages [p_begin, p_end); split 0 also owns the new token (cache write + its own term)
+    // this workgroup handles units [u_begin, u_end); split 0 also owns the new token (cache write + its own term)
     const int z = blockIdx.z;
-    const int pps = (npages + nsplit - 1) / nsplit;
-    const int p_begin = z * pps, p_end = min(npages, p_begin + pps);
+    const int ups = (nunits + nsplit - 1) / nsplit;
+    const int u_begin = z * ups, u_end = min(nunits, u_begin + ups);
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    // Page addresses of the later rounds: SCALAR loads (scalar cache / lgkmcnt - they never enter the in-order vmcnt queue
-    // of the page DMA; the table rows were touched by the first-round lookups).  From inline asm, because behind the DMA
+    // Page addresses of the later units: SCALAR loads (scalar cache / lgkmcnt - they never enter the in-order vmcnt queue
+    // of the unit DMA; the table rows were touched by the first-round lookups).  From inline asm, because behind the DMA
     // statements' "memory" clobber the compiler itself would fall back to vector loads for kv_pointers.
     auto next_pages = [&](int p, int64_t& kn, int64_t& vn) {
         const uint64_t ka = (uint64_t)(uintptr_t)(ktab + p), va = (uint64_t)(uintptr_t)(vtab + p);
@@ -211,114 +238,128 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     };
     // LDS-DMA issued from inline asm (recipe: cdna_hip_programming.md 5.7 - M0 carries the wave-uniform LDS base and is
     // written in the statement that reads it).  Deliberately NOT the builtin: the compiler's waitcnt pass models every
-    // builtin LDS-DMA as a pending LDS write and puts a vmcnt(0) in front of the next ds_read of the page loop as soon
-    // as pages are in flight at loop entry - which serialises fetch and compute and makes the counted waits below
-    // meaningless.  With asm the compiler sees no DMA at all; every wait on this queue is explicit (vmcnt(10) / (5) / (0)).
-    auto dma16 = [&](const uint8_t* g, uint8_t* l) {
-        u32 keep;
-        const u32 ldst = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)(lptr_t)l);   // provably wave-uniform for the "s" operand
+    // builtin LDS-DMA as a pending LDS write and puts a vmcnt(0) in front of the next ds_read of the unit loop as soon
+    // as units are in flight at loop entry - which serialises fetch and compute and makes the counted waits below
+    // meaningless.  With asm the compiler sees no DMA at all; every wait on this queue is explicit (vmcnt(9) / (6) / (3) / (0)).
+    // Scalar-base form (global_load_lds voffset, s[base:base+1]): the source address of a piece is a wave-uniform base
+    // (page + head + half + piece offset: SALU adds) plus a per-lane byte offset that never changes (16 * lane) - no 64-bit
+    // vector address arithmetic per request.  (s_nop 4: five wait states between the write of an SGPR by a VALU
+    // instruction - v_readfirstlane - and its use as a VMEM base; covers the M0 write -> LDS-DMA state as well.)
+    auto uni64 = [&](int64_t x) -> uint64_t {        // provably wave-uniform 64-bit value for an "s" operand
+        return ((uint64_t)(u32)__builtin_amdgcn_readfirstlane((u32)((uint64_t)x >> 32)) << 32) |
+               (uint64_t)(u32)__builtin_amdgcn_readfirstlane((u32)(uint64_t)x);
+    };
+    auto glds16 = [&](uint64_t sbase, u32 voff, u32 ldst) {
         if constexpr (!(EXP & 1))
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(g), "s"(ldst) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(ldst) : "memory");
         else
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(g), "s"(ldst) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(ldst) : "memory");
     };
-    auto dma4 = [&](const void* g, const void* l) {       // per-lane source, 4 B per lane: 256 B per wave instruction
-        u32 keep;
-        const u32 ldst = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)(lptr_t)l);   // provably wave-uniform for the "s" operand
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(g), "s"(ldst) : "memory");
+    // 4 B per lane from sbase + voff on HALF of the lanes (EXEC narrowed inside the statement - the surrounding code is
+    // wave-uniform, all 64 lanes active); LDS destination = ldst + 4 * lane (the lane's own number, also for the upper half)
+    auto glds4_lower = [&](uint64_t sbase, u32 voff, u32 ldst) {
+        uint64_t ex;
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_hi, 0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b64 exec, %0"
+                     : "=&s"(ex) : "v"(voff), "s"(sbase), "s"(ldst) : "memory");
     };
-    auto dma_k = [&](int64_t page, int valid_tok = PAGE_TOK) {     // 4 x 1 KiB data + 256 B (scales | zeros): 5 VMEM instructions
-        const uint8_t* kbase = reinterpret_cast<const uint8_t*>(page);
-        const uint8_t* kd = kbase + (u32)(hkv * PAGE_TOK * DHB + lane * 16);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if constexpr (!(EXP & 8)) {
-                // lanes of tokens >= valid stay idle (their bytes are never read: masked scores / zero probabilities);
-                // lane 0 always loads so that the instruction issues and the vmcnt bookkeeping holds
-                if (16 * e + (lane >> 2) < valid_tok || lane == 0) dma16(kd + e * 1024, s_kw + e * 1024);
-            } else {
-                dma16(kd + e * 1024, s_kw + e * 1024);
-            }
+    auto glds4_upper = [&](uint64_t sbase, u32 voff, u32 ldst) {
+        uint64_t ex;
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, 0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b64 exec, %0"
+                     : "=&s"(ex) : "v"(voff), "s"(sbase), "s"(ldst) : "memory");
+    };
+    // Unit u = tokens [32 u, 32 u + 32) = half (u & 1) of page u >> 1.  Request group A: the K scales | zeros of the unit's
+    // tokens (lanes 0-15 | 16-31: 128 B) and 2 x 1 KiB of K data; group B: the same of V (meta by lanes 32-63, so that the
+    // lane-linear LDS destination of both groups is ONE 256-byte record [k scale | k zero | v scale | v zero] per slot).
+    // 3 VMEM instructions each - what the counted waits below rely on.
+    const u32 meta_lane = (u32)(((lane >> 4) & 1) * num_kv_heads * PAGE_TOK * 2 + (lane & 15) * 4);
+    const u32 lane16 = (u32)lane * 16u;
+    const u32 lds_k = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)(lptr_t)s_kw);
+    const u32 lds_v = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)(lptr_t)s_vw);
+    const u32 lds_m = __builtin_amdgcn_readfirstlane((u32)(uintptr_t)(lptr_t)(&s_meta[wave][0][0][0]));
+    const u32 meta_off = (u32)(num_kv_heads * PAGE_TOK * DHB + hkv * PAGE_TOK * 2);
+    const u32 data_off = (u32)(hkv * PAGE_TOK * DHB);
+    auto dma_data = [&](uint64_t base, u32 ldst, int valid_tok) {   // 2 x 1 KiB of one unit
+        if (valid_tok >= UT) {                    // wave-uniform: every unit but the sequence's last one
+            glds16(base, lane16, ldst);
+            glds16(base + 1024, lane16, ldst + 1024);
+        } else {
+            // lanes of tokens >= valid stay idle (their bytes are never read: masked scores / zero probabilities);
+            // lane 0 always loads so that the instruction issues and the vmcnt bookkeeping holds
+            if ((lane >> 2) < valid_tok || lane == 0) glds16(base, lane16, ldst);
+            if (16 + (lane >> 2) < valid_tok || lane == 0) glds16(base + 1024, lane16, ldst + 1024);
         }
-        const uint8_t* mb = kbase + (u32)(num_kv_heads * PAGE_TOK * DHB +
-                                          ((lane >> 5) * num_kv_heads + hkv) * PAGE_TOK * 2 + (lane & 31) * 4);
-        dma4(mb, &s_meta[wave][0][0]);
     };
-    auto dma_v = [&](int64_t page, int valid_tok = PAGE_TOK) {
-        const uint8_t* vbase = reinterpret_cast<const uint8_t*>(page);
-        const uint8_t* vd = vbase + (u32)(hkv * PAGE_TOK * DHB + lane * 16);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if constexpr (!(EXP & 8)) {
-                if (16 * e + (lane >> 2) < valid_tok || lane == 0) dma16(vd + e * 1024, s_vw + e * 1024);
-            } else {
-                dma16(vd + e * 1024, s_vw + e * 1024);
-            }
-        }
-        const uint8_t* mb = vbase + (u32)(num_kv_heads * PAGE_TOK * DHB +
-                                          ((lane >> 5) * num_kv_heads + hkv) * PAGE_TOK * 2 + (lane & 31) * 4);
-        dma4(mb, &s_meta[wave][2][0]);
+    auto dma_a = [&](int64_t page, int half, int slot, int valid_tok) {
+        const uint64_t pg = uni64(page);
+        glds4_lower(pg + (meta_off + (u32)(half * UT * 2)), meta_lane, lds_m + (u32)(slot * (4 * UT * 2)));
+        dma_data(pg + (data_off + (u32)(half * USB)), lds_k + (u32)(slot * USB), valid_tok);
     };
-    // ---- phase A on the SERVICE wave, concurrent with the first page fetch ---------------------------------------------
-    // What the timeline trace (EXP & 32) showed for the one-barrier-after-DMA form: issuing the first-round page DMA
-    // takes a wave 2-4 us (the memory pipeline back-pressures the burst), so any phase-A work that sits behind that issue
-    // in program order, and any barrier all waves must reach after it, completes at ~10 us - the first Q.K^T of a 20 us
-    // kernel started at 11 us.  Now: seven waves do nothing but issue their DMA; the last wave (it owns the fewest
-    // pages) first loads q / k / v / the RoPE coefficients / the page table with ordinary loads - its vmcnt queue is
-    // still empty, the compiler's own counted waits are right - rotates, builds the Q.K^T operand image, raises an LDS
-    // flag (~2 us after launch) and only then issues its own page DMA; the other waves poll that flag after their issue
-    // (no barrier couples the waves to each other) and start on whichever page has landed.  The new token's cache write
-    // and its own score follow on the service wave after its pages, off everybody's critical path.
-    // (A ninth, page-less wave was tried first: 576-thread workgroups no longer fit twice on a CU - 26 vs 20 us.)
-    const int blk = tl >> 6, slot = tl & 63;
-    // Page ownership.  The service wave starts its pages ~2 us after the others (operand build first) and then still has
-    // the new token's cache write and score to do: with its round-robin share of the pages it is the last wave to finish
-    // (timeline trace; EXP 256 / 64 ablations: 19.7 -> 17.9 us at 17 pages).  Whenever seven waves need no more rounds than
-    // eight would - ceil(n / 7) == ceil(n / 8): 1-7, 9-14, 17-21, 25-28, ... pages - it therefore owns NO pages, finishes the
-    // new token right after the operand build and waits at the merge; the other seven take the pages round-robin.
-    // (EXP & 256, timing builds: always.)
-    const int npg = p_end - p_begin;
+    auto dma_b = [&](int64_t page, int half, int slot, int valid_tok) {
+        const uint64_t pg = uni64(page);
+        glds4_upper(pg + (meta_off + (u32)(half * UT * 2)), meta_lane, lds_m + (u32)(slot * (4 * UT * 2)));
+        dma_data(pg + (data_off + (u32)(half * USB)), lds_v + (u32)(slot * USB), valid_tok);
+    };
+    // ---- phase A on the SERVICE wave, concurrent with the first unit fetch ---------------------------------------------
+    // What the timeline trace (EXP & 32) showed for the one-barrier-after-DMA form: issuing the first-round DMA takes a
+    // wave 2-4 us (the memory pipeline back-pressures the burst), so any phase-A work that sits behind that issue in
+    // program order, and any barrier all waves must reach after it, completes at ~10 us.  Now: seven waves do nothing
+    // but issue their DMA; the last wave (it owns the fewest units) first loads q / k / v / the RoPE coefficients with
+    // ordinary loads - its vmcnt queue is still empty, the compiler's own counted waits are right - rotates, builds the
+    // Q.K^T operand image, raises an LDS flag (~2 us after launch) and only then issues its own unit DMA; the other waves
+    // poll that flag after their issue (no barrier couples the waves to each other) and start on whichever unit has
+    // landed.  The new token's cache write and its own score follow on the service wave after its units, off everybody's
+    // critical path.  (A ninth, unit-less wave was tried first: 576-thread workgroups no longer fit twice on a CU.)
+    const int blk = tl >> 6, slot_new = tl & 63;
+    // Unit ownership.  The service wave starts its units ~2 us after the others (operand build first) and then still has
+    // the new token's cache write and score to do: with its round-robin share it is the last wave to finish.  Whenever
+    // seven waves need no more rounds than eight would - ceil(n / 7) == ceil(n / 8) - it therefore owns NO units, finishes
+    // the new token right after the operand build and waits at the merge; the other seven take the units round-robin.
+    const int nu = max(u_end - u_begin, 0);
     // (kflags & 1, qs_set_attention_variant(3): never - the A/B reference)
-    const bool svc_free = (EXP & 256) ? true : (!(kflags & 1) && (npg + NW - 2) / (NW - 1) == (npg + NW - 1) / NW);
-    const int PS = svc_free ? NW - 1 : NW;                            // page stride of a wave
-    const bool pages_here = !svc_free || wave != SVC;
-    const bool has_page = p_begin + wave < p_end && pages_here;
+    const bool svc_free = !(kflags & 1) && (nu + NW - 2) / (NW - 1) == (nu + NW - 1) / NW;
+    const int PS = svc_free ? NW - 1 : NW;                            // unit stride of a wave
+    const bool units_here = !svc_free || wave != SVC;
+    const int u_first = u_begin + wave;
+    const int cnt = (units_here && wave < nu) ? (nu - wave + PS - 1) / PS : 0;   // units this wave owns
     if (tid == SVC * 64) s_flag = 0;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // start-of-kernel barrier (raw: the service wave's loads stay in flight)
-    // (tried in round 3 and dropped: requesting the K pages of ALL waves before any V page - a raw barrier between the two
-    // halves of the first round - so that the first Q.K^T does not queue behind other waves' V pages: +0.5-1.2 us at
-    // 640-1030 tokens, where the barrier itself is the delay, -0.7-1.3 us from 1535 tokens on; not a net gain over the
-    // benchmark's contexts)
     auto first_round = [&]() {
-        if (has_page) {
+        if (cnt > 0) {
             // page addresses: requested together with the length for split 0 (scalar loads, before any asm statement:
             // behind an asm "memory" clobber the compiler falls back to vector loads for kv_pointers)
-            int64_t kfirst = kpage0, vfirst = vpage0;
+            const int u1 = u_first + PS;
+            int64_t kfirst = kpage0, vfirst = vpage0, ksecond = svc_free ? kpage7 : kpage8, vsecond = svc_free ? vpage7 : vpage8;
             if (!spec) {
-                kfirst = ktab[p_begin + wave];
-                vfirst = vtab[p_begin + wave];
+                kfirst = ktab[u_first >> 1];
+                vfirst = vtab[u_first >> 1];
+                if (cnt > 1) {
+                    ksecond = ktab[u1 >> 1];
+                    vsecond = vtab[u1 >> 1];
+                }
             }
-            const int vt0 = min(PAGE_TOK, tl - (p_begin + wave) * PAGE_TOK);
-            dma_k(kfirst, vt0);
-            dma_v(vfirst, vt0);
+            const int vt0 = min(UT, tl - u_first * UT);
+            dma_a(kfirst, u_first & 1, 0, vt0);
+            dma_b(vfirst, u_first & 1, 0, vt0);
+            if (cnt > 1) {
+                const int vt1 = min(UT, tl - u1 * UT);
+                dma_a(ksecond, u1 & 1, 1, vt1);
+                dma_b(vsecond, u1 & 1, 1, vt1);
+            }
         }
         stamp(2);
     };
-    // the new token's cache write (split 0) and its own score: service wave, after its pages - or, when it owns none,
+    // the new token's cache write (split 0) and its own score: service wave, after its units - or, when it owns none,
     // straight after the operand build
     auto new_token_work = [&]() {
         if (z == 0) {
             uint8_t* pgk = reinterpret_cast<uint8_t*>(ktab[blk]);
             __half* sck = reinterpret_cast<__half*>(pgk + (size_t)num_kv_heads * PAGE_TOK * DHB);
-            wave_quant_store4(s_knew[2 * lane], s_knew[2 * lane + 1], pgk + ((size_t)hkv * PAGE_TOK + slot) * DHB,
-                              sck + hkv * PAGE_TOK + slot, sck + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
+            wave_quant_store4(s_knew[2 * lane], s_knew[2 * lane + 1], pgk + ((size_t)hkv * PAGE_TOK + slot_new) * DHB,
+                              sck + hkv * PAGE_TOK + slot_new, sck + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot_new, lane);
             uint8_t* pgv = reinterpret_cast<uint8_t*>(vtab[blk]);
             __half* scv = reinterpret_cast<__half*>(pgv + (size_t)num_kv_heads * PAGE_TOK * DHB);
-            wave_quant_store4(vnew_pair[0], vnew_pair[1], pgv + ((size_t)hkv * PAGE_TOK + slot) * DHB,
-                              scv + hkv * PAGE_TOK + slot, scv + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot, lane);
+            wave_quant_store4(s_vnew[2 * lane], s_vnew[2 * lane + 1], pgv + ((size_t)hkv * PAGE_TOK + slot_new) * DHB,
+                              scv + hkv * PAGE_TOK + slot_new, scv + num_kv_heads * PAGE_TOK + hkv * PAGE_TOK + slot_new, lane);
         }
 #pragma unroll
         for (int h = 0; h < G; ++h) {
@@ -336,25 +377,23 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         if constexpr (!(EXP & 4)) {
             // ordinary loads: this wave's queue carries nothing else, the compiler's own counted waits are right here
             RopeCS cs;
-            if constexpr (EXP & 128) {                 // timing: no dependent table load (identity rotation: wrong by design)
-                cs.c = 1.f;
-                cs.s = 0.f;
-            } else if (rope_tab && tl < rope_tab_len) {
+            if (rope_tab && tl < rope_tab_len) {
                 const float2 t = rope_tab[(size_t)tl * 64 + lane];   // same double-evaluated, float-rounded values
                 cs.c = t.x;
                 cs.s = t.y;
             } else {
                 cs = rope_coef(lane, tl, rope_base, DH);
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the raw q / k / v rows have landed (this wave's queue holds nothing else)
 #pragma unroll
-            for (int h = 0; h < G; ++h) {
+            for (int h = 0; h < G; ++h) {                      // rotated in place: a lane touches only its own two elements
                 _Float16 a, bb;
-                rope_pair((float)qlo[h], (float)qhi[h], cs, a, bb);
+                rope_pair((float)s_q[h][lane], (float)s_q[h][64 + lane], cs, a, bb);
                 s_q[h][lane] = a;
                 s_q[h][64 + lane] = bb;
             }
             _Float16 ka, kbb;
-            rope_pair((float)klo, (float)khi, cs, ka, kbb);
+            rope_pair((float)s_knew[lane], (float)s_knew[64 + lane], cs, ka, kbb);
             s_knew[lane] = ka;
             s_knew[64 + lane] = kbb;
             // B operand of Q.K^T for lane (head li, kg = tg), MFMA w: dims 32tg + 8w + {0,4,1,5,2,6,3,7}; the positions that
@@ -367,24 +406,16 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
                 *reinterpret_cast<h8*>(&s_qp[li][32 * tg + 8 * w]) =
                     (h8){x[0], x[4], x[1] * s16, x[5] * s16, x[2], x[6], x[3] * s16, x[7] * s16};
             }
-            {   // v is consumed much later (after the code shared with the page waves): pin its load as complete HERE, or
-                // the compiler carries "load pending" into the shared code and drains the page waves' DMA queue there
-                u32 bits = __builtin_bit_cast(u32, vnew_pair);
-                asm volatile("" : "+v"(bits));
-                vnew_pair = __builtin_bit_cast(h2, bits);
-            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) *(volatile __attribute__((address_space(3))) int*)(&s_flag) = 1;
             asm volatile("s_setprio 0");
             stamp(4);
-            if constexpr (!(EXP & 64)) {
-                if (svc_free) new_token_work();
-            }
+            if (svc_free) new_token_work();
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) *(volatile __attribute__((address_space(3))) int*)(&s_flag) = 1;
         }
-        first_round();                     // the service wave's own pages: requested only now (its queue was kept clean)
+        first_round();                     // the service wave's own units: requested only now (its queue was kept clean)
     }
 
     // per-lane constants of head li: qsum = sum_d q_eff_d and Qoff = sum over the operand of 1024 * q' (the offset that
@@ -416,42 +447,52 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     for (int e = 0; e < 8; ++e) acc[e] = (v4f){0.f, 0.f, 0.f, 0.f};
     float m_run = -3.0e38f, l_part = 0.f, corr = 0.f, psum = 0.f;   // psum = sum of P' (removes the V operand offsets)
 
-    for (int p = pages_here ? p_begin + wave : p_end; p < p_end; p += PS) {
-        // K(p) landed?  Outstanding younger VMEM ops at this point: the 5 of V(p).
-        asm volatile("s_waitcnt vmcnt(5) ; QS_LOOP_BEGIN" ::: "memory");
-        stamp(5 + 2 * min(2, (p - p_begin) / PS));
-        const bool more = p + PS < p_end;
-        const int valid = min(PAGE_TOK, tl - p * PAGE_TOK);
-        const bool full = valid == PAGE_TOK;   // wave-uniform: only the last page needs masking
-        int64_t kpage_next = 0, vpage_next = 0;
-        if (more) next_pages(p + PS, kpage_next, vpage_next);
-        if constexpr (EXP & 2) {               // timing experiment: memory side only
-            if (more) dma_k(kpage_next, min(PAGE_TOK, tl - (p + PS) * PAGE_TOK));
-            if (more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (more) dma_v(vpage_next, min(PAGE_TOK, tl - (p + PS) * PAGE_TOK));
-            continue;
-        }
-
-        // one opaque per-lane base per buffer: every operand read below is base + immediate (without this the compiler
-        // hoists a dozen loop-invariant address registers out of the loop and spills them)
-        // (the lane id itself is re-derived here with v_mbcnt so that no per-lane address survives across iterations:
-        // with 128 VGPRs the allocator otherwise spills one and reloads it - a scratch load whose vmcnt(0) wait would
-        // also drain the LDS-DMA queue)
-        u32 lid;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
-        const int li_ = lid & 15, tg_ = lid >> 4;
-        const lds_u8 kl = (lds_u8)s_kw + (li_ * DHB + 16 * tg_);
-        const lds_u8 vl = (lds_u8)s_vw + ((4 * tg_) * DHB + 4 * li_);
-        const lds_u8 ml = (lds_u8)(&s_meta[wave][0][0]) + 8 * tg_;
-        const lds_u8 ql = (lds_u8)(&s_qp[0][0]) + (li_ * (DH * 2) + 64 * tg_);
-        // ---------------- Q.K^T : 4 tiles of 16 tokens ----------------
-        v4f craw[4];   // craw[t][r] = raw dot (offsets already cancelled) of token 16t + 4tg + r with head li
-        h8 qB[4];
+    // Lane-constant LDS addresses and the Q.K^T B operand stay in registers across the unit loop (the unit form of the
+    // loop needs ~30 registers fewer than the page form did, so nothing spills: tests/test_kernel_contracts.py)
+    constexpr int NS = GP == 4 ? 2 : 4;     // scores per lane in the compacted softmax
+    // this lane's tokens there: 16 t + 4 tg + r0 + {0 .. NS-1}
+    //   GP = 4: lane li = h + 4 (2 t + rp): r0 = 2 rp;   GP = 8: lane li = h + 8 t: r0 = 0
+    const int tok0 = 16 * (li >> 3) + 4 * tg + (GP == 4 ? 2 * ((li >> 2) & 1) : 0);
+    u32 kl0 = (u32)(uintptr_t)(lptr_t)s_kw + (u32)(li * DHB + 16 * tg);
+    u32 vl0 = (u32)(uintptr_t)(lptr_t)s_vw + (u32)((4 * tg) * DHB + 4 * li);
+    u32 ml0 = (u32)(uintptr_t)(lptr_t)(&s_meta[wave][0][0][0]) + (u32)(2 * tok0);
+    asm volatile("" : "+v"(kl0), "+v"(vl0), "+v"(ml0));   // opaque: one register each, every access below is base + immediate
+    h8 qB[4];
+    {
+        const lds_u8 ql = (lds_u8)(&s_qp[0][0]) + (li * (DH * 2) + 64 * tg);
 #pragma unroll
         for (int w = 0; w < 4; ++w) qB[w] = *(const __attribute__((address_space(3))) h8*)(ql + 16 * w);
+    }
+
+    int it = 0;          // units this wave has consumed: ring slot = it & 1
+    int rem = cnt - 1;   // units this wave still owns after the current one
+    for (int u = cnt > 0 ? u_first : u_end; u < u_end; u += PS, ++it, --rem) {
+        const bool has2 = rem >= 2;   // (has1 = rem >= 1)
+        // A(u) landed?  Younger VMEM operations of this wave at this point: B(u) (3) and, if it exists, unit u + PS (6).
+        // (the wave-uniform choice between the two counted waits is a scalar branch inside the statement)
+        asm volatile("; QS_LOOP_BEGIN\n\ts_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(9)\n\ts_branch 2f\n1:\n\ts_waitcnt vmcnt(3)\n2:"
+                     ::"s"(rem) : "memory", "scc");
+        stamp(5 + 2 * min(2, it));
+        const int slot = it & 1;
+        const int valid = min(UT, tl - u * UT);
+        const bool full = valid == UT;   // wave-uniform: only the last unit needs masking
+        const int u2 = u + 2 * PS, valid2 = min(UT, tl - u2 * UT);
+        int64_t kpage_next = 0, vpage_next = 0;
+        if (has2) next_pages(u2 >> 1, kpage_next, vpage_next);
+        if constexpr (EXP & 2) {               // timing experiment: memory side only
+            if (has2) dma_a(kpage_next, u2 & 1, slot, valid2);
+            asm volatile("s_cmp_lt_u32 %0, 2\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(9)\n\ts_branch 3f\n1:\n\ts_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 2f\n\t"
+                         "s_waitcnt vmcnt(6)\n\ts_branch 3f\n2:\n\ts_waitcnt vmcnt(0)\n3:" ::"s"(rem) : "memory", "scc");
+            if (has2) dma_b(vpage_next, u2 & 1, slot, valid2);
+            continue;
+        }
+        const lds_u8 kl = (lds_u8)(kl0 + (u32)(slot * USB));
+        const lds_u8 vl = (lds_u8)(vl0 + (u32)(slot * USB));
+        const lds_u8 ml = (lds_u8)(ml0 + (u32)(slot * (4 * UT * 2)));
+        // ---------------- Q.K^T : 2 tiles of 16 tokens ----------------
+        v4f craw[2];   // craw[t][r] = raw dot (offsets already cancelled) of token 16t + 4tg + r with head li
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < 2; ++t) {
             const v4u raw = *(const __attribute__((address_space(3))) v4u*)(kl + 16 * t * DHB);
             v4f c = {nqoff, nqoff, nqoff, nqoff};   // start at -Qoff: the operand offsets cancel inside the MFMA chain
 #pragma unroll
@@ -463,104 +504,65 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
             }
             craw[t] = c;
         }
-        u32 pbv[2][4];   // P'^T operands (B of P.V) of the two half pages
+        // Only the columns li < G of the 16x16 results are real heads.  Instead of running the softmax on 8 values per
+        // lane with 3/4 (1/2) of the lanes idle, the values move to the idle lanes of their 16-lane row (DPP row_shr
+        // with bank masks): every lane then owns NS scores of head h = li % GP.
+        float sc[NS];
         float m_new;
-        float scc[4];    // COMPACT: this lane's 4 scores
-        float sc8[8];    // GP == 8: two lane groups, 8 scores per lane
-        if constexpr (COMPACT) {
-            // Only the columns li < G of the 16x16 results are real heads.  Instead of running the softmax on 16
-            // values per lane with 3/4 of the lanes idle, tile t' moves to the lanes li = G t' + h (DPP row_shr inside
-            // the 16-lane row): every lane li < 4G then owns 4 scores of head h = li % G, tokens 16t' + 4tg + r.
-            const int tq_raw = li_ / GP;                   // tile owned by this lane; lanes li >= 4G stay idle (G < 4)
-            const bool lane_ok = GP == 4 || tq_raw < 4;
-            const int tq = GP == 4 ? tq_raw : min(tq_raw, 3);
-            float (&sc)[4] = scc;
-            const h4 ks = *(const __attribute__((address_space(3))) h4*)(ml + 32 * tq);
-            const h4 kz = *(const __attribute__((address_space(3))) h4*)(ml + 2 * PAGE_TOK + 32 * tq);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // (scalar copies first: __builtin_bit_cast of a vector-element lvalue reads element 0)
-                const float c0 = craw[0][r], c1 = craw[1][r], c2 = craw[2][r], c3 = craw[3][r];
-                int x = __builtin_bit_cast(int, c0);
-                if constexpr (GP == 4) {   // whole 4-lane banks move: bank-masked DPP writes
-                    x = __builtin_amdgcn_update_dpp(x, __builtin_bit_cast(int, c1), 0x114, 0xF, 0x2, false);
-                    x = __builtin_amdgcn_update_dpp(x, __builtin_bit_cast(int, c2), 0x118, 0xF, 0x4, false);
-                    x = __builtin_amdgcn_update_dpp(x, __builtin_bit_cast(int, c3), 0x11C, 0xF, 0x8, false);
-                } else {
-                    const int s1 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c1), 0x110 + GP, 0xF, 0xF, true);
-                    const int s2 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c2), 0x110 + 2 * GP, 0xF, 0xF, true);
-                    const int s3 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c3), 0x110 + 3 * GP, 0xF, 0xF, true);
-                    x = tq_raw == 1 ? s1 : x;
-                    x = tq_raw == 2 ? s2 : x;
-                    x = tq_raw == 3 ? s3 : x;
-                }
-                sc[r] = ((float)ks[r] * qk_scale) * (__builtin_bit_cast(float, x) - (float)kz[r] * qsum);
-                if (!lane_ok) sc[r] = -3.0e38f;
-            }
-            if (!full) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (16 * tq + 4 * tg_ + r >= valid) sc[r] = -3.0e38f;   // also discards NaN from garbage scales
-            }
-            // K buffer consumed -> request K(p+NW)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (more) dma_k(kpage_next, min(PAGE_TOK, tl - (p + PS) * PAGE_TOK));
-            float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        {
+            float ksf[NS], kzf[NS];
             if constexpr (GP == 4) {
-                mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx),
-                                                                                     0x124, 0xF, 0xF, true)));   // row_ror:4
-                mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx),
-                                                                                     0x128, 0xF, 0xF, true)));   // row_ror:8
+                const h2 ks = *(const __attribute__((address_space(3))) h2*)(ml);
+                const h2 kz = *(const __attribute__((address_space(3))) h2*)(ml + UT * 2);
+                ksf[0] = (float)ks[0], ksf[1] = (float)ks[1], kzf[0] = (float)kz[0], kzf[1] = (float)kz[1];
             } else {
-                mx = fmaxf(mx, xor_lane(mx, lid, GP));
-                mx = fmaxf(mx, xor_lane(mx, lid, 2 * GP));
-            }
-            mx = fmaxf(mx, xor_lane(mx, lid, 16));
-            mx = fmaxf(mx, xor_lane(mx, lid, 32));
-            m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            if (__any(alpha != 1.0f)) {
-                l_part *= alpha;
-                corr *= alpha;
-                psum *= alpha;
+                const h4 ks = *(const __attribute__((address_space(3))) h4*)(ml);
+                const h4 kz = *(const __attribute__((address_space(3))) h4*)(ml + UT * 2);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] *= alpha;
+                for (int j = 0; j < 4; ++j) ksf[j] = (float)ks[j], kzf[j] = (float)kz[j];
             }
-        } else {   // GP == 8
-            // two lane groups: li < 8 keeps tiles 0 and 2 of head li, li >= 8 takes tiles 1 and 3 of head li - 8 (row_shr:8
-            // into the upper two 4-lane banks): 8 scores per lane, every lane busy
-            const int tq2 = li_ >> 3;
-            const h4 ksa = *(const __attribute__((address_space(3))) h4*)(ml + 32 * tq2);
-            const h4 kza = *(const __attribute__((address_space(3))) h4*)(ml + 2 * PAGE_TOK + 32 * tq2);
-            const h4 ksb = *(const __attribute__((address_space(3))) h4*)(ml + 32 * (2 + tq2));
-            const h4 kzb = *(const __attribute__((address_space(3))) h4*)(ml + 2 * PAGE_TOK + 32 * (2 + tq2));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float c0 = craw[0][r], c1 = craw[1][r], c2 = craw[2][r], c3 = craw[3][r];
-                const int xa = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, c0), __builtin_bit_cast(int, c1), 0x118,
-                                                           0xF, 0xC, false);
-                const int xb = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, c2), __builtin_bit_cast(int, c3), 0x118,
-                                                           0xF, 0xC, false);
-                sc8[r] = ((float)ksa[r] * qk_scale) * (__builtin_bit_cast(float, xa) - (float)kza[r] * qsum);
-                sc8[4 + r] = ((float)ksb[r] * qk_scale) * (__builtin_bit_cast(float, xb) - (float)kzb[r] * qsum);
+            for (int j = 0; j < NS; ++j) {
+                // (scalar copies first: __builtin_bit_cast of a vector-element lvalue reads element 0)
+                int x;
+                if constexpr (GP == 4) {   // whole 4-lane banks move: bank-masked DPP writes
+                    const float c00 = craw[0][j], c02 = craw[0][2 + j], c10 = craw[1][j], c12 = craw[1][2 + j];
+                    x = __builtin_bit_cast(int, c00);
+                    x = __builtin_amdgcn_update_dpp(x, __builtin_bit_cast(int, c02), 0x114, 0xF, 0x2, false);   // row_shr:4 -> bank 1
+                    x = __builtin_amdgcn_update_dpp(x, __builtin_bit_cast(int, c10), 0x118, 0xF, 0x4, false);   // row_shr:8 -> bank 2
+                    x = __builtin_amdgcn_update_dpp(x, __builtin_bit_cast(int, c12), 0x11C, 0xF, 0x8, false);   // row_shr:12 -> bank 3
+                } else {
+                    const float c0 = craw[0][j], c1 = craw[1][j];
+                    x = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, c0), __builtin_bit_cast(int, c1), 0x118, 0xF, 0xC, false);
+                }
+                sc[j] = (ksf[j] * qk_scale) * (__builtin_bit_cast(float, x) - kzf[j] * qsum);
             }
             if (!full) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (16 * tq2 + 4 * tg_ + r >= valid) sc8[r] = -3.0e38f;
-                    if (16 * (2 + tq2) + 4 * tg_ + r >= valid) sc8[4 + r] = -3.0e38f;
-                }
+                for (int j = 0; j < NS; ++j)
+                    if (tok0 + j >= valid) sc[j] = -3.0e38f;   // also discards NaN from garbage scales
             }
-            // K buffer consumed -> request K(p+NW)
+            // K slot consumed -> request A(u + 2 PS) into it
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (more) dma_k(kpage_next, min(PAGE_TOK, tl - (p + PS) * PAGE_TOK));
-            float mx = sc8[0];
+            if (has2) dma_a(kpage_next, u2 & 1, slot, valid2);
+            // maximum over the unit's 32 tokens of head h: own scores, the lanes li +- 4 / 8 of the row (GP = 4; li +- 8 for
+            // GP = 8) as DPP source operands of the max itself, the other three rows by lane-permute swaps - no LDS round trip
+            // (s_nop 1: two wait states between a VALU write and its use as a DPP source)
+            float mx = sc[0];
 #pragma unroll
-            for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc8[j]);
-            mx = fmaxf(mx, xor_lane(mx, lid, 8));
-            mx = fmaxf(mx, xor_lane(mx, lid, 16));
-            mx = fmaxf(mx, xor_lane(mx, lid, 32));
+            for (int j = 1; j < NS; ++j) mx = fmaxf(mx, sc[j]);
+            if constexpr (GP == 4) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(mx));
+            asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(mx));
+            {
+                const int xi = __builtin_bit_cast(int, mx);
+                const auto r = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+                mx = fmaxf(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
+            }
+            {
+                const int xi = __builtin_bit_cast(int, mx);
+                const auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+                mx = fmaxf(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
+            }
             m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
@@ -572,58 +574,31 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
                 for (int e = 0; e < 8; ++e) acc[e] *= alpha;
             }
         }
-        if (more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // V(p) landed (K(p+NW) may still be in flight)
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (COMPACT) {
-            const int tq_raw = li_ / GP;
-            const bool lane_ok = GP == 4 || tq_raw < 4;
-            const int tq = GP == 4 ? tq_raw : min(tq_raw, 3);
-            float (&sc)[4] = scc;
-            const h4 vs = *(const __attribute__((address_space(3))) h4*)(ml + 4 * PAGE_TOK + 32 * tq);
-            const h4 vz = *(const __attribute__((address_space(3))) h4*)(ml + 6 * PAGE_TOK + 32 * tq);
-            float pp[4];
+        // B(u) landed?  Younger: unit u + PS (6, if it exists) and A(u + 2 PS) (3, if it exists)
+        asm volatile("s_cmp_lt_u32 %0, 2\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(9)\n\ts_branch 3f\n1:\n\ts_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 2f\n\t"
+                     "s_waitcnt vmcnt(6)\n\ts_branch 3f\n2:\n\ts_waitcnt vmcnt(0)\n3:" ::"s"(rem) : "memory", "scc");
+        u32 pbv[4];   // P'^T operand (B of P.V) of the unit
+        {
+            float vsf[NS], vzf[NS];
+            if constexpr (GP == 4) {
+                const h2 vs = *(const __attribute__((address_space(3))) h2*)(ml + 2 * UT * 2);
+                const h2 vz = *(const __attribute__((address_space(3))) h2*)(ml + 3 * UT * 2);
+                vsf[0] = (float)vs[0], vsf[1] = (float)vs[1], vzf[0] = (float)vz[0], vzf[1] = (float)vz[1];
+            } else {
+                const h4 vs = *(const __attribute__((address_space(3))) h4*)(ml + 2 * UT * 2);
+                const h4 vz = *(const __attribute__((address_space(3))) h4*)(ml + 3 * UT * 2);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pe = __builtin_amdgcn_exp2f(sc[r] - m_new);   // 0 for masked tokens
+                for (int j = 0; j < 4; ++j) vsf[j] = (float)vs[j], vzf[j] = (float)vz[j];
+            }
+            float pp[NS];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const float pe = __builtin_amdgcn_exp2f(sc[j] - m_new);   // 0 for masked tokens
                 l_part += pe;
                 // P' = p * v-scale rounded to fp16 for the MFMA; the zero-point term uses the SAME rounded value
-                float ps = (float)(_Float16)(pe * (float)vs[r]);
-                float pz = ps * (float)vz[r];
-                if ((!full && 16 * tq + 4 * tg_ + r >= valid) || !lane_ok) {   // garbage (possibly NaN) scales of unused slots
-                    ps = 0.f;
-                    pz = 0.f;
-                }
-                corr += pz;
-                psum += ps;
-                pp[r] = ps;
-            }
-            const int pk0 = (int)pack_h2(pp[0], pp[1]), pk1 = (int)pack_h2(pp[2], pp[3]);
-            // B operand of P.V for lane (head li < G, kg = tg): tokens 16t + 4tg + r of tiles t = 2hp, 2hp + 1 - they sit
-            // in the lanes li + G t of the same row (row_shl; lanes >= 4 receive other heads' values or zeros: their
-            // output columns are never read)
-            pbv[0][0] = (u32)pk0;
-            pbv[0][1] = (u32)pk1;
-            pbv[0][2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + GP, 0xF, 0xF, true);
-            pbv[0][3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + GP, 0xF, 0xF, true);
-            pbv[1][0] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + 2 * GP, 0xF, 0xF, true);
-            pbv[1][1] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 2 * GP, 0xF, 0xF, true);
-            pbv[1][2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x100 + 3 * GP, 0xF, 0xF, true);
-            pbv[1][3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x100 + 3 * GP, 0xF, 0xF, true);
-        } else {   // GP == 8
-            const int tq2 = li_ >> 3;
-            const h4 vsa = *(const __attribute__((address_space(3))) h4*)(ml + 4 * PAGE_TOK + 32 * tq2);
-            const h4 vza = *(const __attribute__((address_space(3))) h4*)(ml + 6 * PAGE_TOK + 32 * tq2);
-            const h4 vsb = *(const __attribute__((address_space(3))) h4*)(ml + 4 * PAGE_TOK + 32 * (2 + tq2));
-            const h4 vzb = *(const __attribute__((address_space(3))) h4*)(ml + 6 * PAGE_TOK + 32 * (2 + tq2));
-            float pp[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int r = j & 3, t = j < 4 ? tq2 : 2 + tq2;
-                const float pe = __builtin_amdgcn_exp2f(sc8[j] - m_new);   // 0 for masked tokens
-                l_part += pe;
-                float ps = (float)(_Float16)(pe * (float)(j < 4 ? vsa[r] : vsb[r]));
-                float pz = ps * (float)(j < 4 ? vza[r] : vzb[r]);
-                if (!full && 16 * t + 4 * tg_ + r >= valid) {                  // garbage (possibly NaN) scales of unused slots
+                float ps = (float)(_Float16)(pe * vsf[j]);
+                float pz = ps * vzf[j];
+                if (!full && tok0 + j >= valid) {   // garbage (possibly NaN) scales of unused slots
                     ps = 0.f;
                     pz = 0.f;
                 }
@@ -631,32 +606,34 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
                 psum += ps;
                 pp[j] = ps;
             }
-            const int pka0 = (int)pack_h2(pp[0], pp[1]), pka1 = (int)pack_h2(pp[2], pp[3]);
-            const int pkb0 = (int)pack_h2(pp[4], pp[5]), pkb1 = (int)pack_h2(pp[6], pp[7]);
-            // B operand for lane (head li < 8, kg = tg): tiles 0 / 2 are its own, tiles 1 / 3 sit in lane li + 8
-            pbv[0][0] = (u32)pka0;
-            pbv[0][1] = (u32)pka1;
-            pbv[0][2] = (u32)__builtin_amdgcn_update_dpp(0, pka0, 0x108, 0xF, 0xF, true);
-            pbv[0][3] = (u32)__builtin_amdgcn_update_dpp(0, pka1, 0x108, 0xF, 0xF, true);
-            pbv[1][0] = (u32)pkb0;
-            pbv[1][1] = (u32)pkb1;
-            pbv[1][2] = (u32)__builtin_amdgcn_update_dpp(0, pkb0, 0x108, 0xF, 0xF, true);
-            pbv[1][3] = (u32)__builtin_amdgcn_update_dpp(0, pkb1, 0x108, 0xF, 0xF, true);
+            // B operand of P.V for lane (head li < G, kg = tg): k index 8 tg + e <-> token 16 (e >> 2) + 4 tg + (e & 3); the
+            // values sit in the lanes li + 4 d (GP = 4: dword d = e >> 1) resp. li, li + 8 (GP = 8) of the same row
+            // (row_shl; lanes >= GP receive other heads' values or zeros: their output columns are never read)
+            if constexpr (GP == 4) {
+                const int pk = (int)pack_h2(pp[0], pp[1]);
+                pbv[0] = (u32)pk;
+                pbv[1] = (u32)__builtin_amdgcn_update_dpp(0, pk, 0x104, 0xF, 0xF, true);
+                pbv[2] = (u32)__builtin_amdgcn_update_dpp(0, pk, 0x108, 0xF, 0xF, true);
+                pbv[3] = (u32)__builtin_amdgcn_update_dpp(0, pk, 0x10C, 0xF, 0xF, true);
+            } else {
+                const int pk0 = (int)pack_h2(pp[0], pp[1]), pk1 = (int)pack_h2(pp[2], pp[3]);
+                pbv[0] = (u32)pk0;
+                pbv[1] = (u32)pk1;
+                pbv[2] = (u32)__builtin_amdgcn_update_dpp(0, pk0, 0x108, 0xF, 0xF, true);
+                pbv[3] = (u32)__builtin_amdgcn_update_dpp(0, pk1, 0x108, 0xF, 0xF, true);
+            }
         }
-        // ---------------- P.V : two half pages of 32 tokens ----------------
-#pragma unroll
-        for (int hp = 0; hp < 2; ++hp) {
-            const h8 pB = __builtin_bit_cast(h8, (v4u){pbv[hp][0], pbv[hp][1], pbv[hp][2], pbv[hp][3]});
+        // ---------------- P.V : the unit's 32 tokens ----------------
+        {
+            const h8 pB = __builtin_bit_cast(h8, (v4u){pbv[0], pbv[1], pbv[2], pbv[3]});
             u32 raw[8];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                raw[jj] = *(const __attribute__((address_space(3))) u32*)(vl + (16 * (2 * hp + (jj >> 2)) + (jj & 3)) * DHB);
+                raw[jj] = *(const __attribute__((address_space(3))) u32*)(vl + (16 * (jj >> 2) + (jj & 3)) * DHB);
             }
-
-            // V operands stay in offset form (1024 + n for low nibbles, 1024 + 16 n for high ones, fed with P'/16): the
-            // offsets add 1024 * sum(P') resp. 64 * sum(P') to the accumulators, removed once at the end (psum)
-            const _Float16 s16 = (_Float16)0.0625f;
-            const h8 pB16 = pB * (h8){s16, s16, s16, s16, s16, s16, s16, s16};
+            // V operands stay in offset form (1024 + n for the low nibbles, 1024 + 16 n for the high ones): the offsets add
+            // 1024 * sum(P') to every accumulator and the high-nibble dims come out 16 x too large - both removed once at
+            // the end (psum; exact: powers of two)
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) {
                 u32 lo[4], hi[4];
@@ -669,31 +646,27 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
                 const h8 a_lo = __builtin_bit_cast(h8, (v4u){lo[0], lo[1], lo[2], lo[3]});
                 const h8 a_hi = __builtin_bit_cast(h8, (v4u){hi[0], hi[1], hi[2], hi[3]});
                 acc[2 * bb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, pB, acc[2 * bb], 0, 0, 0);
-                acc[2 * bb + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, pB16, acc[2 * bb + 1], 0, 0, 0);
+                acc[2 * bb + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, pB, acc[2 * bb + 1], 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0) ; QS_LOOP_END" ::: "memory");
-        stamp(6 + 2 * min(2, (p - p_begin) / PS));
-        if (more) dma_v(vpage_next, min(PAGE_TOK, tl - (p + PS) * PAGE_TOK));
+        stamp(6 + 2 * min(2, it));
+        if (has2) dma_b(vpage_next, u2 & 1, slot, valid2);
     }
 
     // ---- per-wave partials -> LDS.  Lane (head li, tg) holds out dims 8*(4tg + r) + e in acc[e][r] ---------------
     // (lane-derived values are re-derived here so that none of them has to survive the page loop in a register)
     const u32 lid2 = fresh_lane_id();
     const int li2 = lid2 & 15, tg2 = lid2 >> 4, tid2 = wave * 64 + (int)lid2;
-    if constexpr (GP == 8) {   // two lane groups per head
-        l_part += xor_lane(l_part, lid2, 8);
-        corr += xor_lane(corr, lid2, 8);
-        psum += xor_lane(psum, lid2, 8);
+    // the head's tokens were spread over the lanes li = h + GP j of the row as well
+    if constexpr (GP == 4) {
+        l_part += xor_lane(l_part, lid2, 4);
+        corr += xor_lane(corr, lid2, 4);
+        psum += xor_lane(psum, lid2, 4);
     }
-    if constexpr (COMPACT) {   // the head's tokens were spread over the lanes li = G t' + h as well
-        l_part += xor_lane(l_part, lid2, GP);
-        l_part += xor_lane(l_part, lid2, 2 * GP);
-        corr += xor_lane(corr, lid2, GP);
-        corr += xor_lane(corr, lid2, 2 * GP);
-        psum += xor_lane(psum, lid2, GP);
-        psum += xor_lane(psum, lid2, 2 * GP);
-    }
+    l_part += xor_lane(l_part, lid2, 8);
+    corr += xor_lane(corr, lid2, 8);
+    psum += xor_lane(psum, lid2, 8);
     l_part += xor_lane(l_part, lid2, 16);
     l_part += xor_lane(l_part, lid2, 32);
     corr += xor_lane(corr, lid2, 16);
@@ -703,7 +676,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     // ---- service wave, off every critical path: the new token's cache write (split 0) and its own score -------------------
     // (placed here, after the code the page waves share with it: pending stores of the service wave at a control-flow
     // merge in front of the page loop would make the compiler put a vmcnt(0) there - which drains the page waves' DMA)
-    if constexpr (!(EXP & 4) && !(EXP & 64)) {   // (EXP & 64: timing, the new token's cache write and own score skipped)
+    if constexpr (!(EXP & 4)) {
         if (wave == SVC && !svc_free) new_token_work();
     }
     // every LDS-DMA of this wave has landed (a wave without pages never waited for its first-round fetch, and the merge
@@ -720,7 +693,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         for (int e = 0; e < 8; ++e)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                s_o[wave][li2][8 * (4 * tg2 + r) + e] = acc[e][r] - (corr + ((e & 1) ? 64.f : 1024.f) * psum);
+                s_o[wave][li2][8 * (4 * tg2 + r) + e] = ((e & 1) ? acc[e][r] * 0.0625f : acc[e][r]) - (corr + ((e & 1) ? 64.f : 1024.f) * psum);
         if (tg2 == 0) {
             s_m[wave][li2] = m_run;
             s_l[wave][li2] = l_part;
@@ -1054,15 +1027,7 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
             QS_LAUNCH_EXP(2);
             QS_LAUNCH_EXP(4);
             QS_LAUNCH_EXP(6);
-            QS_LAUNCH_EXP(8);
-            QS_LAUNCH_EXP(9);
             QS_LAUNCH_EXP(32);
-            QS_LAUNCH_EXP(64);
-            QS_LAUNCH_EXP(128);
-            QS_LAUNCH_EXP(192);
-            QS_LAUNCH_EXP(256);
-            QS_LAUNCH_EXP(320);
-            QS_LAUNCH_EXP(448);
             default: break;
         }
     }
