@@ -138,14 +138,19 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hkv = blockIdx.x, b = blockIdx.y;
-    // EXP & 32: timeline trace (s_memtime stamps of lane 0 of every wave into the split workspace; timing tool only)
+    // EXP & 32: timeline trace (timing tool only): s_memtime stamps of every wave, collected in LDS - a global store per stamp
+    // would queue behind the CU's LDS-DMA burst and stall the wave, i.e. perturb exactly what is being measured - and copied
+    // to the split workspace when the kernel ends
+    __shared__ unsigned long long s_stamps[(EXP & 32) ? NWT * 16 : 1];
     auto stamp = [&](int i) {
         if constexpr (EXP & 32) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
-            if (lane == 0)
-                reinterpret_cast<unsigned long long*>(ws)[(((size_t)b * gridDim.x + hkv) * NWT + wave) * 16 + i] = t;
+            if (lane == 0) s_stamps[wave * 16 + i] = t;
         }
     };
+    if constexpr (EXP & 32) {
+        if (lane < 16) s_stamps[wave * 16 + lane] = 0;
+    }
     stamp(0);
     // the rows of the new token (wave-uniform addresses: scalar bases of the service wave's entry requests below)
     const _Float16* qb = q + (size_t)b * q_stride0 + (size_t)hkv * G * DH;
@@ -160,13 +165,12 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     const int64_t* vtab = ktab + max_blocks;
     // The page addresses of a wave's first two units are requested together with the length (they do not depend on it
     // when this workgroup starts at unit 0): one memory round trip less on the launch -> first bytes chain.  The wave's
-    // first unit is unit `wave` (page wave / 2); its second one is unit wave + 7 or wave + 8 - which of the two is known
-    // only with the length (page-ownership rule below), so both candidates are fetched.
-    // (the service wave's speculative addresses are simply not used when it turns out to own no units, see svc_free)
+    // first unit is unit `wave` (page wave / 2), its second one unit wave + 7 when seven waves share the units (the usual
+    // case, see the ownership rule below; with eight the address is fetched when the length is known).
     const bool spec = (nsplit == 1 || blockIdx.z == 0);
-    int64_t kpage0 = 0, vpage0 = 0, kpage7 = 0, vpage7 = 0, kpage8 = 0, vpage8 = 0;
+    int64_t kpage0 = 0, vpage0 = 0, kpage7 = 0, vpage7 = 0;
     if (spec) {
-        const int p0 = wave >> 1, p7 = (wave + NW - 1) >> 1, p8 = (wave + NW) >> 1;
+        const int p0 = wave >> 1, p7 = (wave + NW - 1) >> 1;
         if (p0 < max_blocks) {
             kpage0 = ktab[p0];
             vpage0 = vtab[p0];
@@ -174,10 +178,6 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         if (p7 < max_blocks) {
             kpage7 = ktab[p7];
             vpage7 = vtab[p7];
-        }
-        if (p8 < max_blocks) {
-            kpage8 = ktab[p8];
-            vpage8 = vtab[p8];
         }
     }
     // (the length and the first-round page addresses are requested FIRST, as scalar loads: anything the compiler cannot
@@ -314,39 +314,49 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     // the new token's cache write and score to do: with its round-robin share it is the last wave to finish.  Whenever
     // seven waves need no more rounds than eight would - ceil(n / 7) == ceil(n / 8) - it therefore owns NO units, finishes
     // the new token right after the operand build and waits at the merge; the other seven take the units round-robin.
+    // (round 4 also tried a graded form - the service wave takes the last 0-7 units of the range, chosen by a time model read
+    // off the timeline trace so that all eight waves finish together: 0.1-0.5 us SLOWER at 1 030-2 000 tokens, 1.2 us at 640:
+    // units requested that late arrive behind everything else.  Dropped; HISTORY.md.)
     const int nu = max(u_end - u_begin, 0);
-    // (kflags & 1, qs_set_attention_variant(3): never - the A/B reference)
-    const bool svc_free = !(kflags & 1) && (nu + NW - 2) / (NW - 1) == (nu + NW - 1) / NW;
+    const bool svc_free = (nu + NW - 2) / (NW - 1) == (nu + NW - 1) / NW;
     const int PS = svc_free ? NW - 1 : NW;                            // unit stride of a wave
-    const bool units_here = !svc_free || wave != SVC;
     const int u_first = u_begin + wave;
-    const int cnt = (units_here && wave < nu) ? (nu - wave + PS - 1) / PS : 0;   // units this wave owns
-    if (tid == SVC * 64) s_flag = 0;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // start-of-kernel barrier (raw: the service wave's loads stay in flight)
-    auto first_round = [&]() {
+    const int cnt = ((!svc_free || wave != SVC) && wave < nu) ? (nu - wave + PS - 1) / PS : 0;   // units this wave owns
+    // speculative page addresses fit: the first unit always, the second one for the seven-wave round-robin
+    const bool spec2 = spec && PS == NW - 1;
+    // Hand-over of the operands from the service wave to the unit waves: an LDS flag the unit waves poll after issuing their
+    // first requests (reset behind a start-of-kernel barrier).  Round 4 measured the alternative - ONE raw s_barrier that the
+    // unit waves enter after their first requests and the service wave when the operands are in LDS, no reset barrier, no
+    // polling - at +-0.2 us of this form over 300 ... 2 000 tokens (kflags & 2, qs_set_attention_variant(5)): not adopted.
+    const bool use_flag = !(kflags & 2);
+    if (use_flag) {
+        if (tid == SVC * 64) s_flag = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    // first request of a wave: its unit 0 (4.25 KiB), then - see the call sites for WHEN - its unit 1
+    auto first_round = [&](int which) {       // which: 1 = unit 0 only, 2 = unit 1 only, 3 = both
         if (cnt > 0) {
             // page addresses: requested together with the length for split 0 (scalar loads, before any asm statement:
             // behind an asm "memory" clobber the compiler falls back to vector loads for kv_pointers)
             const int u1 = u_first + PS;
-            int64_t kfirst = kpage0, vfirst = vpage0, ksecond = svc_free ? kpage7 : kpage8, vsecond = svc_free ? vpage7 : vpage8;
-            if (!spec) {
-                kfirst = ktab[u_first >> 1];
-                vfirst = vtab[u_first >> 1];
-                if (cnt > 1) {
-                    ksecond = ktab[u1 >> 1];
-                    vsecond = vtab[u1 >> 1];
-                }
+            int64_t kfirst = kpage0, vfirst = vpage0, ksecond = kpage7, vsecond = vpage7;
+            // (everything else by the asm scalar loads - compiler-visible loads here would be vector loads whose pending state
+            //  reaches the shared code on some path and is drained there with vmcnt(0))
+            if ((which & 1) && !spec) next_pages(u_first >> 1, kfirst, vfirst);
+            if ((which & 2) && cnt > 1 && !spec2) next_pages(u1 >> 1, ksecond, vsecond);
+            if (which & 1) {
+                const int vt0 = min(UT, tl - u_first * UT);
+                dma_a(kfirst, u_first & 1, 0, vt0);
+                stamp(3);
+                dma_b(vfirst, u_first & 1, 0, vt0);
             }
-            const int vt0 = min(UT, tl - u_first * UT);
-            dma_a(kfirst, u_first & 1, 0, vt0);
-            dma_b(vfirst, u_first & 1, 0, vt0);
-            if (cnt > 1) {
+            if ((which & 2) && cnt > 1) {
                 const int vt1 = min(UT, tl - u1 * UT);
                 dma_a(ksecond, u1 & 1, 1, vt1);
                 dma_b(vsecond, u1 & 1, 1, vt1);
             }
         }
-        stamp(2);
+        if (which & 2) stamp(2);
     };
     // the new token's cache write (split 0) and its own score: service wave, after its units - or, when it owns none,
     // straight after the operand build
@@ -369,9 +379,16 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         }
     };
     if (wave != SVC) {
-        first_round();
-        while (*(volatile __attribute__((address_space(3))) int*)(&s_flag) == 0) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
+        // (round 4: requesting the wave's second unit later - when group A of the first has landed, after the operand flag,
+        //  after a fixed 2k / 4k cycles - measured: no gain at 640 ... 2 000 tokens; the first data of a wave is not earlier
+        //  for a smaller first burst.  HISTORY.md.)
+        first_round(3);
+        if (use_flag) {
+            while (*(volatile __attribute__((address_space(3))) int*)(&s_flag) == 0) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         stamp(4);
     } else {
         if constexpr (!(EXP & 4)) {
@@ -406,22 +423,30 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
                 *reinterpret_cast<h8*>(&s_qp[li][32 * tg + 8 * w]) =
                     (h8){x[0], x[4], x[1] * s16, x[5] * s16, x[2], x[6], x[3] * s16, x[7] * s16};
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) *(volatile __attribute__((address_space(3))) int*)(&s_flag) = 1;
+            if (use_flag) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) *(volatile __attribute__((address_space(3))) int*)(&s_flag) = 1;
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
             asm volatile("s_setprio 0");
             stamp(4);
             if (svc_free) new_token_work();
         } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) *(volatile __attribute__((address_space(3))) int*)(&s_flag) = 1;
+            if (use_flag) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) *(volatile __attribute__((address_space(3))) int*)(&s_flag) = 1;
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
         }
-        first_round();                     // the service wave's own units: requested only now (its queue was kept clean)
+        first_round(3);                    // the service wave's own units: requested only now (its queue was kept clean)
     }
 
     // per-lane constants of head li: qsum = sum_d q_eff_d and Qoff = sum over the operand of 1024 * q' (the offset that
     // the 1024+n / 1024+16n operand form adds to the raw dot product); q_eff = what the MFMA effectively multiplies n by
     float qsum, qoff;
-    {
+    for (int rep = 0; rep < ((EXP & 32) ? 2 : 1); ++rep) {   // (trace build: twice - is the first pass slow because its code is cold?)
         float se = 0.f, so = 0.f;   // sums over lo-form / hi-form operand positions of this lane's 32 dims
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -435,8 +460,17 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         so += __shfl_xor(so, 32, 64);
         qsum = se + 16.f * so;
         qoff = 1024.f * (se + so);
+        if constexpr (EXP & 32) {
+            asm volatile("" : "+v"(qsum), "+v"(qoff) :: "memory");
+            stamp(9 + rep);
+        }
     }
     const float nqoff = -qoff;
+    if constexpr (EXP & 32) {
+        float probe = nqoff;
+        asm volatile("" : "+v"(probe));
+        stamp(11);
+    }
 
     // mask / magic constants parked in VGPRs so that (x & m) | c is one v_and_or_b32
     u32 c_lo = 0x000F000Fu, c_hi = 0x00F000F0u, c_magic = 0x64006400u;
@@ -466,13 +500,13 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
 
     int it = 0;          // units this wave has consumed: ring slot = it & 1
     int rem = cnt - 1;   // units this wave still owns after the current one
-    for (int u = cnt > 0 ? u_first : u_end; u < u_end; u += PS, ++it, --rem) {
+    for (int u = u_first; it < cnt; u += PS, ++it, --rem) {
         const bool has2 = rem >= 2;   // (has1 = rem >= 1)
         // A(u) landed?  Younger VMEM operations of this wave at this point: B(u) (3) and, if it exists, unit u + PS (6).
         // (the wave-uniform choice between the two counted waits is a scalar branch inside the statement)
         asm volatile("; QS_LOOP_BEGIN\n\ts_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(9)\n\ts_branch 2f\n1:\n\ts_waitcnt vmcnt(3)\n2:"
                      ::"s"(rem) : "memory", "scc");
-        stamp(5 + 2 * min(2, it));
+        if (it < 2) stamp(5 + 2 * it);
         const int slot = it & 1;
         const int valid = min(UT, tl - u * UT);
         const bool full = valid == UT;   // wave-uniform: only the last unit needs masking
@@ -650,7 +684,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0) ; QS_LOOP_END" ::: "memory");
-        stamp(6 + 2 * min(2, it));
+        if (it < 2) stamp(6 + 2 * it);
         if (has2) dma_b(vpage_next, u2 & 1, slot, valid2);
     }
 
@@ -815,6 +849,10 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         }
     }
     stamp(15);
+    if constexpr (EXP & 32) {
+        if (lane < 16)
+            reinterpret_cast<unsigned long long*>(ws)[(((size_t)b * gridDim.x + hkv) * NWT + wave) * 16 + lane] = s_stamps[wave * 16 + lane];
+    }
 }
 
 // second phase of split-KV: one workgroup per (sequence, query head) combines the nsplit partials
@@ -1017,6 +1055,7 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
                            Hkv, qs, kvs, mb, timestep, base, tab, tab_len, nsplit, ws, qout, qscale, qsum, qcnt, kflags); \
         return qs_launch_status("single_query_attention")
 #ifdef QS_TIMING   // ablation / trace instantiations (some are wrong by design): not in the shipped library
+    if (const char* e = getenv("QS_ATTN_KFLAGS")) kflags = atoi(e);   // experiment switches under a trace variant
     if (exp_flags & 32) {                     // timeline trace: stamps go to the (otherwise unused) split workspace
         ws = qs_split_workspace((size_t)blocks * NWT * 16 * 8, st);
         if (!ws) exp_flags = 0;

@@ -62,10 +62,19 @@ for L in LS:
     q, k, v = q.reshape(B, H, 128), k.reshape(B, Hkv, 128), v.reshape(B, Hkv, 128)
     lens = torch.full((B,), L, dtype=torch.int32, device=dev)
     bytes_ = B * (L - 1) * Hkv * (2 * dhb + 8)
-    row = []
-    for var in VARS:
-        lib.qs_set_attention_variant(var)
-        us = timeit(lambda i: fa.single_query_attention(q, k, v, tables[i % NL], lens, None, 8192, 64, Hkv * dhb, L, 128, 5e5, True, int4, True), reps=16)
-        row.append(f"variant {var}: {us:7.2f} us {bytes_ / us / 1e3:7.0f} GB/s")
+    # every variant is measured ROUNDS times, round-robin (clock / thermal drift and the cold first measurement of a process
+    # otherwise decide an A/B of a few per cent); the median is reported
+    ROUNDS = int(os.environ.get("ROUNDS", "5"))
+    res = {i: [] for i in range(len(VARS))}
+    call = lambda i: fa.single_query_attention(q, k, v, tables[i % NL], lens, None, 8192, 64, Hkv * dhb, L, 128, 5e5, True, int4, True)
+    timeit(call, reps=16)                                  # warm-up of clocks and caches, discarded
+    for _ in range(ROUNDS):
+        for i, var in enumerate(VARS):
+            lib.qs_set_attention_variant(var)
+            res[i].append(timeit(call, reps=16))
     lib.qs_set_attention_variant(0)
+    row = []
+    for i, var in enumerate(VARS):
+        us = sorted(res[i])[len(res[i]) // 2]
+        row.append(f"variant {var}: {us:7.2f} us {bytes_ / us / 1e3:7.0f} GB/s")
     print(f"KV{'4' if int4 else '8'} B={B} L={L}: " + "   ".join(row))

@@ -39,13 +39,15 @@ st = np.where(st > 0, st, np.nan)
 wg0 = np.nanmin(st[:, :, 0], axis=1)                  # every workgroup's own first entry
 skew = wg0 - np.nanmin(wg0)
 rel = st - wg0[:, None, None]
-names = ["entry", "tl", "dma issued", "phaseA in", "phaseA done", "K0 in", "pg0 done", "K1 in", "pg1 done", "K2 in", "pg2 done", "", "loop done", "sync1", "merged", "end"]
+names = ["entry", "tl", "dma issued", "A0 issued", "flag seen", "A0 in", "u0 done", "A1 in", "u1 done", "qsum pass 1", "qsum pass 2", "qsum done", "loop done", "sync1", "merged", "end"]
 print(f"L={L} VAR={VAR}: s_memtime ticks (shader cycles) since the workgroup's first wave entered; mean / min / max over workgroups x waves")
 for i, nm in enumerate(names):
     if not nm: continue
     x = rel[:, :, i]
     if np.all(np.isnan(x)): continue
     print(f"  {i:2d} {nm:12s} mean {np.nanmean(x):7.0f}  min {np.nanmin(x):7.0f}  max {np.nanmax(x):7.0f}   wave0 {np.nanmean(rel[:, 0, i]):7.0f}  wave3 {np.nanmean(rel[:, 3, i]):7.0f}  wave7 {np.nanmean(rel[:, 7, i]):7.0f}")
+print("  per wave (mean): " + "  ".join(f"w{w}: A0in {np.nanmean(rel[:, w, 5]):6.0f} done {np.nanmean(rel[:, w, 12]):6.0f}" for w in range(8)))
+print("  slowest wave of a workgroup, loop done: mean %.0f;  earliest A0 in of a workgroup: mean %.0f" % (np.nanmean(np.nanmax(rel[:, :, 12], axis=1)), np.nanmean(np.nanmin(rel[:, :, 5], axis=1))))
 end = np.nanmax(rel[:, :, 15], axis=1)
 print(f"  workgroup lifetime: mean {end.mean():.0f}  min {end.min():.0f}  max {end.max():.0f};  start skew: mean {skew.mean():.0f}  max {skew.max():.0f};  "
       f"last end since first entry: {np.nanmax(st[:, :, 15]) - np.nanmin(wg0):.0f}")
