@@ -66,9 +66,6 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the context sweep and the eager / op-by-op timings")
     ap.add_argument("--op-by-op", action="store_true",
                     help="issue the reference's ops one by one (no fused pairs) in the timed step")
-    ap.add_argument("--tails", action="store_true",
-                    help="A/B: run the row kernels between the GEMMs as tails of the GEMM launches (5 launches per layer "
-                         "instead of 8; bit-identical, measured slower on MI355X - DESIGN.md)")
     ap.add_argument("--gemm-variant", type=int, default=-1, help="A/B: qs_set_gemm_variant code (include/qserve_amd.h)")
     ap.add_argument("--attn-variant", type=int, default=0, help="A/B: qs_set_attention_variant code")
     ap.add_argument("--tp-full-graph", action="store_true",
@@ -278,29 +275,11 @@ def kernel_bench(eng, args, torch, contexts):
     specs = [("qkv", qa, eng.qkv_buf), ("o", qo, eng.proj_out), ("gate_up", qa, eng.gate_up_buf),
              ("down", eng.q_mlp, eng.proj_out)]
     sums = eng.q_sum if eng.group_size == -1 else None
-    hid_scratch = torch.zeros_like(eng.hidden)
-    qa_scratch, qm_scratch = torch.empty_like(eng.q_act), torch.empty_like(eng.q_mlp)
-    sc_scratch, sm_scratch = torch.empty_like(eng.q_scale), torch.empty_like(eng.q_sum)
     for name, x, out in specs:
         lin0 = eng.layers[0][name]
         by = gemm_bytes(B, lin0.n, lin0.k, eng.group_size)
         label = name
-        if eng.fuse_tails and lin0.bias is None and name in ("o", "down", "gate_up"):
-            # what the step launches: the GEMM with its row-op tail (the row kernel's bytes are added to the GEMM's)
-            if name == "gate_up":
-                us = time_kernel(lambda i: eng.layers[i % nl][name].silu_mul_quant(
-                    x, eng.q_scale, eng.q_sum, eng.mlp_act, out, qm_scratch, sc_scratch, sm_scratch if sums is not None else None),
-                    4 * nl, torch)
-                by += -B * lin0.n + B * (lin0.n // 2) + 4 * B      # [M, N/2] fp16 instead of [M, N]; int8 row + statistics
-                label = "gate_up+silu*mul+quant"
-            else:
-                us = time_kernel(lambda i: eng.layers[i % nl][name].add_norm_quant(
-                    x, eng.q_scale, eng.q_sum, out, hid_scratch, eng.layers[i % nl]["ln1"], qa_scratch, sc_scratch,
-                    eng.cfg["eps"], sm_scratch if sums is not None else None), 4 * nl, torch)
-                by += 4 * B * lin0.n + B * lin0.n + 2 * lin0.n + 4 * B   # residual stream read + write, int8 row, norm weight
-                label = f"{name}+add+norm+quant"
-            hid_scratch.zero_()
-        elif name == "gate_up" and eng.fuse_pairs and lin0.bias is None:
+        if name == "gate_up" and eng.fuse_pairs and lin0.bias is None:
             # what the step launches: the GEMM with the silu * mul epilogue (writes [M, N/2] instead of [M, N])
             us = time_kernel(lambda i: eng.layers[i % nl][name].silu_mul(x, eng.q_scale, eng.q_sum, eng.mlp_act, out),
                              4 * nl, torch)
@@ -457,7 +436,7 @@ def main():
         direct, collective_note = direct_allreduce_or_none(args.batch * cfg["hidden"], rank, world, dev, mode)
     eng = D.DecodeEngine(cfg, args.batch, args.prompt_len, args.max_new, group_size=args.group_size,
                          int4_kv=not args.kv8, device=dev, tp_rank=rank, tp_world=world,
-                         fuse_pairs=not args.op_by_op, direct_allreduce=direct, fuse_tails=args.tails)
+                         fuse_pairs=not args.op_by_op, direct_allreduce=direct)
     # the whole cache of the generation (prompt + max_new - 1 positions) is written by the prefill writer up front, so
     # that any context of the run (start / mid / end) reads real quantised pages; `lengths` selects the context
     full_ctx = args.prompt_len + args.max_new - 1
@@ -509,16 +488,7 @@ def main():
         dt = float(t.item())
     ms = dt / args.steps * 1e3
     extra = {}
-    eng.check()                         # bounded in-launch waits (direct all-reduce, row-op tails): raise if one gave up
-    if eng.fuse_tails:
-        from qserve_amd import fused as _fz
-        tl0 = _lib.lib.qs_debug_tail_launches()
-        eng.step()                      # one eager step: how many launches took a row-op tail
-        torch.cuda.synchronize()
-        eng.lengths.sub_(1)
-        extra["row_op_tails"] = {"launches_per_step": int(_lib.lib.qs_debug_tail_launches() - tl0),
-                                 "a_bounded_wait_gave_up": bool(_fz.fused_tail_gave_up())}
-        assert not extra["row_op_tails"]["a_bounded_wait_gave_up"], "a row-op tail gave up waiting: results undefined"
+    eng.check()                         # bounded in-launch waits (direct all-reduce): raise if one gave up
 
     # ---- secondary timings (single GPU): other contexts of the generation, eager launches, op-by-op sequence ---------
     sweep = {}
@@ -540,20 +510,8 @@ def main():
                 eng.run()
             extra["eager_tokens_per_s"] = round(args.batch / (time_steps(eng, n2, torch) / 1e3), 1)
             eng.graph, eng.pieces = g_saved, p_saved
-            if not args.op_by_op and eng.fuse_tails:      # the round-2 op sequence (pairs, row kernels as own launches)
-                eng.fuse_tails = False
-                eng.lengths.fill_(start_len)
-                eng.capture()
-                eng.lengths.fill_(start_len)
-                for _ in range(2):
-                    eng.run()
-                extra["pairs_only_tokens_per_s"] = round(args.batch / (time_steps(eng, n2, torch) / 1e3), 1)
-                eng.fuse_tails = True
-                eng.graph, eng.pieces = g_saved, p_saved
             if not args.op_by_op:
-                tails_saved = eng.fuse_tails
                 eng.fuse_pairs = False
-                eng.fuse_tails = False
                 eng.lengths.fill_(start_len)
                 eng.capture()
                 eng.lengths.fill_(start_len)
@@ -561,7 +519,6 @@ def main():
                     eng.run()
                 extra["op_by_op_tokens_per_s"] = round(args.batch / (time_steps(eng, n2, torch) / 1e3), 1)
                 eng.fuse_pairs = True
-                eng.fuse_tails = tails_saved
                 eng.graph, eng.pieces = g_saved, p_saved
 
     # ---- one rank's COMPUTE-ONLY share of the tensor-parallel step (N = 1 line only): what a real N-GPU run should take per
@@ -729,13 +686,9 @@ def main():
                                     if graphed and world > 1 and not full_graph and direct is None else graphed),
                        "layers": cfg["layers"],
                        "op_sequence": "reference ops one by one" if args.op_by_op else
-                       ("reference ops; 5 launches per layer: qkv GEMM | attention + quant | o_proj GEMM + residual add + norm "
-                        "+ quant | gate_up GEMM + silu_and_mul + quant | down GEMM + residual add + next norm + quant - the row "
-                        "ops run as tails of the GEMM launches, bit-identical to the separate ops (qserve_amd/fused.py)"
-                        if eng.fuse_tails else
-                        "reference ops; (residual add, layer norm), (gate_up GEMM, silu_and_mul) and (attention, quant) "
+                       ("reference ops; (residual add, layer norm), (gate_up GEMM, silu_and_mul) and (attention, quant) "
                         "issued as bit-identical fused pairs (qserve_amd/fused.py)"),
-                       "launches_per_layer": 5 if eng.fuse_tails else (8 if not args.op_by_op else 12),
+                       "launches_per_layer": 8 if not args.op_by_op else 12,
                        "value_context": f"decode steps at context {start_len + args.warmup}..{start_len + args.warmup + args.steps - 1} "
                                         "(start of the 1024 -> +512 generation); mid / end of generation: "
                                         "decode_tokens_per_s_by_context, whole generation: e2e_decode_only_tokens_per_s",

@@ -16,14 +16,13 @@
  *     a positive hipError_t if the launch failed.  qs_last_error() returns a thread-local message;
  *   - callers own every tensor buffer (ownership rules of the reference, SURVEY.md 8(b) "Conventions"); the library
  *     keeps a few small device scratch areas of its own (RoPE cos/sin tables, split-KV partials, split-K slabs, the split
- *     argmax's keys / tickets, the arrival words of the fused attention quantiser and of the GEMM row-op tails).  Each
+ *     argmax's keys / tickets, the arrival words of the fused attention quantiser).  Each
  *     is a fixed-size allocation made lazily on a first EAGER call (never while the stream is being captured into a
  *     graph: such a call runs the variant that needs no scratch) and is NEVER freed, moved or grown afterwards, so a
  *     hipGraph that captured its address stays valid for the life of the process.  Requests beyond the fixed capacity
  *     fall back to the un-split variants.  The scratch areas are per device (the CURRENT device of the calling thread):
  *     launches that use them (split-KV attention, K-sliced GEMMs, the split argmax, the fused attention quantiser's
- *     tickets, GEMMs with a row-op tail) must not run concurrently on different streams of
- *     one device (the reference's engine is single-stream).
+ *     tickets) must not run concurrently on different streams of one device (the reference's engine is single-stream).
  */
 #ifndef QSERVE_AMD_H
 #define QSERVE_AMD_H
@@ -85,44 +84,6 @@ int qs_w4a8_per_group_gemm_silu_mul(const int8_t* in_feats, const int8_t* kernel
                                     const int8_t* scales_i8, const void* wscales, const void* ascales, void* out_act,
                                     void* tmp, int M, int N, int K, qs_stream_t stream);
 
-/* Decode-layer fusions with a row-op tail (engine-side, no reference op of their own; LlamaDecoderLayer.forward,
- * llama_w4a8_unpad.py:330-361, issues o_proj / down_proj, the torch residual add, then the next RMSNormGeneral; LlamaMLP.forward
- * :69-93 issues gate_up_proj, silu_and_mul, invoke_quant).  Each call is BIT-IDENTICAL to the launches it stands for:
- *   qs_w4a8_*_gemm_add_norm_quant == qs_w4a8_*_gemm(..., out_feats) ;
- *                                    qs_add_residual_rms_norm_general(quant_out, hidden_io, out_feats, norm_weight, ...)
- *        out_feats half [M, N] is still written (the GEMM result = the residual delta); hidden_io half [M, N] += out_feats in
- *        place; quant_out int8 [M, N], quant_scale half [M], quant_sum half [M] or NULL = the layer norm's quantised output.
- *        quant_scale / quant_sum may alias ascales / a_ssums (a row's statistics are read by the GEMM before that row's
- *        tail overwrites them).
- *   qs_w4a8_*_gemm_silu_mul_quant == qs_w4a8_*_gemm_silu_mul(..., out_act, tmp) ; qs_invoke_quant(quant_out, out_act, ...)
- *        out_act half [M, N/2] is still written; quant_out int8 [M, N/2].
- * One launch when the dispatcher takes a decode (ring) geometry whose workgroups are all co-resident (grid <= compute
- * units): the workgroups that complete a token row run the row kernel's own code on it (same thread -> element mapping,
- * same reduction trees); any other shape runs as the separate launches, issued here.  Uses a per-device arrival-word
- * scratch (same stream rule as the other scratch areas).  Every in-launch wait is bounded: qs_fused_tail_status reports
- * (after synchronising the device) whether one ever gave up - that would mean a workgroup of a launch never became
- * resident, and the results of that launch are undefined. */
-int qs_w4a8_per_chn_gemm_add_norm_quant(const int8_t* in_feats, const int8_t* kernel, const void* wscales,
-                                        const void* ascales, const void* w_szs, const void* a_ssums, void* out_feats,
-                                        void* hidden_io, const void* norm_weight, int8_t* quant_out, void* quant_sum,
-                                        void* quant_scale, float epsilon, int M, int N, int K, qs_stream_t stream);
-int qs_w4a8_per_group_gemm_add_norm_quant(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros,
-                                          const int8_t* scales_i8, const void* wscales, const void* ascales,
-                                          void* out_feats, void* hidden_io, const void* norm_weight, int8_t* quant_out,
-                                          void* quant_sum, void* quant_scale, float epsilon, int M, int N, int K,
-                                          qs_stream_t stream);
-int qs_w4a8_per_chn_gemm_silu_mul_quant(const int8_t* in_feats, const int8_t* kernel, const void* wscales,
-                                        const void* ascales, const void* w_szs, const void* a_ssums, void* out_act,
-                                        void* tmp, int8_t* quant_out, void* quant_sum, void* quant_scale, int M, int N,
-                                        int K, qs_stream_t stream);
-int qs_w4a8_per_group_gemm_silu_mul_quant(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros,
-                                          const int8_t* scales_i8, const void* wscales, const void* ascales, void* out_act,
-                                          void* tmp, int8_t* quant_out, void* quant_sum, void* quant_scale, int M, int N,
-                                          int K, qs_stream_t stream);
-int qs_fused_tail_status(int* gave_up);
-/* tests / bench: number of launches that took a row-op tail since the library was loaded (host-side counter) */
-long qs_debug_tail_launches(void);
-
 /* Debug/parity entry points: same kernels, but the raw INT32 accumulators are written to acc_out [M,N]
  * instead of the fp16 epilogue (the reference keeps them in registers: gemm_cuda.cu:327). */
 int qs_w4a8_per_chn_gemm_acc(const int8_t* in_feats, const int8_t* kernel, int32_t* acc_out, int M, int N, int K,
@@ -144,9 +105,8 @@ int qs_w8a8_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscal
  *   3000 ... tiled (prefill) kernel off, 3001 / 3002 ... forced with the 256- / 128-token tile;
  *   4000 ... ring (decode) kernel off, 4001 ... ring kernel without K slices, 4002 ... cost model without the per-group term,
  *   4100 + 100*(k_slices-1) + 10*m_tiles + units ... forced ring geometry;
- *   5000 + bits ... A/B switches of the ring kernel (1: weight DMA without the non-temporal hint; 2: never take a row-op
- *                   tail; 256 * d: ring depth d; [QS_TIMING builds: 32 / 64 no MFMA / no operand reads]); sticky until reset
- *                   with 5000;
+ *   5000 + bits ... A/B switches of the ring kernel (1: weight DMA without the non-temporal hint; 256 * d: ring depth d;
+ *                   [QS_TIMING builds: 32 / 64 no MFMA / no operand reads]); sticky until reset with 5000;
  *   3200 + 10*p + o ... tiled kernel A/B, sticky until reset with 3200: tile order o (0 super-tiles, 1 / 2 token- /
  *                   channel-fastest bands); p = 1 one workgroup per tile instead of one per CU walking the tiles,
  *                   p = 2 three workgroups walk all tiles (tests of the tile-to-tile hand-over);

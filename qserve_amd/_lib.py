@@ -21,12 +21,6 @@ SIGNATURES = {
     "qs_w4a8_per_chn_gemm_acc": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_w4a8_per_chn_gemm_silu_mul": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_w4a8_per_group_gemm_silu_mul": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "qs_w4a8_per_chn_gemm_add_norm_quant": (_i, [_vp] * 12 + [_f, _i, _i, _i, _vp]),
-    "qs_w4a8_per_group_gemm_add_norm_quant": (_i, [_vp] * 12 + [_f, _i, _i, _i, _vp]),
-    "qs_w4a8_per_chn_gemm_silu_mul_quant": (_i, [_vp] * 11 + [_i, _i, _i, _vp]),
-    "qs_w4a8_per_group_gemm_silu_mul_quant": (_i, [_vp] * 11 + [_i, _i, _i, _vp]),
-    "qs_fused_tail_status": (_i, [C.POINTER(C.c_int)]),
-    "qs_debug_tail_launches": (C.c_long, []),
     "qs_w4a8_per_group_gemm_acc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_w8a8_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_set_gemm_variant": (None, [_i]),

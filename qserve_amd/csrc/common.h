@@ -169,23 +169,6 @@ struct QsAttnQuant {
 };
 extern thread_local QsAttnQuant g_qs_attn_quant;
 
-// Row-op tail of a decode GEMM launch (gemm_w4a8_ring.hip, ring_tail): the workgroups that finish a token row run the
-// row kernel that follows the GEMM in the decode layer themselves.  kind 1 = residual add + general layer norm + quantiser
-// of the [M, N] output (qs_add_residual_rms_norm_general), 2 = quantiser of the [M, N/2] silu * mul output
-// (qs_invoke_quant).  `done` is set by the launcher that took the tail; otherwise the entry point issues the row kernel.
-struct QsRingTail {
-    unsigned* ticket;          // per token block: arrivals (low 16 bits) | owner acknowledgements (high 16); zero between launches
-    unsigned* err;             // device word: bit 0 = a bounded wait gave up
-    int8_t* qout;              // int8 [M, row width]
-    __half* qscale;            // fp16 [M]
-    __half* qsum;              // fp16 [M] or null
-    _Float16* hidden_io;       // kind 1: residual stream [M, N], updated in place
-    const _Float16* gamma;     // kind 1: norm weight [N]
-    float eps;
-    int kind;                  // host side only
-    int done;                  // host side only
-};
-
 // butterfly exchange with an explicitly supplied lane id: __shfl_xor derives its own (loop-invariant) lane id, which the
 // register allocator then keeps alive - or spills - across a long loop
 __device__ __forceinline__ float xor_lane(float x, unsigned lid, int mask) {

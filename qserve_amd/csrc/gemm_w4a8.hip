@@ -395,7 +395,7 @@ int qs_launch_gemm_pair(int mode, int outk, const int8_t* A, const uint8_t* W, c
 int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, const uint8_t* W, const int8_t* zeros,
                         const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
                         const void* assums, void* out, int M, int N, int K, int mblocks, int ksplit, int* slabs,
-                        unsigned* counters, hipStream_t stream, QsRingTail* tail);
+                        unsigned* counters, hipStream_t stream);
 // compute-bound tiled kernel (gemm_w4a8_tiled.hip)
 int qs_launch_gemm_tiled(int mode, int outk, const int8_t* A, const uint8_t* W, const int8_t* zeros,
                          const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
@@ -407,9 +407,7 @@ constexpr int QS_UNFUSED = 1 << 20;   // internal: the chosen kernel has no acti
 template <int MODE, int OUTK>
 int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
              const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K,
-             qs_stream_t stream_, bool act = false, QsRingTail* tail = nullptr) {
-    // tail: the row op that follows this GEMM in the decode layer; a ring launch whose workgroups are all co-resident
-    // finishes it itself (tail->done = 1), every other kernel family leaves it to the caller
+             qs_stream_t stream_, bool act = false) {
     // act: `out` is [M, N/2] = silu(gate) * up of the stacked gate_up result (epilogue of the ring / tiled kernels,
     // OUTK = 2 there); QS_UNFUSED when the shape is served by a kernel without that epilogue (the caller runs the two ops)
     const int outk = act ? 2 : OUTK;
@@ -477,7 +475,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         unsigned* counters = nullptr;
         QS_REQUIRE(ring_ws(mt, mb, ks, &slabs, &counters), "w4a8 gemm: no split-K workspace for the forced geometry");
         return qs_launch_gemm_ring(MODE, outk, mt, wn, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N,
-                                   K, mb, ks, slabs, counters, stream, tail);
+                                   K, mb, ks, slabs, counters, stream);
     }
     // Geometry choice (measured: scripts/bench_gemm.py for the Llama-3-8B shapes, scripts/bench_gemm_shard.py for the
     // tensor-parallel shard shapes): a workgroup of (16 mt tokens) x (64 wn channels) streams K (16 mt + 32 wn) bytes
@@ -546,7 +544,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
             }
             if (best >= 0)
                 return qs_launch_gemm_ring(MODE, outk, bmt, bwn, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out,
-                                           M, N, K, mb, bks, slabs, counters, stream, tail);
+                                           M, N, K, mb, bks, slabs, counters, stream);
         }
     }
     if (act) return QS_UNFUSED;
@@ -658,13 +656,13 @@ namespace {
 template <int MODE>
 int gate_up_silu(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros, const int8_t* scales_i8,
                  const void* wscales, const void* ascales, const void* w_szs, const void* a_ssums, void* out_act,
-                 void* tmp, int M, int N, int K, qs_stream_t stream, QsRingTail* tail = nullptr) {
+                 void* tmp, int M, int N, int K, qs_stream_t stream) {
     QS_REQUIRE(N > 0 && N % 128 == 0, "w4a8 gate_up + silu: N=%d must stack two multiples of 64 channels", N);
     if (M == 0) return QS_OK;
     QS_REQUIRE(out_act, "w4a8 gate_up + silu: null output");
     int rc = g_act_off ? QS_UNFUSED
                        : dispatch<MODE, 0>(in_feats, kernel, zeros, scales_i8, wscales, ascales, w_szs, a_ssums, out_act, M,
-                                           N, K, stream, true, tail);
+                                           N, K, stream, true);
     if (rc != QS_UNFUSED) return rc;
     QS_REQUIRE(tmp, "w4a8 gate_up + silu: this shape needs the [M, N] fp16 scratch `tmp` (two launches)");
     rc = dispatch<MODE, 0>(in_feats, kernel, zeros, scales_i8, wscales, ascales, w_szs, a_ssums, tmp, M, N, K, stream);
@@ -685,82 +683,6 @@ extern "C" int qs_w4a8_per_group_gemm_silu_mul(const int8_t* in_feats, const int
                                                void* out_act, void* tmp, int M, int N, int K, qs_stream_t stream) {
     return gate_up_silu<1>(in_feats, kernel, zeros, scales_i8, wscales, ascales, nullptr, nullptr, out_act, tmp, M, N, K,
                            stream);
-}
-
-// ---- decode-layer fusions with a row-op tail (gemm_w4a8_ring.hip: ring_tail) -------------------------------------------
-// One launch where the dispatcher takes a ring geometry whose workgroups are all co-resident; otherwise the row kernel is
-// issued here as its own launch - bit-identical either way.
-namespace {
-template <int MODE>
-int gemm_add_norm_quant(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros, const int8_t* scales_i8,
-                        const void* wscales, const void* ascales, const void* w_szs, const void* a_ssums, void* out_feats,
-                        void* hidden_io, const void* norm_weight, int8_t* quant_out, void* quant_sum, void* quant_scale,
-                        float epsilon, int M, int N, int K, qs_stream_t stream) {
-    QS_REQUIRE(hidden_io && norm_weight && quant_out && quant_scale, "w4a8 gemm + add + norm + quant: null pointer");
-    QS_REQUIRE(hidden_io != out_feats, "w4a8 gemm + add + norm + quant: hidden_io must not alias out_feats");
-    if (M == 0) return QS_OK;
-    QsRingTail t = {};
-    t.kind = 1;
-    t.qout = quant_out;
-    t.qscale = reinterpret_cast<__half*>(quant_scale);
-    t.qsum = reinterpret_cast<__half*>(quant_sum);
-    t.hidden_io = reinterpret_cast<_Float16*>(hidden_io);
-    t.gamma = reinterpret_cast<const _Float16*>(norm_weight);
-    t.eps = epsilon;
-    const int rc = dispatch<MODE, 0>(in_feats, kernel, zeros, scales_i8, wscales, ascales, w_szs, a_ssums, out_feats, M, N, K,
-                                     stream, false, &t);
-    if (rc != QS_OK || t.done) return rc;
-    return qs_add_residual_rms_norm_general(quant_out, hidden_io, out_feats, norm_weight, quant_sum, quant_scale, epsilon, M,
-                                            N, stream);
-}
-template <int MODE>
-int gate_up_silu_quant(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros, const int8_t* scales_i8,
-                       const void* wscales, const void* ascales, const void* w_szs, const void* a_ssums, void* out_act,
-                       void* tmp, int8_t* quant_out, void* quant_sum, void* quant_scale, int M, int N, int K,
-                       qs_stream_t stream) {
-    QS_REQUIRE(quant_out && quant_scale, "w4a8 gate_up + silu + quant: null pointer");
-    if (M == 0) return QS_OK;
-    QsRingTail t = {};
-    t.kind = 2;
-    t.qout = quant_out;
-    t.qscale = reinterpret_cast<__half*>(quant_scale);
-    t.qsum = reinterpret_cast<__half*>(quant_sum);
-    const int rc = gate_up_silu<MODE>(in_feats, kernel, zeros, scales_i8, wscales, ascales, w_szs, a_ssums, out_act, tmp, M, N,
-                                      K, stream, &t);
-    if (rc != QS_OK || t.done) return rc;
-    return qs_invoke_quant(quant_out, out_act, quant_sum, quant_scale, M, N / 2, stream);
-}
-}  // namespace
-
-extern "C" int qs_w4a8_per_chn_gemm_add_norm_quant(const int8_t* in_feats, const int8_t* kernel, const void* wscales,
-                                                   const void* ascales, const void* w_szs, const void* a_ssums,
-                                                   void* out_feats, void* hidden_io, const void* norm_weight,
-                                                   int8_t* quant_out, void* quant_sum, void* quant_scale, float epsilon,
-                                                   int M, int N, int K, qs_stream_t stream) {
-    return gemm_add_norm_quant<0>(in_feats, kernel, nullptr, nullptr, wscales, ascales, w_szs, a_ssums, out_feats, hidden_io,
-                                  norm_weight, quant_out, quant_sum, quant_scale, epsilon, M, N, K, stream);
-}
-extern "C" int qs_w4a8_per_group_gemm_add_norm_quant(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros,
-                                                     const int8_t* scales_i8, const void* wscales, const void* ascales,
-                                                     void* out_feats, void* hidden_io, const void* norm_weight,
-                                                     int8_t* quant_out, void* quant_sum, void* quant_scale, float epsilon,
-                                                     int M, int N, int K, qs_stream_t stream) {
-    return gemm_add_norm_quant<1>(in_feats, kernel, zeros, scales_i8, wscales, ascales, nullptr, nullptr, out_feats,
-                                  hidden_io, norm_weight, quant_out, quant_sum, quant_scale, epsilon, M, N, K, stream);
-}
-extern "C" int qs_w4a8_per_chn_gemm_silu_mul_quant(const int8_t* in_feats, const int8_t* kernel, const void* wscales,
-                                                   const void* ascales, const void* w_szs, const void* a_ssums,
-                                                   void* out_act, void* tmp, int8_t* quant_out, void* quant_sum,
-                                                   void* quant_scale, int M, int N, int K, qs_stream_t stream) {
-    return gate_up_silu_quant<0>(in_feats, kernel, nullptr, nullptr, wscales, ascales, w_szs, a_ssums, out_act, tmp, quant_out,
-                                 quant_sum, quant_scale, M, N, K, stream);
-}
-extern "C" int qs_w4a8_per_group_gemm_silu_mul_quant(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros,
-                                                     const int8_t* scales_i8, const void* wscales, const void* ascales,
-                                                     void* out_act, void* tmp, int8_t* quant_out, void* quant_sum,
-                                                     void* quant_scale, int M, int N, int K, qs_stream_t stream) {
-    return gate_up_silu_quant<1>(in_feats, kernel, zeros, scales_i8, wscales, ascales, nullptr, nullptr, out_act, tmp,
-                                 quant_out, quant_sum, quant_scale, M, N, K, stream);
 }
 
 extern "C" int qs_w4a8_per_chn_gemm_acc(const int8_t* in_feats, const int8_t* kernel, int32_t* acc_out, int M, int N,

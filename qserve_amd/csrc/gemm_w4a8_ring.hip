@@ -21,12 +21,10 @@
 //   * the KG partial int32 tiles are summed exactly through LDS, the fp32 epilogue is fused, its scale operands are
 //     requested before the reduction, and the fp16 tile leaves through LDS as whole 128-byte rows.
 #include "common.h"
-#include "row_ops.h"
 #include <type_traits>
 
 // A/B switches (qs_set_gemm_variant(5000 + bits); every setting computes the same results):
 //   1 = weight DMA with the default cache policy instead of non-temporal
-//   2 = never take a row-op tail (the entry points then issue the row kernel as its own launch: in-run A/B of the tails)
 //   32 / 64 = (libraries built with -DQS_TIMING only; ignored by the shipped library) timing only, WRONG RESULTS: no MFMA /
 //        no LDS operand reads (what is left is the DMA + barrier pipeline:
 //        gate_up at M = 64 17.5 us -> 16.3 / 16.8, both off 15.9 us = 4.2 us of head and tail + 512 KB per CU at 44 GB/s,
@@ -124,19 +122,9 @@ __device__ __forceinline__ RingCoords ring_coords(int b, int N, int wn, int mblo
     return c;
 }
 
-// 16-byte row store of the epilogue.  SC (launches with a row-op tail): write-through (sc0 sc1), so that the workgroup
-// that finishes the token row - any CU, any XCD - reads it back from memory without fences (see ring_tail below).
-template <bool SC>
-__device__ __forceinline__ void store_row16(_Float16* dst, v4u v) {
-    if (SC) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
-    else *reinterpret_cast<v4u*>(dst) = v;
-}
-
-// The GEMM proper.  Returns (wave-uniform) the number of 64-channel output units whose rows THIS wave's group completed
-// (1 for the kg == 0 wave of every unit the workgroup finished, else 0): the tail's arrival count.  TAILED: the fp16
-// rows leave with write-through stores.
-template <int MT, int WN, int MODE, int OUTK, bool KSPLIT, bool TAILED>
-__device__ __forceinline__ int ring_body(const int8_t* __restrict__ A, const uint8_t* __restrict__ W,
+// The GEMM proper.
+template <int MT, int WN, int MODE, int OUTK, bool KSPLIT>
+__device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const uint8_t* __restrict__ W,
                                          const int8_t* __restrict__ zeros, const int8_t* __restrict__ scales8,
                                          const __half* __restrict__ wscales, const __half* __restrict__ ascales,
                                          const __half* __restrict__ wszs, const __half* __restrict__ assums,
@@ -516,7 +504,7 @@ __device__ __forceinline__ int ring_body(const int8_t* __restrict__ A, const uin
                 }
             }
         }
-        if (OUTK == 1) return 0;
+        if (OUTK == 1) return;
         __syncthreads();                               // the fp16 tile of every unit is staged
         QS_STAMP(5);
         if (ACT) {                                     // rows of 64 WN bytes, shared by all eight waves
@@ -529,9 +517,9 @@ __device__ __forceinline__ int ring_body(const int8_t* __restrict__ A, const uin
                 const int r = i * RPI + lane / LPR;
                 const int m = m0 + r;
                 const v4u v = *reinterpret_cast<const v4u*>(sa0 + r * RS + (lane % LPR) * 16);
-                if (m < M) store_row16<TAILED>(arow + (size_t)m * (N / 2), v);
+                if (m < M) *reinterpret_cast<v4u*>(arow + (size_t)m * (N / 2)) = v;
             }
-            return kg == 0 ? 1 : 0;
+            return;
         }
         _Float16* const orow = reinterpret_cast<_Float16*>(out) + (unit0 + wn) * 64 + (lane & 7) * 8;
 #pragma unroll
@@ -540,12 +528,12 @@ __device__ __forceinline__ int ring_body(const int8_t* __restrict__ A, const uin
             const int r = i * 8 + (lane >> 3);
             const int m = m0 + r;
             const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane & 7) * 16);
-            if (m < M) store_row16<TAILED>(orow + (size_t)m * N, v);
+            if (m < M) *reinterpret_cast<v4u*>(orow + (size_t)m * N) = v;
         }
         QS_STAMP(6);
-        return kg == 0 ? 1 : 0;
+        return;
     }
-    if (ACT) return 0;                                 // (never instantiated with K slices)
+    if (ACT) return;                                   // (never instantiated with K slices)
     h4 ws4[4], wz4[4];
     _Float16 sa_h[MT], ss_h[MT];
     if (OUTK == 0 && kg == 0) {                        // requested now: their latency overlaps the reduction
@@ -575,7 +563,7 @@ __device__ __forceinline__ int ring_body(const int8_t* __restrict__ A, const uin
     }
     __syncthreads();
     QS_STAMP(4);
-    if (kg > 0) return 0;
+    if (kg > 0) return;
 #pragma unroll
     for (int k2 = 0; k2 < KG - 1; ++k2)
 #pragma unroll
@@ -605,7 +593,7 @@ __device__ __forceinline__ int ring_body(const int8_t* __restrict__ A, const uin
         unsigned ticket = 0;
         if (lane == 0) ticket = __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
-        if (ticket != (unsigned)(ksplit - 1)) return 0;
+        if (ticket != (unsigned)(ksplit - 1)) return;
         if (lane == 0) __hip_atomic_store(counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // the other slices' slabs: all requested before ONE wait while they fit the register budget (mt <= 2, up to 3
         // slices = 96 VGPRs), slice by slice otherwise - each wait is a full memory round trip
@@ -650,7 +638,7 @@ __device__ __forceinline__ int ring_body(const int8_t* __restrict__ A, const uin
             for (int cl = 0; cl < 4; ++cl)
                 *reinterpret_cast<v4i*>(reinterpret_cast<int*>(out) + (size_t)m * N + ncol0 + 8 * cl) = acc[mt][cl];
         }
-        return 0;
+        return;
     }
     constexpr int RS = 144;                            // staged fp16 row: 128 B + 16 (keeps 16-byte alignment)
     uint8_t* const st = smem + (KG - 1) * WN * NP * 4 * 64 * 4 + wn * (16 * MT * RS);
@@ -679,113 +667,14 @@ __device__ __forceinline__ int ring_body(const int8_t* __restrict__ A, const uin
         const int r = i * 8 + (lane >> 3);
         const int m = m0 + r;
         const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane & 7) * 16);
-        if (m < M) store_row16<TAILED>(orow + (size_t)m * N, v);
+        if (m < M) *reinterpret_cast<v4u*>(orow + (size_t)m * N) = v;
     }
     QS_STAMP(6);
-    return 1;
-}
-
-// ---- row-op tail -------------------------------------------------------------------------------------------------------
-// At decode batch sizes every row kernel between two GEMMs is a ~5 us latency chain plus a kernel boundary, while the
-// GEMM that produces its input fills the chip with <= 256 co-resident workgroups.  With a tail, the GEMM launch finishes
-// the following row op itself:
-//   * every workgroup publishes its fp16 rows with write-through stores, waits for their acknowledgement and adds the
-//     number of 64-channel units it completed to a per-token-block word (device-scope atomic; low 16 bits);
-//   * workgroup j of a token block (j < rows of the block) OWNS row j (and j + P, ... when there are fewer workgroups than
-//     rows): it requests the operands that do not depend on this launch (residual stream, norm weight), waits - one lane,
-//     relaxed polls, bounded - until the word says every unit of the block has arrived, reads the row back with
-//     cache-bypassing loads and runs the row op with the stand-alone kernel's own code and thread -> element mapping
-//     (row_ops.h: bit-identical results by construction);
-//   * owners acknowledge in the high 16 bits; the last one puts the word back to zero (graph replays need no host reset).
-// Waiting is safe only while all workgroups of the launch are co-resident: the launcher takes this form only when the
-// grid does not exceed the number of CUs (one workgroup per CU), and every wait is bounded (tail.err reports a give-up).
-// No fences: write-through stores + acknowledgement (vmcnt 0) + device-scope atomics, as in the K-slice seam above.
-//   TAIL 1: hidden_io += out row ; rms_norm_general(_fuse_sum)        (add_residual_norm_quant_kernel<NC>, N <= 4096)
-//   TAIL 2: invoke_quant(_fuse_sum) of the [M, N/2] activation row    (quant_kernel<NC, NT>; ACT launches)
-template <int MT, int WN, int OUTK, int TAIL>
-__device__ __forceinline__ void ring_tail(int fin_units, const void* out, int M, int N, int mblocks, int ksplit,
-                                          const QsRingTail& t, uint8_t* smem, int flags) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores are acknowledged
-    __syncthreads();                                   // ... everybody's are, and the GEMM's LDS is dead
-    int* const s_i = reinterpret_cast<int*>(smem);     // [0..7] units per wave, [8] ready flag
-    float* const sm = reinterpret_cast<float*>(smem + 64);
-    if (lane == 0) s_i[wave] = fin_units;
-    if (tid == 0) s_i[8] = 0;
-    __syncthreads();
-    const RingCoords rc = ring_coords(blockIdx.x, N, WN, mblocks, ksplit);
-    unsigned* const word = t.ticket + rc.mblk;
-    if (tid == 0) {
-        int p = 0;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) p += s_i[w];
-        if (flags & 8) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if (p) __hip_atomic_fetch_add(word, (unsigned)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const int P = (N / (64 * WN)) * ksplit;            // workgroups per token block
-    const int j = rc.nblk * ksplit + rc.kq;            // this workgroup's index among them
-    const int m0 = rc.mblk * (16 * MT);
-    const int R = min(16 * MT, M - m0);                // rows of the block
-    if (j >= R) return;                                // not an owner (workgroup-uniform)
-    const unsigned target = (unsigned)(N / 64);        // units per token block
-    bool first = true;
-    auto ready = [&]() {
-        if (!first) return;
-        first = false;
-        if (tid == 0) {
-            unsigned spins = 0;
-            while ((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFu) != target) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 24)) {            // ~ seconds: a workgroup of this launch never ran
-                    __hip_atomic_fetch_or(t.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-            s_i[8] = 1;
-            if (flags & 4) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-    };
-    for (int row = j; row < R; row += P) {
-        const size_t m = (size_t)(m0 + row);
-        if (row != j) __syncthreads();                 // the previous row's LDS partials are consumed
-        if constexpr (TAIL == 1) {
-            const _Float16* delta = reinterpret_cast<const _Float16*>(out) + m * N;
-            _Float16* hid = t.hidden_io + m * N;
-            __half* sum = t.qsum ? t.qsum + m : nullptr;
-            if (N <= 2048)
-                qs_row::norm_quant_row<1, 4, 4, true, true>(t.qout + m * N, hid, delta, t.gamma, sum, t.qscale + m, t.eps, N,
-                                                            sm, tid, ready);
-            else
-                qs_row::norm_quant_row<2, 4, 4, true, true>(t.qout + m * N, hid, delta, t.gamma, sum, t.qscale + m, t.eps, N,
-                                                            sm, tid, ready);
-        } else {
-            const int Wd = N / 2;
-            const _Float16* in = reinterpret_cast<const _Float16*>(out) + m * Wd;
-            __half* sum = t.qsum ? t.qsum + m : nullptr;
-            int8_t* q = t.qout + m * Wd;
-            // the layouts of qs_invoke_quant (fused_small.hip): 256 virtual threads up to 4096 values, 1024 beyond
-            if (Wd <= 2048) qs_row::quant_row<1, 4, 4, true>(q, in, sum, t.qscale + m, Wd, sm, tid, ready);
-            else if (Wd <= 4096) qs_row::quant_row<2, 4, 4, true>(q, in, sum, t.qscale + m, Wd, sm, tid, ready);
-            else if (Wd <= 8192) qs_row::quant_row<1, 16, 8, true>(q, in, sum, t.qscale + m, Wd, sm, tid, ready);
-            else if (Wd <= 16384) qs_row::quant_row<2, 16, 8, true>(q, in, sum, t.qscale + m, Wd, sm, tid, ready);
-            else qs_row::quant_row<4, 16, 8, true>(q, in, sum, t.qscale + m, Wd, sm, tid, ready);
-        }
-    }
-    if (tid == 0) {
-        const unsigned owners = (unsigned)min(P, R);
-        const unsigned old = __hip_atomic_fetch_add(word, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((old >> 16) == owners - 1) __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
 
 // MT m-tiles (16 tokens each) per wave = tokens per workgroup / 16; WN units per workgroup; KG = 8 / WN K-groups.
-// KSPLIT = false folds every K-slice path away (the un-split launches keep exactly their earlier code).  TAIL: see above.
-template <int MT, int WN, int MODE, int OUTK, bool KSPLIT, int TAIL>
+// KSPLIT = false folds every K-slice path away (the un-split launches keep exactly their earlier code).
+template <int MT, int WN, int MODE, int OUTK, bool KSPLIT>
 __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restrict__ A, const uint8_t* __restrict__ W,
                                                          const int8_t* __restrict__ zeros,
                                                          const int8_t* __restrict__ scales8,
@@ -795,20 +684,17 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restric
                                                          const __half* __restrict__ assums, void* __restrict__ out,
                                                          int M, int N, int K, int mblocks, int ns, int ksplit_arg,
                                                          int* __restrict__ slabs, unsigned* __restrict__ counters,
-                                                         int flags, QsRingTail tail) {
+                                                         int flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int fin = ring_body<MT, WN, MODE, OUTK, KSPLIT, TAIL != 0>(A, W, zeros, scales8, wscales, ascales, wszs, assums,
-                                                                     out, M, N, K, mblocks, ns, ksplit_arg, slabs, counters,
-                                                                     flags, smem);
-    if constexpr (TAIL != 0) ring_tail<MT, WN, OUTK, TAIL>(fin, out, M, N, mblocks, KSPLIT ? ksplit_arg : 1, tail, smem, flags);
+    ring_body<MT, WN, MODE, OUTK, KSPLIT>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, mblocks, ns,
+                                          ksplit_arg, slabs, counters, flags, smem);
 }
 
-template <int MT, int WN, int MODE, int OUTK, bool KSPLIT, int TAIL = 0>
+template <int MT, int WN, int MODE, int OUTK, bool KSPLIT>
 int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
                 const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K,
-                int mblocks, int ksplit, int* slabs, unsigned* counters, hipStream_t stream,
-                const QsRingTail* rtail = nullptr) {
-    auto kern = w4a8_gemm_ring<MT, WN, MODE, OUTK, KSPLIT, TAIL>;
+                int mblocks, int ksplit, int* slabs, unsigned* counters, hipStream_t stream) {
+    auto kern = w4a8_gemm_ring<MT, WN, MODE, OUTK, KSPLIT>;
     constexpr int KG = 8 / WN;
     constexpr int GSTAGE = ring_gstage<MT, WN, MODE>();
     // ring depth: as deep as 144 KiB of LDS allows, never deeper than a group's stage count + 1.  At most 5: every
@@ -846,7 +732,7 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, A, W, zeros, scales8,
                        reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
                        reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K,
-                       mblocks, ns, ksplit, slabs, counters, g_ring_flags, rtail ? *rtail : QsRingTail{});
+                       mblocks, ns, ksplit, slabs, counters, g_ring_flags);
     return qs_launch_status("w4a8 gemm (ring)");
 }
 
@@ -859,47 +745,11 @@ extern "C" int qs_debug_ring_trace(void* buf) {
 }
 #endif
 
-// Per-device scratch of the row-op tails: 4096 arrival words (one per token block of a launch) + the give-up word.  Fixed
-// allocation on the first eager call, zeroed once (the words return to zero by themselves), never freed; nullptr while it
-// cannot be made (first use inside a stream capture): the caller then issues the row kernel as its own launch.
 namespace {
-constexpr int TAIL_WORDS = 4096;
-unsigned* g_tail_ws[QS_MAX_DEVICES];
-unsigned* tail_scratch(hipStream_t st) {
-    const int dev = qs_device_slot();
-    if (g_tail_ws[dev]) return g_tail_ws[dev];
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    void* p = nullptr;
-    // (the memset runs on the NULL stream: synchronise, or a launch on a non-blocking stream could overtake it)
-    if (hipMalloc(&p, (TAIL_WORDS + 16) * sizeof(unsigned)) != hipSuccess ||
-        hipMemset(p, 0, (TAIL_WORDS + 16) * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    g_tail_ws[dev] = reinterpret_cast<unsigned*>(p);
-    return g_tail_ws[dev];
-}
-
 template <int MT, int WN, int MODE, int OUTK>
-int ring_go(bool ks, const QsRingTail* tail, const int8_t* A, const uint8_t* W, const int8_t* zeros, const int8_t* scales8,
-            const void* wscales, const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K,
-            int mblocks, int ksplit, int* slabs, unsigned* counters, hipStream_t stream) {
-    constexpr int TL = OUTK == 0 ? 1 : OUTK == 2 ? 2 : 0;
-    if constexpr (TL != 0) {
-        if (tail) {
-            if constexpr (OUTK == 0) {
-                if (ks)
-                    return launch_ring<MT, WN, MODE, OUTK, true, TL>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out,
-                                                                     M, N, K, mblocks, ksplit, slabs, counters, stream, tail);
-            }
-            return launch_ring<MT, WN, MODE, OUTK, false, TL>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N,
-                                                              K, mblocks, 1, nullptr, nullptr, stream, tail);
-        }
-    }
+int ring_go(bool ks, const int8_t* A, const uint8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
+            const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K, int mblocks,
+            int ksplit, int* slabs, unsigned* counters, hipStream_t stream) {
     if constexpr (OUTK != 2) {
         if (ks)
             return launch_ring<MT, WN, MODE, OUTK, true>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,
@@ -910,35 +760,14 @@ int ring_go(bool ks, const QsRingTail* tail, const int8_t* A, const uint8_t* W, 
 }
 }  // namespace
 
-// launches that took a row-op tail since the library was loaded (tests / bench: was the one-launch form really taken?)
-static long g_tail_launches = 0;
-extern "C" long qs_debug_tail_launches(void) { return g_tail_launches; }
-
-// give-up word of the row-op tails (qs_fused_tail_status): synchronises the device
-extern "C" int qs_fused_tail_status(int* gave_up) {
-    QS_REQUIRE(gave_up, "fused_tail_status: null output");
-    *gave_up = 0;
-    unsigned* ws = g_tail_ws[qs_device_slot()];
-    if (!ws) return QS_OK;
-    unsigned v = 0;
-    hipError_t e = hipMemcpy(&v, ws + TAIL_WORDS, sizeof(v), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) {
-        qs_set_error("fused_tail_status: %s", hipGetErrorString(e));
-        return (int)e;
-    }
-    *gave_up = (int)(v & 1u);
-    return QS_OK;
-}
-
 // Entry used by the dispatcher in gemm_w4a8.hip.  mt = m-tiles per workgroup (1, 2, 4), wn = units per workgroup
 // (1, 2, 4); ksplit = K slices (1 = none; > 1 needs the slab / counter workspace: (N/64) * mblocks * ksplit * mt KiB * 4 and
 // (N/64) * mblocks counters); preconditions (checked there): N % (64*wn) == 0, (K/64/ksplit) % (8/wn) == 0,
-// M*K and N*K/2 below 4 GiB.  tail (may be null): the row op that follows this GEMM; taken (tail->done = 1) when every
-// workgroup of the launch is co-resident (grid <= CUs) and the row fits the row op's layouts, left to the caller otherwise.
+// M*K and N*K/2 below 4 GiB.
 int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, const uint8_t* W, const int8_t* zeros,
                         const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
                         const void* assums, void* out, int M, int N, int K, int mblocks, int ksplit, int* slabs,
-                        unsigned* counters, hipStream_t stream, QsRingTail* tail) {
+                        unsigned* counters, hipStream_t stream) {
     if (g_qs_plan.active) {
         g_qs_plan.family = 3;
         g_qs_plan.p[0] = mt, g_qs_plan.p[1] = wn, g_qs_plan.p[2] = mblocks, g_qs_plan.p[3] = ksplit;
@@ -948,25 +777,9 @@ int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, con
         qs_set_error("w4a8 gemm (ring): the activation epilogue has no K-sliced form");
         return QS_ENOSUP;
     }
-    QsRingTail tl = {};
-    const QsRingTail* tp = nullptr;
-    if (tail && !tail->done && tail->kind == (outk == 0 ? 1 : outk == 2 ? 2 : 0) && !(g_ring_flags & 2)) {
-        const long grid = (long)(N / (64 * wn)) * mblocks * ksplit;
-        const bool fits = tail->kind == 1 ? N <= 4096 : N / 2 <= 32768;
-        if (grid <= qs_num_cus() && fits && mblocks <= TAIL_WORDS && N / 64 < 65536) {
-            if (unsigned* ws = tail_scratch(stream)) {
-                tl = *tail;
-                tl.ticket = ws;
-                tl.err = ws + TAIL_WORDS;
-                tp = &tl;
-                tail->done = 1;
-                ++g_tail_launches;
-            }
-        }
-    }
     const bool ks = ksplit > 1;
 #define QS_R(MTV, WNV, MODEV, OUTV)                                                                                  \
-    return ring_go<MTV, WNV, MODEV, OUTV>(ks, tp, A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, \
+    return ring_go<MTV, WNV, MODEV, OUTV>(ks, A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, \
                                           mblocks, ksplit, slabs, counters, stream)
 #define QS_RM(MODEV, OUTV)                              \
     do {                                                \
@@ -989,10 +802,6 @@ int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, con
     if (mode == 1 && outk == 2) QS_RM(1, 2);
 #undef QS_RM
 #undef QS_R
-    if (tail && tp) {
-        tail->done = 0;
-        --g_tail_launches;
-    }
     qs_set_error("w4a8 gemm (ring): unsupported geometry mt=%d wn=%d", mt, wn);
     return QS_ENOSUP;
 }

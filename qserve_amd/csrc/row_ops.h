@@ -1,6 +1,8 @@
 // row_ops.h -- the per-token row operations of the activation side (quantiser, general layer norm + quantiser) as
-// device functions, shared by the stand-alone row kernels (fused_small.hip) and by the tails of the decode GEMMs
-// (gemm_w4a8_ring.hip: the workgroup that finishes a token row runs the following row op itself).
+// device functions behind the stand-alone row kernels (fused_small.hip).  (Round 3 also ran them as tails of the decode
+// GEMM launches - the workgroup that finished a token row ran the following row op itself, bit-identical, measured slower
+// than the kernel boundary it saved and removed in round 4: HISTORY.md; the virtual-wave layout, the cache-bypassing
+// loads `SC` and the `ready` hook below are what made that possible.)
 //
 // Behaviour follows (not code):
 //   invoke_quant(_fuse_sum) ......... kernels/csrc/fused_kernels.cu:52-137

@@ -7,9 +7,6 @@ It issues exactly the op sequence of the reference's model code for `is_prompt=F
     -> residual add -> rms_norm_general_fuse_sum -> gate_up GEMM -> silu_and_mul -> invoke_quant_fuse_sum
     -> down GEMM -> residual add;   then rms_norm, fp16 lm_head, greedy sampling.
 
-With `fuse_tails=True` (round 3; off by default: measured slower, see DecodeEngine.__init__) the row kernels between the
-GEMMs additionally run as tails of the GEMM launches (5 launches per layer: qkv GEMM, attention + quant, o_proj + add + norm + quant, gate_up + silu * mul + quant,
-down_proj + add + norm + quant) - still the same arithmetic and bit-identical tensors (tests/test_gemm_tail_gpu.py).
 With `fuse_pairs=True` (default) the adjacent pairs (attention, quant of its output), (residual add, layer norm) and
 (gate_up GEMM, silu_and_mul) are issued as one launch each (qserve_amd/fused.py) - same arithmetic, same intermediate fp16 roundings, bit-identical tensors
 (tests/test_fused_gpu.py, tests/test_decode_gpu.py); `fuse_pairs=False` issues the reference's ops one by one.
@@ -104,27 +101,6 @@ class W4A8Linear:
         if self.bias is not None and not self.defer_bias:
             out += self.bias
 
-    def add_norm_quant(self, x, input_scales, input_sum, out, hidden, norm_w, quant_out, quant_scale, eps, quant_sum):
-        """GEMM -> residual add -> next layer norm (+ quantiser) as one op (qserve_amd.fused.gemm_add_norm_quant_*).  Only
-        for a projection without bias (the bias would have to be added between the GEMM and the residual add)."""
-        assert self.bias is None
-        if self.group_size == -1:
-            fusedmod.gemm_add_norm_quant_per_chn(x, self.qweight, self.s1_scales, input_scales, self.s1_szeros, input_sum,
-                                                 out, hidden, norm_w, quant_out, quant_scale, eps, quant_sum)
-        else:
-            fusedmod.gemm_add_norm_quant_per_group(x, self.qweight, self.s2_zeros, self.s2_scales, self.s1_scales,
-                                                   input_scales, out, hidden, norm_w, quant_out, quant_scale, eps, quant_sum)
-
-    def silu_mul_quant(self, x, input_scales, input_sum, out_act, tmp, quant_out, quant_scale, quant_sum):
-        """gate_up projection + silu_and_mul + invoke_quant(_fuse_sum) as one op (gemm_silu_and_mul_quant_*)."""
-        assert self.bias is None
-        if self.group_size == -1:
-            fusedmod.gemm_silu_and_mul_quant_per_chn(x, self.qweight, self.s1_scales, input_scales, self.s1_szeros, input_sum,
-                                                     out_act, quant_out, quant_scale, tmp, quant_sum)
-        else:
-            fusedmod.gemm_silu_and_mul_quant_per_group(x, self.qweight, self.s2_zeros, self.s2_scales, self.s1_scales,
-                                                       input_scales, out_act, quant_out, quant_scale, tmp, quant_sum)
-
     def silu_mul(self, x, input_scales, input_sum, out_act, tmp):
         """gate_up projection + silu_and_mul as one op (qserve_amd.fused.gemm_silu_and_mul_*): out_act [T, n/2].  Only for
         a stacked gate_up weight without bias (the bias would have to be added between the two ops)."""
@@ -140,26 +116,16 @@ class W4A8Linear:
 class DecodeEngine:
     def __init__(self, cfg, batch, prompt_len, max_new, group_size=-1, int4_kv=True, device="cuda:0", seed=0,
                  tp_rank=0, tp_world=1, with_lm_head=True, fuse_pairs=True, weights=None, vocab_parallel=True,
-                 direct_allreduce=None, fuse_tails=False):
+                 direct_allreduce=None):
         """weights: None = synthetic random-quantised tensors of the right shapes; otherwise this rank's tensors as
         qserve_amd.loader.load_llama_w4a8 returns them (checkpoint path)."""
         self.cfg, self.B, self.dev = cfg, batch, torch.device(device)
         # fuse_pairs: issue (residual add + layer norm) and (silu_and_mul + quant) as one launch each
         # (qserve_amd/fused.py: bit-identical to the op pairs; False = the reference's exact op-by-op sequence)
         self.fuse_pairs = fuse_pairs
-        # fuse_tails (round 3, OFF by default): the row kernels between the GEMMs run as tails of the GEMM launches (o_proj /
-        # down_proj + residual add + norm + quant, gate_up + silu * mul + quant; qserve_amd/fused.py gemm_*_quant): 5 launches
-        # per layer instead of 8, bit-identical tensors - and MEASURED SLOWER on MI355X (in-run A/B, profiles/round3_a_*:
-        # 19.5 k vs 21.6 k tokens/s; every tail costs 7.5-9 us against 4.9 us + a 0.45 us gap for the row kernel it
-        # replaces: the all-to-all seam inside a launch - write-through stores, acknowledgement, device-scope ticket, poll,
-        # cache-bypassing re-read - is four dependent memory round trips, a kernel boundary is cheaper).  Needs fuse_pairs;
-        # not under tensor parallelism (the all-reduce sits between the row-parallel GEMM and the residual add).
-        self.fuse_tails = bool(fuse_tails and fuse_pairs and tp_world == 1)
         self.tp_rank, self.tp_world = tp_rank, tp_world
         self.group_size, self.int4 = group_size, int4_kv
         H, Hkv = cfg["heads"], cfg["kv_heads"]
-        # (more ranks than KV heads would need the loader's replicated-KV shards AND an engine that de-duplicates the
-        # replicated cache writes: the loader supports it, this engine does not - reject instead of mis-sizing the pools)
         # KV heads: Hkv / tp per rank, or - beyond one rank per KV head - ONE head replicated over tp / Hkv neighbouring ranks
         # (the loader's rule, qserve_amd/loader.py: rank r then holds KV head r // (tp / Hkv))
         assert H % tp_world == 0 and (Hkv % tp_world == 0 or tp_world % Hkv == 0) and \
@@ -419,40 +385,27 @@ class DecodeEngine:
                     fused_kernels.invoke_quant_fuse_sum(qo, attn, self.q_sum, self.q_scale)
                 else:
                     fused_kernels.invoke_quant(qo, attn, self.q_scale)
-            tails = self.fuse_tails
-            if tails and L["o"].bias is None:          # o_proj GEMM + residual add + post-attention norm + quantiser
-                L["o"].add_norm_quant(qo, self.q_scale, self.q_sum, self.proj_out, h, L["ln2"], qa, self.q_scale, cfg["eps"],
-                                      sums)
+            L["o"](qo, self.q_scale, self.q_sum, self.proj_out)
+            res = self.proj_out
+            if self.tp_world > 1:
+                yield self.proj_out
+                res = self.proj_res
+                if L["o"].defer_bias and L["o"].bias is not None:
+                    res += L["o"].bias                    # once, after the reduce
+            add_norm_quant(h, res, L["ln2"])
+            if fuse and L["gate_up"].bias is None:     # gate_up GEMM with the silu * mul epilogue, then the quantiser
+                L["gate_up"].silu_mul(qa, self.q_scale, self.q_sum, self.mlp_act, self.gate_up_buf)
             else:
-                L["o"](qo, self.q_scale, self.q_sum, self.proj_out)
-                res = self.proj_out
-                if self.tp_world > 1:
-                    yield self.proj_out
-                    res = self.proj_res
-                    if L["o"].defer_bias and L["o"].bias is not None:
-                        res += L["o"].bias                    # once, after the reduce
-                add_norm_quant(h, res, L["ln2"])
-            if tails and L["gate_up"].bias is None:    # gate_up GEMM + silu * mul + quantiser
-                L["gate_up"].silu_mul_quant(qa, self.q_scale, self.q_sum, self.mlp_act, self.gate_up_buf, self.q_mlp,
-                                            self.q_scale, sums)
+                L["gate_up"](qa, self.q_scale, self.q_sum, self.gate_up_buf)
+            if fuse and L["gate_up"].bias is not None:
+                fusedmod.silu_and_mul_quant(self.q_mlp, self.gate_up_buf, self.q_scale, sums)
             else:
-                if fuse and L["gate_up"].bias is None:     # gate_up GEMM with the silu * mul epilogue, then the quantiser
-                    L["gate_up"].silu_mul(qa, self.q_scale, self.q_sum, self.mlp_act, self.gate_up_buf)
+                if not fuse:
+                    activation_ops.silu_and_mul(self.mlp_act, self.gate_up_buf)
+                if fuse_sum:
+                    fused_kernels.invoke_quant_fuse_sum(self.q_mlp, self.mlp_act, self.q_sum, self.q_scale)
                 else:
-                    L["gate_up"](qa, self.q_scale, self.q_sum, self.gate_up_buf)
-                if fuse and L["gate_up"].bias is not None:
-                    fusedmod.silu_and_mul_quant(self.q_mlp, self.gate_up_buf, self.q_scale, sums)
-                else:
-                    if not fuse:
-                        activation_ops.silu_and_mul(self.mlp_act, self.gate_up_buf)
-                    if fuse_sum:
-                        fused_kernels.invoke_quant_fuse_sum(self.q_mlp, self.mlp_act, self.q_sum, self.q_scale)
-                    else:
-                        fused_kernels.invoke_quant(self.q_mlp, self.mlp_act, self.q_scale)
-            if tails and L["down"].bias is None and li + 1 < nl:   # down GEMM + residual add + the NEXT layer's input norm
-                L["down"].add_norm_quant(self.q_mlp, self.q_scale, self.q_sum, self.proj_out, h, self.layers[li + 1]["ln1"],
-                                         qa, self.q_scale, cfg["eps"], sums)
-                continue
+                    fused_kernels.invoke_quant(self.q_mlp, self.mlp_act, self.q_scale)
             L["down"](self.q_mlp, self.q_scale, self.q_sum, self.proj_out)
             res = self.proj_out
             if self.tp_world > 1:
@@ -548,13 +501,11 @@ class DecodeEngine:
 
     def check(self):
         """Raise if a bounded in-launch wait gave up since the last call (the library's direct all-reduce waiting for a
-        peer, a GEMM row-op tail waiting for a workgroup): the tensors of that step are undefined.  Synchronises the
-        device - call it once per batch of steps, not per step."""
+        peer): the tensors of that step are undefined.  Synchronises the device - call it once per batch of steps, not
+        per step."""
         if self.ar is not None and self.ar.error():
             raise RuntimeError("direct all-reduce: a wait for a peer rank timed out (ranks more than a few seconds apart, or "
                                "a peer died); the communicators' epochs no longer match - re-create them")
-        if self.fuse_tails and fusedmod.fused_tail_gave_up():
-            raise RuntimeError("GEMM row-op tail: a wait for a workgroup of the same launch gave up")
 
     def run(self):
         if getattr(self, "pieces", None):

@@ -8,11 +8,6 @@ they exist because at decode batch sizes each row kernel is a fixed ~5 us latenc
     single_query_attention_quant(_fuse_sum)   ==  fused_attention.single_query_attention ; fused_kernels.invoke_quant(_fuse_sum)
     gemm_silu_and_mul_per_chn / _per_group    ==  qgemm_w4a8_per_*.gemm_forward_cuda(gate_up) ; activation_ops.silu_and_mul
 
-Decode-layer fusions with a row-op tail (round 3; one launch where the GEMM's workgroups are all co-resident, the separate
-launches otherwise - bit-identical either way, tests/test_gemm_tail_gpu.py):
-
-    gemm_add_norm_quant_per_chn / _per_group     ==  gemm_forward_cuda(o_proj | down_proj) ; add_residual_rms_norm_general
-    gemm_silu_and_mul_quant_per_chn / _per_group ==  gemm_silu_and_mul_* ; fused_kernels.invoke_quant(_fuse_sum)
 """
 import torch
 
@@ -131,83 +126,3 @@ def _gemm_common(per_group, in_feats, kernel, rest):
     if kernel.size(1) * 2 != K:
         raise RuntimeError(f"w4a8 gemm: kernel {tuple(kernel.shape)} does not match K={K}")
     return M, N, K
-
-
-def _gemm_add_norm_quant(per_group, in_feats, kernel, rest, out_feats, hidden, norm_weight, quant_out, quant_scale,
-                         epsilon, quant_sum):
-    M, N, K = _gemm_common(per_group, in_feats, kernel, rest)
-    expect(out_feats, torch.float16, "out_feats")
-    expect(hidden, torch.float16, "hidden")
-    expect(norm_weight, torch.float16, "norm_weight")
-    expect(quant_out, torch.int8, "quant_out")
-    expect(quant_scale, torch.float16, "quant_scale")
-    if quant_sum is not None:
-        expect(quant_sum, torch.float16, "quant_sum")
-    if out_feats.numel() != M * N or hidden.numel() != M * N or quant_out.numel() != M * N or norm_weight.numel() != N:
-        raise RuntimeError(f"gemm_add_norm_quant: out_feats / hidden / quant_out must hold {M} x {N} values, norm_weight {N}")
-    if quant_scale.numel() < M or (quant_sum is not None and quant_sum.numel() < M):
-        raise RuntimeError("gemm_add_norm_quant: quant_scale / quant_sum must hold one value per token")
-    fn = lib.qs_w4a8_per_group_gemm_add_norm_quant if per_group else lib.qs_w4a8_per_chn_gemm_add_norm_quant
-    with guard(out_feats):
-        check(fn(ptr(in_feats), ptr(kernel), *[ptr(t) for t in rest], ptr(out_feats), ptr(hidden), ptr(norm_weight),
-                 ptr(quant_out), ptr(quant_sum) if quant_sum is not None else 0, ptr(quant_scale), float(epsilon), M, N, K,
-                 stream()), "fused.gemm_add_norm_quant")
-
-
-def gemm_add_norm_quant_per_chn(in_feats, kernel, wscales, ascales, w_szs, a_ssums, out_feats, hidden, norm_weight,
-                                quant_out, quant_scale, epsilon, quant_sum=None):
-    """out_feats fp16 [M, N] = per-channel W4A8 GEMM (o_proj / down_proj); hidden fp16 [M, N] += out_feats in place;
-    quant_out int8 [M, N] / quant_scale (/ quant_sum) = rms_norm_general(_fuse_sum)(hidden, norm_weight) - the decode layer's
-    GEMM -> residual add -> next norm (llama_w4a8_unpad.py:346-351, 358-360 + the next layer's :337) as one call."""
-    _gemm_add_norm_quant(False, in_feats, kernel, (wscales, ascales, w_szs, a_ssums), out_feats, hidden, norm_weight,
-                         quant_out, quant_scale, epsilon, quant_sum)
-
-
-def gemm_add_norm_quant_per_group(in_feats, kernel, zeros, scales_i8, wscales, ascales, out_feats, hidden, norm_weight,
-                                  quant_out, quant_scale, epsilon, quant_sum=None):
-    """Per-group (g128) form of `gemm_add_norm_quant_per_chn`."""
-    _gemm_add_norm_quant(True, in_feats, kernel, (zeros, scales_i8, wscales, ascales), out_feats, hidden, norm_weight,
-                         quant_out, quant_scale, epsilon, quant_sum)
-
-
-def _gemm_silu_quant(per_group, in_feats, kernel, rest, out_act, tmp, quant_out, quant_scale, quant_sum):
-    M, N, K = _gemm_common(per_group, in_feats, kernel, rest)
-    expect(out_act, torch.float16, "out_act")
-    expect(quant_out, torch.int8, "quant_out")
-    expect(quant_scale, torch.float16, "quant_scale")
-    if quant_sum is not None:
-        expect(quant_sum, torch.float16, "quant_sum")
-    if out_act.numel() != M * (N // 2) or quant_out.numel() != M * (N // 2):
-        raise RuntimeError(f"gemm_silu_and_mul_quant: out_act / quant_out must hold {M} x {N // 2} values")
-    if tmp is not None:
-        expect(tmp, torch.float16, "tmp")
-        if tmp.numel() < M * N:
-            raise RuntimeError(f"gemm_silu_and_mul_quant: tmp has {tmp.numel()} elements, needs {M} x {N}")
-    fn = lib.qs_w4a8_per_group_gemm_silu_mul_quant if per_group else lib.qs_w4a8_per_chn_gemm_silu_mul_quant
-    with guard(out_act):
-        check(fn(ptr(in_feats), ptr(kernel), *[ptr(t) for t in rest], ptr(out_act), ptr(tmp) if tmp is not None else 0,
-                 ptr(quant_out), ptr(quant_sum) if quant_sum is not None else 0, ptr(quant_scale), M, N, K, stream()),
-              "fused.gemm_silu_and_mul_quant")
-
-
-def gemm_silu_and_mul_quant_per_chn(in_feats, kernel, wscales, ascales, w_szs, a_ssums, out_act, quant_out, quant_scale,
-                                    tmp=None, quant_sum=None):
-    """out_act fp16 [M, N/2] = silu_and_mul(gate_up GEMM) and quant_out int8 [M, N/2] / quant_scale (/ quant_sum) =
-    invoke_quant(_fuse_sum)(out_act): LlamaMLP.forward up to the down projection's input (llama_w4a8_unpad.py:69-93)."""
-    _gemm_silu_quant(False, in_feats, kernel, (wscales, ascales, w_szs, a_ssums), out_act, tmp, quant_out, quant_scale,
-                     quant_sum)
-
-
-def gemm_silu_and_mul_quant_per_group(in_feats, kernel, zeros, scales_i8, wscales, ascales, out_act, quant_out, quant_scale,
-                                      tmp=None, quant_sum=None):
-    """Per-group (g128) form of `gemm_silu_and_mul_quant_per_chn`."""
-    _gemm_silu_quant(True, in_feats, kernel, (zeros, scales_i8, wscales, ascales), out_act, tmp, quant_out, quant_scale,
-                     quant_sum)
-
-
-def fused_tail_gave_up():
-    """True if a bounded in-launch wait of a GEMM row-op tail ever gave up on the current device (synchronises)."""
-    import ctypes
-    v = ctypes.c_int(0)
-    check(lib.qs_fused_tail_status(ctypes.byref(v)), "fused.fused_tail_status")
-    return bool(v.value)

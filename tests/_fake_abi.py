@@ -104,33 +104,6 @@ def qs_w4a8_per_group_gemm_silu_mul(in_feats, kernel, zeros, scales_i8, wscales,
     return 0
 
 
-def qs_w4a8_per_chn_gemm_add_norm_quant(in_feats, kernel, wscales, ascales, w_szs, a_ssums, out_feats, hidden_io,
-                                        norm_weight, quant_out, quant_sum, quant_scale, eps, M, N, K, stream):
-    """The launches it is defined as (include/qserve_amd.h): GEMM, residual add, general norm + quantiser."""
-    rc = qs_w4a8_per_chn_gemm(in_feats, kernel, wscales, ascales, w_szs, a_ssums, out_feats, M, N, K, stream)
-    return rc or qs_add_residual_rms_norm_general(quant_out, hidden_io, out_feats, norm_weight, quant_sum, quant_scale, eps, M,
-                                                  N, stream)
-
-
-def qs_w4a8_per_group_gemm_add_norm_quant(in_feats, kernel, zeros, scales_i8, wscales, ascales, out_feats, hidden_io,
-                                          norm_weight, quant_out, quant_sum, quant_scale, eps, M, N, K, stream):
-    rc = qs_w4a8_per_group_gemm(in_feats, kernel, zeros, scales_i8, wscales, ascales, out_feats, M, N, K, stream)
-    return rc or qs_add_residual_rms_norm_general(quant_out, hidden_io, out_feats, norm_weight, quant_sum, quant_scale, eps, M,
-                                                  N, stream)
-
-
-def qs_w4a8_per_chn_gemm_silu_mul_quant(in_feats, kernel, wscales, ascales, w_szs, a_ssums, out_act, tmp, quant_out,
-                                        quant_sum, quant_scale, M, N, K, stream):
-    rc = qs_w4a8_per_chn_gemm_silu_mul(in_feats, kernel, wscales, ascales, w_szs, a_ssums, out_act, tmp, M, N, K, stream)
-    return rc or qs_invoke_quant(quant_out, out_act, quant_sum, quant_scale, M, N // 2, stream)
-
-
-def qs_w4a8_per_group_gemm_silu_mul_quant(in_feats, kernel, zeros, scales_i8, wscales, ascales, out_act, tmp, quant_out,
-                                          quant_sum, quant_scale, M, N, K, stream):
-    rc = qs_w4a8_per_group_gemm_silu_mul(in_feats, kernel, zeros, scales_i8, wscales, ascales, out_act, tmp, M, N, K, stream)
-    return rc or qs_invoke_quant(quant_out, out_act, quant_sum, quant_scale, M, N // 2, stream)
-
-
 def qs_invoke_quant(out, inp, input_sum, scale, T, hidden, stream):
     CALLS.append(("qs_invoke_quant", T, hidden, bool(input_sum)))
     x = _arr(inp, (T, hidden), np.float16)
@@ -269,8 +242,6 @@ def qs_flash_attn_varlen_fwd(q, k, v, out, cu_q, cu_k, batch, H, Hkv, head_dim, 
 
 SYMBOLS = {f.__name__: f for f in (
     qs_w4a8_per_chn_gemm, qs_w4a8_per_group_gemm, qs_w4a8_per_chn_gemm_silu_mul, qs_w4a8_per_group_gemm_silu_mul,
-    qs_w4a8_per_chn_gemm_add_norm_quant, qs_w4a8_per_group_gemm_add_norm_quant, qs_w4a8_per_chn_gemm_silu_mul_quant,
-    qs_w4a8_per_group_gemm_silu_mul_quant,
     qs_invoke_quant, qs_rms_norm_general, qs_rms_norm, qs_silu_and_mul,
     qs_residual_add, qs_argmax_rows, qs_add_residual_rms_norm_general, qs_silu_and_mul_quant, qs_compute_padding_offsets,
     qs_apply_bias_rope_update_kv_cache, qs_single_query_attention, qs_single_query_attention_quant,
