@@ -308,6 +308,42 @@ def kernel_bench(eng, args, torch, contexts):
     return res
 
 
+def other_configs(torch, D, dev):
+    """BASELINE.json configs[2] (g128 per-group, bs = 128) and configs[4] (KV8, bs = 8, 8k context) on the driver-observed
+    line: a short graph-replayed run each (8 warm-up + 16 timed steps at the start of the generation, no CPU leg), with the
+    decode attention's fraction of the HBM peak and the GEMM family's at that configuration's shapes."""
+    res = {}
+    for idx, name in ((3, "config3"), (5, "config5")):
+        c = CONFIGS[idx]
+        cfg = D.LLAMA3_8B
+        try:
+            e = D.DecodeEngine(cfg, c["batch"], c["prompt_len"], c["max_new"], group_size=c["group_size"],
+                               int4_kv=not c["kv8"], device=dev)
+            start = c["prompt_len"] + 1
+            e.prefill_cache(c["prompt_len"] + 40)
+            e.lengths.fill_(start)
+            e.capture()
+            e.lengths.fill_(start)
+            for _ in range(8):
+                e.run()
+            ms = time_steps(e, 16, torch)
+            ns = argparse.Namespace(no_extras=True)
+            ks = kernel_bench(e, ns, torch, [start + 8])
+            att = next(r for r in ks if r["family"] == "decode_attention")
+            fam = [r for r in ks if r["family"] == "w4a8_gemm"]
+            fb, fu = sum(r["bytes"] for r in fam), sum(r["us"] for r in fam)
+            res[name] = dict(workload=f"Llama-3-8B W4A8{'g128' if c['group_size'] == 128 else ' per-channel'} "
+                                      f"KV{'8' if c['kv8'] else '4'}, bs={c['batch']}, context {start + 8}..{start + 23}",
+                             tokens_per_s=round(c["batch"] / (ms / 1e3), 1), ms_per_step=round(ms, 4), steps=16, warmup=8,
+                             attention_us=round(att["us"], 2), attention_frac=round(att["gbs"] / HBM_PEAK_GBS, 4),
+                             gemm_family_us=round(fu, 2), gemm_family_frac=round(fb / fu / 1e3 / HBM_PEAK_GBS, 4))
+            del e
+            torch.cuda.empty_cache()
+        except RuntimeError as ex:
+            res[name] = dict(skipped=str(ex)[:200])
+    return res
+
+
 def gemm_config1_bench(torch, dev):
     """BASELINE.json configs[0] on the GPU: 4096 x 4096 x 4096 W4A8 GEMM, per-channel and per-group, compute-bound;
     TOPS against the dense INT8 MFMA peak (north_star: >= 70 %)."""
@@ -652,14 +688,16 @@ def main():
             for k2, nd in (("us", 2), ("gbs", 1), ("tops", 1), ("frac_of_hbm_peak", 4), ("frac_of_int8_mfma_peak", 4)):
                 if k2 in r:
                     r[k2] = round(r[k2], nd)
+    headline = (args.model == "llama3-8b" and per_gpu_batch == 64 and args.group_size == -1 and not args.kv8
+                and args.prompt_len == 1024 and args.max_new == 512)
+    if headline and world == 1 and not args.no_extras and not args.op_by_op:
+        extra["other_configs"] = other_configs(torch, D, dev)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, cfg, torch)
         cpu["value"] = round(cpu["value"], 3)
 
     if rank == 0:
-        headline = (args.model == "llama3-8b" and per_gpu_batch == 64 and args.group_size == -1 and not args.kv8
-                    and args.prompt_len == 1024 and args.max_new == 512)
         cfg_idx = next((i for i, c in CONFIGS.items() if all(getattr(args, k) == v for k, v in c.items()
                                                               if k not in ("gpus", "scaling", "batch")) and c["batch"] == per_gpu_batch), None)
         out = {

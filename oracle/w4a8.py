@@ -121,16 +121,53 @@ def gemm_per_chn_acc(A, qweight):
     return int_matmul(np.asarray(A, np.int8), Q, 128, 15).astype(np.int32)
 
 
-def epilogue_per_chn(acc, wscales, ascales, w_szs, a_ssums):
+def _fmaf(a, b, c):
+    """Correctly rounded float32 fma(a, b, c) for float32 arrays: the product of two float32 is exact in float64, the sum
+    with c is made exact by an error-free TwoSum, and the pair (s, e) is rounded to float32 ONCE - the rare cases where s sits
+    exactly on a float32 rounding boundary are decided by the sign of the residual e (no double rounding)."""
+    p = a.astype(np.float64) * b.astype(np.float64)
+    c = np.broadcast_to(c.astype(np.float64), p.shape)
+    s = p + c
+    bb = s - p
+    e = (p - (s - bb)) + (c - bb)                     # s + e == p + c exactly
+    r = s.astype(np.float32)
+    d = s - r.astype(np.float64)                      # exact: what the float64 -> float32 rounding dropped
+    tie = (np.abs(d) * 2 == np.spacing(np.abs(r)).astype(np.float64)) & (e != 0) & np.isfinite(r)
+    if tie.any():
+        # s is the midpoint of r and its neighbour on the side of d: the exact value s + e lies on the side of e
+        toward = np.where(d > 0, np.float32(np.inf), np.float32(-np.inf))
+        other = np.nextafter(r, toward.astype(np.float32))
+        pick_other = tie & (np.sign(e) == np.sign(d))
+        pick_r = tie & (np.sign(e) != np.sign(d))
+        r = np.where(pick_other, other, r)
+        del pick_r                                    # (r already is the near side)
+    # also the non-tie case where e pushes s + e across the midpoint cannot occur: |e| <= ulp64(s) / 2 << ulp32 / 2 - |d|
+    return r.astype(np.float32)
+
+
+def epilogue_per_chn(acc, wscales, ascales, w_szs, a_ssums, fma=False):
     """fp32 epilogue, evaluation order of gemm_cuda.cu:585-588:
-    out = half_rn( (float(acc) * wscale[n]) * ascale[m] - w_sz[n] * a_ssum[m] ), no FMA contraction."""
+        out = half_rn( (float(acc) * wscale[n]) * ascale[m] - w_sz[n] * a_ssum[m] )
+    fma = False: every operation rounded separately (no FMA contraction) - the convention the HIP kernels are built to
+        (`#pragma clang fp contract(off)`), bit-exact in tests/test_gemm_gpu.py;
+    fma = True:  t = acc * wscale ; u = w_sz * a_ssum ; out = fmaf(t, ascale, -u) - what nvcc's default --fmad=true most
+        likely makes of line 586 (the last multiply fused with the subtraction);
+    fma = "sub": the other legal contraction, fmaf(-w_sz, a_ssum, (acc * wscale) * ascale).
+    The reference cannot be compiled here (inline PTX, no nvcc), so which of the three its binary computes is unpinned; they
+    differ by at most one fp16 ulp on a small fraction of the outputs (tests/test_gemm_gpu.py::test_epilogue_fma_envelope
+    records it)."""
     p = acc.astype(np.float32)
     ws = np.asarray(wscales, np.float16).astype(np.float32)[None, :]
     sa = np.asarray(ascales, np.float16).astype(np.float32)[:, None]
     wz = np.asarray(w_szs, np.float16).astype(np.float32)[None, :]
     ss = np.asarray(a_ssums, np.float16).astype(np.float32)[:, None]
     t = (p * ws).astype(np.float32)
+    if fma is True:
+        u = (wz * ss).astype(np.float32)
+        return _fmaf(t, np.broadcast_to(sa, t.shape), -u).astype(np.float16)
     t = (t * sa).astype(np.float32)
+    if fma == "sub":
+        return _fmaf(np.broadcast_to(-wz, t.shape), np.broadcast_to(ss, t.shape), t).astype(np.float16)
     u = (wz * ss).astype(np.float32)
     return (t - u).astype(np.float32).astype(np.float16)
 

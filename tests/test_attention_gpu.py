@@ -92,13 +92,32 @@ def run_case(gpu, B, H, Hkv, lengths, int4, seed):
                             max_abs_err_vs_kernel_order=float(ek[long_rows].max()), max_abs_err_vs_fp32=float(ef[long_rows].max()),
                             max_abs_err_vs_exact=float(ee[long_rows].max()), max_abs_output=float(np.abs(o[long_rows]).max())))
         assert ee[long_rows].max() <= TOL, f"max abs err vs exact oracle {ee[long_rows].max():.2e}"
-        # against the reference-order ("kernel") and fp32 restatements of these SHORT contexts (64-200 tokens, |out| up to
-        # ~1-2, one fp16 ulp = 2.4e-4 .. 9.8e-4): the restatements' own fp16 roundings (hfma2 de-quantisation, fp16
-        # probabilities, fp16 tree reduction) sit up to 1.5e-3 away from exact math, so the bar is the measured bound 2e-3
-        # (worst case 1.46e-3, G = 8 / KV4; profiles/round3_attention_parity.json).  At the BASELINE configurations' sizes,
-        # where |out| < 0.25, the plain 1e-3 holds against all three modes: test_config2_* / test_config5_* below.
-        assert ek[long_rows].max() <= 2 * TOL, f"max abs err vs reference-order oracle {ek[long_rows].max():.2e}"
-        assert ef[long_rows].max() <= 2 * TOL, f"max abs err vs fp32 oracle {ef[long_rows].max():.2e}"
+        # The contract against the reference-order ("kernel") and fp32 restatements, per element: within 1e-3 (north_star)
+        # OR within 2 fp16 ulp of the output.  On these SHORT contexts (64-200 tokens, |out| up to ~1-2, one fp16 ulp =
+        # 2.4e-4 .. 9.8e-4) a handful of elements fall outside it - not because the HIP kernel is off (it stays within
+        # 4.9e-4 of exact math, asserted above at 1e-3 and re-checked per exception below) but because the reference's own
+        # fp16 roundings (hfma2 de-quantisation, fp16 probabilities, fp16 tree reduction) sit up to 1.5e-3 from exact math at
+        # |out| ~ 1.  Every such element is listed BY NAME in the parity record (gpurun_out/round4_attention_parity.json ->
+        # profiles/), must be the oracle's deviation rather than the kernel's, and their number is bounded.  At the BASELINE
+        # configurations' sizes (|out| < 0.25) the plain 1e-3 holds against all three modes with no exception:
+        # test_config2_* / test_config5_* below.
+        exceptions = []
+        for mode, err, ref in (("kernel", ek, ref_k), ("fp32", ef, ref_f)):
+            ulps = ulp_diff_f16(o16, ref)
+            beyond = (err > TOL) & (ulps > 2)
+            beyond[~long_rows] = False
+            for b_, h_, d_ in zip(*np.nonzero(beyond)):
+                exceptions.append(dict(vs=mode, seq=int(b_), head=int(h_), dim=int(d_), context=int(pr["lengths"][b_]),
+                                       hip=float(o[b_, h_, d_]), oracle=float(ref[b_, h_, d_]), abs_err=float(err[b_, h_, d_]),
+                                       fp16_ulps=int(ulps[b_, h_, d_]), hip_vs_exact=float(ee[b_, h_, d_]),
+                                       half_fp16_ulp_of_output=float(np.spacing(np.float16(abs(o[b_, h_, d_])))) / 2))
+        _PARITY_RECORD[f"short_B{B}_H{H}_Hkv{Hkv}_{'kv4' if int4 else 'kv8'}_seed{seed}"]["beyond_1e-3_and_2ulp"] = exceptions
+        _flush_parity()
+        # (the kernel itself: the fp16 rounding of its output - half an ulp - plus < 5e-5 of fp32 / fp16-probability error)
+        assert all(e["hip_vs_exact"] <= e["half_fp16_ulp_of_output"] + 5e-5 for e in exceptions), \
+            f"an exception is the kernel's own error: {exceptions}"
+        assert len(exceptions) <= 1e-3 * int(long_rows.sum()) * H * 128, f"{len(exceptions)} elements beyond 1e-3 and 2 fp16 ulp"
+        assert ek[long_rows].max() <= 2 * TOL and ef[long_rows].max() <= 2 * TOL, "hard ceiling 2e-3"
     return ek.max(), ef.max()
 
 
@@ -356,26 +375,32 @@ def test_attention_quant_fusion_is_bit_identical_to_the_pair(gpu, B, H, Hkv, L, 
 # fp16, fp16 tree reduction: decoderMaskedMultiheadAttentionTemplate.hpp:450-467, 1474-1624, 1794-1845, 1901-1977,
 # 2163-2187).  The HIP kernels compute exact math on the cache integers; north_star's bar is 1e-3 between the two.  Every
 # case goes through the production entry of the decode step (attention + fused quantiser), writes max |err| against the
-# three oracle modes into gpurun_out/round3_attention_parity.json (copied to profiles/), then asserts the plain 1e-3.
+# three oracle modes into gpurun_out/round4_attention_parity.json (copied to profiles/), then asserts the plain 1e-3.
 # ---------------------------------------------------------------------------------------------------------------------
 _PARITY_RECORD = {}
 
 
-def _record_parity(name, entry):
+def _flush_parity():
     import json
     import os
-    _PARITY_RECORD[name] = entry
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     d = os.path.join(root, "gpurun_out")
     try:
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "round3_attention_parity.json"), "w") as f:
-            json.dump(dict(tolerance=TOL, note="max |HIP fp16 output - oracle| over the sampled sequences x all heads x 128 "
-                                              "dims; oracle modes: kernel = the reference's own precisions / order, fp32 = "
-                                              "fp16-rounded cache values + fp64 math, exact = un-rounded de-quantisation",
+        with open(os.path.join(d, "round4_attention_parity.json"), "w") as f:
+            json.dump(dict(tolerance=TOL, contract="per element: |HIP - reference-order oracle| <= 1e-3 OR <= 2 fp16 ulp; elements "
+                                                   "beyond it are listed by name under beyond_1e-3_and_2ulp (short contexts only)",
+                           note="max |HIP fp16 output - oracle| over the sampled sequences x all heads x 128 "
+                                "dims; oracle modes: kernel = the reference's own precisions / order, fp32 = "
+                                "fp16-rounded cache values + fp64 math, exact = un-rounded de-quantisation",
                            cases=_PARITY_RECORD), f, indent=1, sort_keys=True)
     except OSError:
         pass
+
+
+def _record_parity(name, entry):
+    _PARITY_RECORD[name] = entry
+    _flush_parity()
 
 
 def reference_order_case(gpu, name, B, L, int4, sample, H=32, Hkv=8, seed=3):

@@ -520,6 +520,48 @@ def test_config2_per_channel_full_shapes_fp16(gpu, M, N, K):
     assert ulp_diff_f16(out.cpu().numpy(), w4a8.epilogue_per_chn(ref.cpu().numpy().astype(np.int32), ws, sa, wz, ss)).max() == 0
 
 
+@pytest.mark.parametrize("N,K", [(28672, 4096), (4096, 14336), (6144, 4096), (4096, 4096)])
+def test_epilogue_fma_envelope(gpu, N, K):
+    """The reference's per-channel epilogue line (gemm_cuda.cu:586) may be contracted by nvcc (--fmad=true is its default);
+    the reference cannot be compiled here, so WHICH rounding sequence its binary uses is unpinned.  This records, at the
+    BASELINE configs[1] shapes, how many fp16 outputs differ between the un-contracted evaluation (what the HIP kernels
+    compute, bit for bit) and the two legal contractions, and pins the envelope: never more than one fp16 ulp."""
+    import json
+    import os
+    import qserve_backend.qgemm_w4a8_per_chn as op
+    M = 64
+    g = torch.Generator(device=gpu).manual_seed(N + K + 5)
+    W = torch.randint(-128, 128, (N, K // 2), dtype=torch.int8, device=gpu, generator=g)
+    A = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=gpu, generator=g)
+    acc = int_matmul_torch(A, unpack_qweight_torch(W)).cpu().numpy().astype(np.int32)
+    r = np.random.default_rng(N + K + 5)
+    ws = r.uniform(0.002, 0.02, N).astype(np.float16)
+    wz = (r.integers(0, 16, N).astype(np.float16) * ws).astype(np.float16)
+    sa = r.uniform(0.005, 0.05, M).astype(np.float16)
+    ss = (sa.astype(np.float32) * A.cpu().numpy().astype(np.int64).sum(1).astype(np.float32)).astype(np.float16)
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+    op.gemm_forward_cuda(A, W, dev(ws), dev(sa), dev(wz), dev(ss), out)
+    o = out.cpu().numpy()
+    plain = w4a8.epilogue_per_chn(acc, ws, sa, wz, ss)
+    fma = w4a8.epilogue_per_chn(acc, ws, sa, wz, ss, fma=True)
+    sub = w4a8.epilogue_per_chn(acc, ws, sa, wz, ss, fma="sub")
+    assert ulp_diff_f16(o, plain).max() == 0, "the HIP epilogue is the un-contracted evaluation, bit for bit"
+    d_fma, d_sub = ulp_diff_f16(plain, fma), ulp_diff_f16(plain, sub)
+    assert d_fma.max() <= 1 and d_sub.max() <= 1, "a contraction moves an output by at most one fp16 ulp"
+    rec = dict(shape=[M, N, K], outputs=int(o.size), hip_equals="no-contraction evaluation (every output)",
+               differ_from_fmaf_t_sa_minus_u=int((d_fma != 0).sum()), differ_from_fmaf_minus_wz_ss_plus_t=int((d_sub != 0).sum()),
+               max_fp16_ulps=int(max(d_fma.max(), d_sub.max())))
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(path, exist_ok=True)
+        fn = os.path.join(path, "round4_epilogue_fma_envelope.json")
+        allrec = json.load(open(fn)) if os.path.exists(fn) else {}
+        allrec[f"{M}x{N}x{K}"] = rec
+        json.dump(allrec, open(fn, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
 def _float_reference(A, sa, Wdeq):
     """A_deq . W_deq^T in float64: what the quantised GEMM approximates (SURVEY 8d config 1 "plumbing" reference)."""
     return (A.astype(np.float64) * sa.astype(np.float64)[:, None]) @ Wdeq.T

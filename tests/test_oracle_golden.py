@@ -277,3 +277,28 @@ def test_torch_cpu_baseline_matches_exact_oracle():
                     p = np.exp(s - s.max())
                     ref = (p / p.sum()) @ Vd
                     assert np.abs(got[b, hk * 2 + g] - ref).max() < 1e-4
+
+
+def test_oracle_fmaf_is_correctly_rounded():
+    """oracle.w4a8._fmaf (the fma = True / "sub" epilogue conventions) against exact rational arithmetic, including results
+    that sit exactly on a float32 rounding boundary before the residual is taken into account."""
+    from fractions import Fraction
+
+    import numpy as np
+
+    from oracle import w4a8
+    r = np.random.default_rng(3)
+    a = (r.standard_normal(3000) * 1000).astype(np.float32)
+    b = r.standard_normal(3000).astype(np.float32)
+    c = (-(a.astype(np.float64) * b) + r.standard_normal(3000) * 1e-3).astype(np.float32)     # cancellation: many low bits matter
+    # constructed ties: a * b = 1 + 2^-24 exactly (midpoint of two float32), c = +-2^-60 decides
+    a[:2] = np.float32(1 + 2.0 ** -12)
+    b[:2] = np.float32((1 + 2.0 ** -24) / (1 + 2.0 ** -12))
+    c[0], c[1] = np.float32(2.0 ** -60), np.float32(-2.0 ** -60)
+    got = w4a8._fmaf(a, b, c)
+    for i in range(a.size):
+        ex = Fraction(float(a[i])) * Fraction(float(b[i])) + Fraction(float(c[i]))
+        g = np.float32(got[i])
+        dg = abs(ex - Fraction(float(g)))
+        for nb in (np.nextafter(g, np.float32(-np.inf)), np.nextafter(g, np.float32(np.inf))):
+            assert abs(ex - Fraction(float(nb))) >= dg, (i, float(a[i]), float(b[i]), float(c[i]), float(g))
