@@ -608,6 +608,26 @@ def main():
             print(f"[bench] end-to-end protocol skipped: {e}", file=sys.stderr)
         eng.lengths.fill_(start_len + args.warmup)
 
+    # ---- the reference's OWN engine running its own benchmark protocol over this backend (when its tree is staged under the
+    # git-ignored oracle/_ref/, scripts/stage_reference.sh): qserve_benchmark.py:process_requests, LLMEngine, scheduler, block
+    # manager, model code - all unchanged - in a child process (scripts/run_reference_engine.py), Llama-3-8B shape, synthetic
+    # random-quantised weights, batch x 1024 -> 512.  Beside e2e_tokens_per_s: same protocol through this repository's engine.
+    if (world == 1 and not args.no_extras and not args.no_prefill and not args.op_by_op and args.model == "llama3-8b"
+            and args.group_size == -1 and not args.kv8 and os.path.isdir(os.path.join(ROOT, "oracle", "_ref", "qserve"))):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_reference_engine.py"), "--mode", "protocol",
+                                "--backend", "ext", "--batch", str(args.batch), "--prompt-len", str(args.prompt_len),
+                                "--gen-len", str(args.max_new), "--rounds", "2"], capture_output=True, text=True, timeout=600)
+            rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            extra.update(reference_engine_tokens_per_s=rec["reference_engine_tokens_per_s"],
+                         reference_engine_note="the reference's unchanged LLMEngine + qserve_benchmark.py:process_requests over "
+                                               "the compiled qserve_backend extension of this repository (staged copy under "
+                                               "oracle/_ref/, second of two rounds as the reference's script reports; eager "
+                                               "launches, the reference's op-by-op sequence and Python per step); logits "
+                                               f"finite: {rec['rounds'][-1]['all_logits_finite']}")
+        except Exception as e:                                    # absent extension, no JSON line, time-out ...
+            print(f"[bench] reference engine leg skipped: {type(e).__name__}: {str(e)[:200]}", file=sys.stderr)
+
     # ---- collective cost (N > 1): one fp16 all-reduce of the row-parallel partial [batch, hidden] ---------------------
     if world > 1:
         buf = torch.zeros_like(eng.proj_out)

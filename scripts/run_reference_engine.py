@@ -145,10 +145,46 @@ def run_ragged(args):
                           all_logits_finite=finite[0])))
 
 
+def trace_ops():
+    """Debugging aid (--trace-ops): print every backend call with its tensor shapes and synchronise after it."""
+    import importlib
+
+    import torch
+    for m in ("qgemm_w4a8_per_chn", "qgemm_w4a8_per_group", "fused_attention", "fused_kernels", "layernorm_ops", "activation_ops"):
+        mod = importlib.import_module("qserve_backend." + m)
+        for name in dir(mod):
+            fn = getattr(mod, name)
+            if name.startswith("_") or not callable(fn) or isinstance(fn, type):
+                continue
+
+            def wrap(fn=fn, label=m + "." + name):
+                def inner(*a, **k):
+                    print("[op]", label, [tuple(x.shape) if isinstance(x, torch.Tensor) else x for x in a], flush=True)
+                    r = fn(*a, **k)
+                    torch.cuda.synchronize()
+                    return r
+                return inner
+            setattr(mod, name, wrap())
+    import flash_attn.flash_attn_interface as fai
+    orig = fai.flash_attn_varlen_func
+
+    def fa(*a, **k):
+        print("[op] flash_attn_varlen_func", [tuple(x.shape) if isinstance(x, torch.Tensor) else x for x in a], k, flush=True)
+        r = orig(*a, **k)
+        torch.cuda.synchronize()
+        return r
+    fai.flash_attn_varlen_func = fa
+    import qserve.modeling.models.llama_w4a8_unpad as mm
+    if hasattr(mm, "flash_attn_varlen_func"):
+        mm.flash_attn_varlen_func = fa
+
+
 def run_protocol(args):
     import torch
     compat = transformers_compat()
     EngineArgs, LLMEngine, SamplingParams, backend_kind = import_reference(args.backend)
+    if args.trace_ops:
+        trace_ops()
     sys.path.insert(0, REF)
     import qserve_benchmark as qb                                 # the reference's benchmark driver, unchanged
     cfg = dict(LLAMA3_8B)
@@ -165,20 +201,34 @@ def run_protocol(args):
         for rnd in range(args.rounds):
             engine = LLMEngine.from_engine_args(ea)
             engine.profiling_mode = True
-            # random-initialised parameters (quant_path=None is the reference's own dummy-weight path): make the fp16 ones
-            # finite and small so that no NaN reaches the sampler - parameters only, not code
+            # quant_path=None is the reference's own dummy-weight path: its tensors are torch.empty.  Fill them with synthetic
+            # random-quantised values of the right scale (parameters only, not code) so that activations stay O(1) through
+            # 32 layers and the sampler always sees finite logits - the same synthetic model as bench.py's own engine
             model = engine.driver_worker.model_runner.model
             g = torch.Generator(device="cuda").manual_seed(0)
-            for n, p in model.named_parameters():
-                if p.dtype == torch.float16:
-                    p.data.copy_((torch.rand(p.shape, generator=g, device=p.device) * 0.01 + 0.002).to(torch.float16))
-            for n, b in model.named_buffers():
-                if b.dtype == torch.float16:
-                    b.data.copy_((torch.rand(b.shape, generator=g, device=b.device) * 0.01 + 0.002).to(torch.float16))
+            sd = model.state_dict()
+            for n, t in sd.items():
+                if n.endswith("qweight"):
+                    t.copy_(torch.randint(-128, 128, t.shape, generator=g, device=t.device, dtype=torch.int8))
+                elif n.endswith("s1_scales"):
+                    t.copy_((torch.rand(t.shape, generator=g, device=t.device) * 0.001 + 0.0005).to(t.dtype))
+                    sd[n[:-len("s1_scales")] + "s1_szeros"].copy_((t.float() * 7.5).to(t.dtype))
+                elif n.endswith("s1_szeros"):
+                    pass
+                elif "layernorm" in n or n.endswith("norm.weight"):
+                    t.fill_(1.0)
+                elif n.endswith("embed_tokens.weight"):
+                    t.copy_((torch.randn(t.shape, generator=g, device=t.device) * 0.5).to(t.dtype))
+                elif n.endswith("lm_head.weight"):
+                    t.copy_((torch.randn(t.shape, generator=g, device=t.device) * 0.02).to(t.dtype))
+                elif t.dtype == torch.float16:
+                    t.copy_((torch.rand(t.shape, generator=g, device=t.device) * 0.01).to(t.dtype))
+            finite = [True]
+            model.lm_head.register_forward_hook(lambda _m, _i, out: finite.__setitem__(0, finite[0] and bool(torch.isfinite(out).all())))
             t_lis, num_tokens = qb.process_requests(engine, batch_size=args.batch, prompt_len=args.prompt_len,
                                                     generation_len=args.gen_len)
             res.append(dict(round=rnd, tokens=num_tokens, seconds=round(sum(t_lis), 4),
-                            tokens_per_s=round(num_tokens / sum(t_lis), 1)))
+                            tokens_per_s=round(num_tokens / sum(t_lis), 1), all_logits_finite=finite[0]))
             del engine, model
             torch.cuda.empty_cache()
     print(json.dumps(dict(mode="protocol", backend=args.backend, backend_module=backend_kind, transformers_compat=compat,
@@ -200,5 +250,6 @@ if __name__ == "__main__":
     ap.add_argument("--gen-len", type=int, default=512)
     ap.add_argument("--layers", type=int, default=0)
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--trace-ops", action="store_true", help="debugging: print and synchronise every backend call")
     a = ap.parse_args()
     (run_ragged if a.mode == "ragged" else run_protocol)(a)

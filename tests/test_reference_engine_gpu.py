@@ -74,8 +74,8 @@ def test_staged_reference_is_the_reference_byte_for_byte():
 def test_unchanged_reference_engine_ragged_inflight_batch(gpu, group_size):
     ext = run_engine("--mode", "ragged", "--backend", "ext", "--group-size", str(group_size))
     mir = run_engine("--mode", "ragged", "--backend", "ctypes", "--group-size", str(group_size))
-    assert "compiled" in ext["backend_module"] and "qserve_amd/backend" in mir["backend_module"], (ext["backend_module"],
-                                                                                                  mir["backend_module"])
+    assert "qserve_backend_ext" in ext["backend_module"] and "qserve_amd/backend" in mir["backend_module"], \
+        (ext["backend_module"], mir["backend_module"])
     for rec in (ext, mir):
         assert rec["all_logits_finite"] and rec["lm_head_calls"] == rec["engine_steps"]
         gens = rec["generation_lengths"]
