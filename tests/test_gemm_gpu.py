@@ -525,7 +525,8 @@ def test_epilogue_fma_envelope(gpu, N, K):
     """The reference's per-channel epilogue line (gemm_cuda.cu:586) may be contracted by nvcc (--fmad=true is its default);
     the reference cannot be compiled here, so WHICH rounding sequence its binary uses is unpinned.  This records, at the
     BASELINE configs[1] shapes, how many fp16 outputs differ between the un-contracted evaluation (what the HIP kernels
-    compute, bit for bit) and the two legal contractions, and pins the envelope: never more than one fp16 ulp."""
+    compute, bit for bit) and the two legal contractions, and pins the envelope: one fp32 ulp of the larger product (an
+    absolute step that is many fp16 ulps of the result where the products cancel)."""
     import json
     import os
     import qserve_backend.qgemm_w4a8_per_chn as op
@@ -547,10 +548,22 @@ def test_epilogue_fma_envelope(gpu, N, K):
     sub = w4a8.epilogue_per_chn(acc, ws, sa, wz, ss, fma="sub")
     assert ulp_diff_f16(o, plain).max() == 0, "the HIP epilogue is the un-contracted evaluation, bit for bit"
     d_fma, d_sub = ulp_diff_f16(plain, fma), ulp_diff_f16(plain, sub)
-    assert d_fma.max() <= 1 and d_sub.max() <= 1, "a contraction moves an output by at most one fp16 ulp"
+    # The envelope is ABSOLUTE, not "one fp16 ulp": a contraction removes one fp32 rounding of t * sa (or of w_sz * a_ssum), i.e.
+    # it moves the result by at most one fp32 ulp of that product - but where the two products nearly cancel the result is small
+    # and that same absolute step is many fp16 ulps OF THE RESULT (measured: up to ~20 at these shapes).
+    t32 = (acc.astype(np.float32) * ws.astype(np.float32)[None, :]).astype(np.float32) * sa.astype(np.float32)[:, None]
+    u32 = wz.astype(np.float32)[None, :] * ss.astype(np.float32)[:, None]
+    bound = np.spacing(np.maximum(np.abs(t32), np.abs(u32)).astype(np.float32)).astype(np.float64) \
+        + np.spacing(np.abs(plain).astype(np.float16)).astype(np.float64)            # + the fp16 output rounding
+    for other in (fma, sub):
+        assert (np.abs(plain.astype(np.float64) - other.astype(np.float64)) <= bound).all()
+    a_fma = np.abs(plain.astype(np.float64) - fma.astype(np.float64))
+    a_sub = np.abs(plain.astype(np.float64) - sub.astype(np.float64))
     rec = dict(shape=[M, N, K], outputs=int(o.size), hip_equals="no-contraction evaluation (every output)",
                differ_from_fmaf_t_sa_minus_u=int((d_fma != 0).sum()), differ_from_fmaf_minus_wz_ss_plus_t=int((d_sub != 0).sum()),
-               max_fp16_ulps=int(max(d_fma.max(), d_sub.max())))
+               max_fp16_ulps_of_the_result=int(max(d_fma.max(), d_sub.max())), max_abs_difference=float(max(a_fma.max(), a_sub.max())),
+               max_abs_output=float(np.abs(plain.astype(np.float64)).max()),
+               bound="one fp32 ulp of the larger product + one fp16 ulp of the result (asserted per element)")
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
         os.makedirs(path, exist_ok=True)
