@@ -35,8 +35,8 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def _compile(src, force, extra):
-    obj = os.path.join(BUILD, src.replace(".hip", ".o"))
+def _compile(src, force, extra, build_dir):
+    obj = os.path.join(build_dir, src.replace(".hip", ".o"))
     srcp = os.path.join(CSRC, src)
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), _deps_mtime())):
         return obj, False
@@ -51,26 +51,26 @@ def build(force=False, verbose=True, extra=(), timing=False):
     """timing=True: the measurement build (-DQS_TIMING: ablation switches that turn kernel parts off, timeline traces) ->
     libqserve_amd_timing.so from its own object directory; never loaded by the product (qserve_amd/_lib.py loads it only when
     QS_AMD_LIBRARY names it - scripts/)."""
-    global BUILD, LIB
+    build_dir, lib = BUILD, LIB      # (locals: a timing build must not redirect later product builds of this process)
     if timing:
-        BUILD, LIB = os.path.join(HERE, "_build_timing"), os.path.join(HERE, "libqserve_amd_timing.so")
+        build_dir, lib = os.path.join(HERE, "_build_timing"), os.path.join(HERE, "libqserve_amd_timing.so")
         extra = list(extra) + ["-DQS_TIMING"]
-    os.makedirs(BUILD, exist_ok=True)
+    os.makedirs(build_dir, exist_ok=True)
     extra = list(extra) + os.environ.get("QS_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DQS_RING_TRACE (timing tools)
     with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
-        res = list(ex.map(lambda s: _compile(s, force, list(extra)), SOURCES))
+        res = list(ex.map(lambda s: _compile(s, force, list(extra), build_dir), SOURCES))
     objs = [o for o, _ in res]
     rebuilt = any(r for _, r in res)
-    if rebuilt or not os.path.exists(LIB) or force:
-        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+    if rebuilt or not os.path.exists(lib) or force:
+        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
         if verbose:
-            print(f"[qserve_amd.build] linked {LIB}")
+            print(f"[qserve_amd.build] linked {lib}")
     elif verbose:
-        print(f"[qserve_amd.build] up to date: {LIB}")
-    return LIB
+        print(f"[qserve_amd.build] up to date: {lib}")
+    return lib
 
 
 if __name__ == "__main__":

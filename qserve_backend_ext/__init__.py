@@ -20,7 +20,15 @@ def load():
     `qserve_backend_ext.<module>`.  Called on package import when the object exists; raises ImportError otherwise."""
     global _C
     if _C is None:
+        import os
         import torch  # noqa: F401  (libtorch must be loaded before the extension)
+        alt = os.environ.get("QS_AMD_LIBRARY")
+        if alt and os.path.realpath(alt) != os.path.realpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..",
+                                                                          "qserve_amd", "libqserve_amd.so")):
+            # the extension is linked (rpath) against qserve_amd/libqserve_amd.so; with QS_AMD_LIBRARY naming another build the
+            # ctypes side would load a SECOND copy of the library - two sets of variant switches and scratch areas in one process
+            raise ImportError(f"qserve_backend_ext is linked against qserve_amd/libqserve_amd.so, but QS_AMD_LIBRARY={alt} "
+                              "selects another library for the ctypes side: unset it to use the compiled extension")
         try:
             _C = importlib.import_module(__name__ + "._C")
         except ImportError as e:

@@ -30,14 +30,20 @@ def build(force=False, verbose=True):
     rocm = os.environ.get("ROCM_PATH") or os.environ.get("ROCM_HOME") or "/opt/rocm"
     inc = [os.path.join(ROOT, "include"), os.path.join(rocm, "include")] + ce.include_paths()
     cxx = os.environ.get("CXX") or shutil.which("g++") or "g++"
+    import torch
+    abi = int(getattr(torch._C, "_GLIBCXX_USE_CXX11_ABI", True))          # the ABI the installed torch was built with
     cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
-           "-DTORCH_EXTENSION_NAME=_C", "-DTORCH_API_INCLUDE_EXTENSION_H", "-D_GLIBCXX_USE_CXX11_ABI=1",
+           "-DTORCH_EXTENSION_NAME=_C", "-DTORCH_API_INCLUDE_EXTENSION_H", f"-D_GLIBCXX_USE_CXX11_ABI={abi}",
            "-Wno-deprecated-declarations"]
     cmd += ["-I" + sysconfig.get_paths()["include"]] + ["-I" + i for i in inc]
     cmd += [SRC, "-o", OUT]
-    tl = os.path.join(os.path.dirname(ce.__file__), "..", "lib")
-    tl = os.path.abspath(tl)
-    cmd += ["-L" + tl, "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", "-ltorch_python",
+    tl = (ce.library_paths() or [os.path.abspath(os.path.join(os.path.dirname(ce.__file__), "..", "lib"))])[0]
+    # the libraries this torch build ships (a ROCm wheel: torch_hip / c10_hip); only those that exist are named
+    libs = [l for l in ("torch", "torch_cpu", "torch_hip", "c10", "c10_hip", "torch_python")
+            if glob.glob(os.path.join(tl, "lib" + l + ".so*"))]
+    if "torch_hip" not in libs:
+        raise RuntimeError(f"the installed torch ({torch.__version__}) is not a ROCm build: libtorch_hip is missing from {tl}")
+    cmd += ["-L" + tl] + ["-l" + l for l in libs] + [
             "-L" + os.path.dirname(lib), "-l:libqserve_amd.so",
             "-Wl,-rpath,$ORIGIN/../qserve_amd", "-Wl,-rpath," + tl]
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -41,11 +41,23 @@ void need(const torch::Tensor& t, at::ScalarType dt, const char* name, bool cont
 }
 
 // ---- qgemm_w4a8_per_chn / per_group / w8a8 -----------------------------------------------------------------------------
+// M, N come from out_feats and K from in_feats (as the reference derives them, gemm_cuda.cu:604-613); everything else must fit,
+// or the kernels would read out of bounds.  pack = weights per byte of `kernel` (2 for the 4-bit layouts).
+void gemm_shapes(const torch::Tensor& in_feats, const torch::Tensor& kernel, const torch::Tensor& out_feats, int pack) {
+    TORCH_CHECK(in_feats.dim() >= 2 && kernel.dim() == 2 && out_feats.dim() >= 2, "in_feats / kernel / out_feats must be matrices");
+    const int64_t M = out_feats.size(-2), N = out_feats.size(-1), K = in_feats.size(1);
+    TORCH_CHECK(in_feats.numel() == M * K, "in_feats holds ", in_feats.numel(), " values, out_feats implies ", M, " x ", K);
+    TORCH_CHECK(kernel.size(0) == N && kernel.size(1) * pack == K, "kernel ", kernel.sizes(), " does not match N = ", N, ", K = ", K);
+}
+
 void gemm_per_chn(torch::Tensor in_feats, torch::Tensor kernel, torch::Tensor wscales, torch::Tensor ascales,
                   torch::Tensor w_szs, torch::Tensor a_ssums, torch::Tensor out_feats) {
     need(in_feats, at::kChar, "in_feats"); need(kernel, at::kChar, "kernel"); need(out_feats, at::kHalf, "out_feats");
     need(wscales, at::kHalf, "wscales"); need(ascales, at::kHalf, "ascales"); need(w_szs, at::kHalf, "w_szs");
     need(a_ssums, at::kHalf, "a_ssums");
+    gemm_shapes(in_feats, kernel, out_feats, 2);
+    TORCH_CHECK(wscales.numel() >= out_feats.size(-1) && w_szs.numel() >= out_feats.size(-1), "wscales / w_szs must hold one value per output channel");
+    TORCH_CHECK(ascales.numel() >= out_feats.size(-2) && a_ssums.numel() >= out_feats.size(-2), "ascales / a_ssums must hold one value per token");
     const DeviceGuard guard(in_feats.device());
     // shapes as the reference takes them (gemm_cuda.cu:604-613)
     QS_CALL(qs_w4a8_per_chn_gemm(in_feats.data_ptr<int8_t>(), kernel.data_ptr<int8_t>(), wscales.data_ptr(), ascales.data_ptr(),
@@ -57,6 +69,12 @@ void gemm_per_group(torch::Tensor in_feats, torch::Tensor kernel, torch::Tensor 
     need(in_feats, at::kChar, "in_feats"); need(kernel, at::kChar, "kernel"); need(zeros, at::kChar, "zeros");
     need(scales_i8, at::kChar, "scales_i8"); need(wscales, at::kHalf, "wscales"); need(ascales, at::kHalf, "ascales");
     need(out_feats, at::kHalf, "out_feats");
+    gemm_shapes(in_feats, kernel, out_feats, 2);
+    {
+        const int64_t N = out_feats.size(-1), K = in_feats.size(1);
+        TORCH_CHECK(zeros.numel() >= (K / 128) * N && scales_i8.numel() >= (K / 128) * N, "zeros / scales_i8 must hold K/128 x N values");
+        TORCH_CHECK(wscales.numel() >= N && ascales.numel() >= out_feats.size(-2), "wscales / ascales: one value per channel / token");
+    }
     const DeviceGuard guard(in_feats.device());
     QS_CALL(qs_w4a8_per_group_gemm(in_feats.data_ptr<int8_t>(), kernel.data_ptr<int8_t>(), zeros.data_ptr<int8_t>(),
                                    scales_i8.data_ptr<int8_t>(), wscales.data_ptr(), ascales.data_ptr(), out_feats.data_ptr(),
@@ -66,6 +84,7 @@ void gemm_w8a8(torch::Tensor in_feats, torch::Tensor kernel, torch::Tensor wscal
                torch::Tensor out_feats) {
     need(in_feats, at::kChar, "in_feats"); need(kernel, at::kChar, "kernel"); need(wscales, at::kHalf, "wscales");
     need(ascales, at::kHalf, "ascales"); need(out_feats, at::kHalf, "out_feats");
+    gemm_shapes(in_feats, kernel, out_feats, 1);
     const DeviceGuard guard(in_feats.device());
     QS_CALL(qs_w8a8_gemm(in_feats.data_ptr<int8_t>(), kernel.data_ptr<int8_t>(), wscales.data_ptr(), ascales.data_ptr(),
                          out_feats.data_ptr(), (int)out_feats.size(-2), (int)out_feats.size(-1), (int)in_feats.size(1),
@@ -134,9 +153,19 @@ torch::Tensor compute_padding_offsets(const torch::Tensor cu_seqlens, const int 
 }
 
 // ---- fused_kernels (per-token overloads) ---------------------------------------------------------------------------------
+// out and input hold the same number of values; the per-token vectors one value per row
+void row_shapes(const torch::Tensor& out, const torch::Tensor& input, int hidden, const torch::Tensor* scale,
+                const torch::Tensor* sum) {
+    TORCH_CHECK(hidden > 0 && out.numel() == input.numel(), "out must hold as many values as input");
+    const int64_t rows = input.numel() / hidden;
+    if (scale) TORCH_CHECK(scale->numel() >= rows, "scale must hold one value per token");
+    if (sum) TORCH_CHECK(sum->numel() >= rows, "input_sum must hold one value per token");
+}
+
 void invoke_quant(torch::Tensor& out, torch::Tensor& input, torch::Tensor& scale) {
     need(out, at::kChar, "out"); need(input, at::kHalf, "input"); need(scale, at::kHalf, "scale");
     const int hidden = (int)input.size(-1);
+    row_shapes(out, input, hidden, &scale, nullptr);
     const DeviceGuard guard(out.device());
     QS_CALL(qs_invoke_quant(out.data_ptr<int8_t>(), input.data_ptr(), nullptr, scale.data_ptr(), (int)(input.numel() / hidden),
                             hidden, cur_stream()));
@@ -145,6 +174,7 @@ void invoke_quant_fuse_sum(torch::Tensor& out, torch::Tensor& input, torch::Tens
     need(out, at::kChar, "out"); need(input, at::kHalf, "input"); need(input_sum, at::kHalf, "input_sum");
     need(scale, at::kHalf, "scale");
     const int hidden = (int)input.size(-1);
+    row_shapes(out, input, hidden, &scale, &input_sum);
     const DeviceGuard guard(out.device());
     QS_CALL(qs_invoke_quant(out.data_ptr<int8_t>(), input.data_ptr(), input_sum.data_ptr(), scale.data_ptr(),
                             (int)(input.numel() / hidden), hidden, cur_stream()));
@@ -155,6 +185,8 @@ void rms_norm(torch::Tensor& out, torch::Tensor& input, torch::Tensor& weight, f
     TORCH_CHECK(!use_quant, "rms_norm(use_quant=True) belongs to the W8A8 path (out of scope)");
     need(out, at::kHalf, "out"); need(input, at::kHalf, "input"); need(weight, at::kHalf, "weight");
     const int hidden = (int)input.size(-1);
+    row_shapes(out, input, hidden, nullptr, nullptr);
+    TORCH_CHECK(weight.numel() == hidden, "weight must hold one value per hidden element");
     const DeviceGuard guard(out.device());
     QS_CALL(qs_rms_norm(out.data_ptr(), input.data_ptr(), weight.data_ptr(), epsilon, (int)(input.numel() / hidden), hidden,
                         cur_stream()));
@@ -165,6 +197,8 @@ void rms_norm_general(torch::Tensor& out, torch::Tensor& input, torch::Tensor& w
     need(out, at::kChar, "out"); need(input, at::kHalf, "input"); need(weight, at::kHalf, "weight");
     need(scaling, at::kHalf, "scaling");
     const int hidden = (int)input.size(-1);
+    row_shapes(out, input, hidden, &scaling, nullptr);
+    TORCH_CHECK(weight.numel() == hidden, "weight must hold one value per hidden element");
     const DeviceGuard guard(out.device());
     QS_CALL(qs_rms_norm_general(out.data_ptr<int8_t>(), input.data_ptr(), weight.data_ptr(), nullptr, scaling.data_ptr(), epsilon,
                                 (int)(input.numel() / hidden), hidden, cur_stream()));
@@ -175,6 +209,8 @@ void rms_norm_general_fuse_sum(torch::Tensor& out, torch::Tensor& input, torch::
     need(out, at::kChar, "out"); need(input, at::kHalf, "input"); need(weight, at::kHalf, "weight");
     need(input_sum, at::kHalf, "input_sum"); need(scaling, at::kHalf, "scaling");
     const int hidden = (int)input.size(-1);
+    row_shapes(out, input, hidden, &scaling, &input_sum);
+    TORCH_CHECK(weight.numel() == hidden, "weight must hold one value per hidden element");
     const DeviceGuard guard(out.device());
     QS_CALL(qs_rms_norm_general(out.data_ptr<int8_t>(), input.data_ptr(), weight.data_ptr(), input_sum.data_ptr(),
                                 scaling.data_ptr(), epsilon, (int)(input.numel() / hidden), hidden, cur_stream()));
@@ -184,6 +220,7 @@ void rms_norm_general_fuse_sum(torch::Tensor& out, torch::Tensor& input, torch::
 void silu_and_mul(torch::Tensor& out, torch::Tensor& input) {
     need(out, at::kHalf, "out"); need(input, at::kHalf, "input");
     const int d = (int)input.size(-1) / 2;
+    TORCH_CHECK(input.size(-1) % 2 == 0 && out.numel() * 2 == input.numel(), "out must hold half as many values as input");
     const DeviceGuard guard(out.device());
     QS_CALL(qs_silu_and_mul(out.data_ptr(), input.data_ptr(), (int)(input.numel() / input.size(-1)), d, cur_stream()));
 }

@@ -197,3 +197,36 @@ def test_extension_runs_inside_a_hipgraph_on_the_capturing_stream(gpu, ext):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.gpu
+def test_extension_rejects_mismatched_shapes(gpu, ext):
+    """M and N come from out_feats, K from in_feats (as in the reference): everything else must fit, or the kernels would
+    read out of bounds - the compiled boundary refuses instead of launching."""
+    i8, f16 = torch.int8, torch.float16
+    M, N, K = 16, 128, 256
+    A = torch.zeros((M, K), dtype=i8, device=gpu)
+    W = torch.zeros((N, K // 2), dtype=i8, device=gpu)
+    vN, vM = torch.ones((N,), dtype=f16, device=gpu), torch.ones((M,), dtype=f16, device=gpu)
+    out = torch.empty((M, N), dtype=f16, device=gpu)
+    ext.qgemm_w4a8_per_chn.gemm_forward_cuda(A, W, vN, vM, vN, vM, out)                       # well-formed: runs
+    with pytest.raises(RuntimeError, match="kernel"):
+        ext.qgemm_w4a8_per_chn.gemm_forward_cuda(A, W[:, :-8].contiguous(), vN, vM, vN, vM, out)   # K mismatch
+    with pytest.raises(RuntimeError, match="kernel"):
+        ext.qgemm_w4a8_per_chn.gemm_forward_cuda(A, W[:-32].contiguous(), vN, vM, vN, vM, out)     # N mismatch
+    with pytest.raises(RuntimeError, match="in_feats"):
+        ext.qgemm_w4a8_per_chn.gemm_forward_cuda(A[:-1].contiguous(), W, vN, vM, vN, vM, out)      # rows != M
+    with pytest.raises(RuntimeError, match="per output channel"):
+        ext.qgemm_w4a8_per_chn.gemm_forward_cuda(A, W, vN[:-1].contiguous(), vM, vN, vM, out)
+    with pytest.raises(RuntimeError, match="per token"):
+        ext.qgemm_w4a8_per_chn.gemm_forward_cuda(A, W, vN, vM[:-1].contiguous(), vN, vM, out)
+    x = torch.zeros((M, K), dtype=f16, device=gpu)
+    q = torch.empty((M, K), dtype=i8, device=gpu)
+    with pytest.raises(RuntimeError, match="as many values"):
+        ext.fused_kernels.invoke_quant(q[:-1].contiguous(), x, vM)
+    with pytest.raises(RuntimeError, match="per token"):
+        ext.fused_kernels.invoke_quant(q, x, vM[:-2].contiguous())
+    with pytest.raises(RuntimeError, match="hidden element"):
+        ext.layernorm_ops.rms_norm_general(q, x, torch.ones((K - 8,), dtype=f16, device=gpu), vM, 1e-5, True)
+    with pytest.raises(RuntimeError, match="half as many"):
+        ext.activation_ops.silu_and_mul(torch.empty((M, K), dtype=f16, device=gpu), x)
