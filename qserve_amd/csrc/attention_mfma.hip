@@ -132,6 +132,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     __shared__ __attribute__((aligned(16))) _Float16 s_knew[DH];
     __shared__ __attribute__((aligned(16))) _Float16 s_vnew[DH];                // the new token's raw v
     __shared__ float s_cur[16];
+    __shared__ float2 s_qc[16];                                                 // per head: (qsum, Qoff) - see the operand build
     __shared__ float s_m[NW][G], s_l[NW][G];
     __shared__ int s_flag;                                                      // service wave -> unit waves: operands ready
 
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
             glds4(kb_s, &s_knew[0]);
             glds4(vb_s, &s_vnew[0]);
         }
+        stamp(5);      // (trace: service wave - entry requests issued)
     }
     if (tl < 0) return;
     stamp(1);
@@ -379,9 +381,10 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         }
     };
     if (wave != SVC) {
-        // (round 4: requesting the wave's second unit later - when group A of the first has landed, after the operand flag,
-        //  after a fixed 2k / 4k cycles - measured: no gain at 640 ... 2 000 tokens; the first data of a wave is not earlier
-        //  for a smaller first burst.  HISTORY.md.)
+        // (round 4, measured and dropped - HISTORY.md: the wave's second unit requested later (after the hand-over, when group A
+        //  of the first unit has landed, after fixed delays), the first unit's requests at raised issue priority, raised priority
+        //  for the waves that own one unit more than the others, the service wave taking a graded share of the units: each within
+        //  +-0.3 us of this form at 640 ... 2 000 tokens, none better everywhere)
         first_round(3);
         if (use_flag) {
             while (*(volatile __attribute__((address_space(3))) int*)(&s_flag) == 0) __builtin_amdgcn_s_sleep(1);
@@ -393,6 +396,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     } else {
         if constexpr (!(EXP & 4)) {
             // ordinary loads: this wave's queue carries nothing else, the compiler's own counted waits are right here
+            stamp(6);  // (trace: service wave - phase A entered)
             RopeCS cs;
             if (rope_tab && tl < rope_tab_len) {
                 const float2 t = rope_tab[(size_t)tl * 64 + lane];   // same double-evaluated, float-rounded values
@@ -402,6 +406,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
                 cs = rope_coef(lane, tl, rope_base, DH);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the raw q / k / v rows have landed (this wave's queue holds nothing else)
+            stamp(7);  // (trace: service wave - q / k / v and the RoPE coefficients are here)
 #pragma unroll
             for (int h = 0; h < G; ++h) {                      // rotated in place: a lane touches only its own two elements
                 _Float16 a, bb;
@@ -415,13 +420,36 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
             s_knew[64 + lane] = kbb;
             // B operand of Q.K^T for lane (head li, kg = tg), MFMA w: dims 32tg + 8w + {0,4,1,5,2,6,3,7}; the positions that
             // meet hi-nibble operands (1024 + 16 n) carry q/16 (same wave wrote s_q: LDS keeps a wave's accesses in order)
+            // The per-head constants of the offset form are summed HERE, from the values being written (round 4; rounds 2-3: by
+            // every unit wave after the hand-over, from s_qp - 4 LDS reads and 4 cross-lane shuffles on the critical path of
+            // every wave's first Q.K^T, ~3 000 cycles in the trace): qsum = sum_d q_eff_d, Qoff = sum over the operand of
+            // 1024 * q' (what the 1024+n / 1024+16n operand form adds to the raw dot product); q_eff = what the MFMA effectively
+            // multiplies n by.  Same summation order as before (per lane over its 32 dims, then lanes xor 16, xor 32).
+            float se = 0.f, so = 0.f;   // sums over lo-form / hi-form operand positions of this lane's 32 dims
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 h8 x = {0, 0, 0, 0, 0, 0, 0, 0};                       // heads >= G: zero rows of the operand
                 if (li < G) x = *reinterpret_cast<const h8*>(&s_q[li][32 * tg + 8 * w]);
                 const _Float16 s16 = (_Float16)0.0625f;
-                *reinterpret_cast<h8*>(&s_qp[li][32 * tg + 8 * w]) =
-                    (h8){x[0], x[4], x[1] * s16, x[5] * s16, x[2], x[6], x[3] * s16, x[7] * s16};
+                const h8 op = {x[0], x[4], x[1] * s16, x[5] * s16, x[2], x[6], x[3] * s16, x[7] * s16};
+                *reinterpret_cast<h8*>(&s_qp[li][32 * tg + 8 * w]) = op;
+                se += (float)op[0] + (float)op[1] + (float)op[4] + (float)op[5];
+                so += (float)op[2] + (float)op[3] + (float)op[6] + (float)op[7];
+            }
+            {
+                auto xor16 = [](float v) {
+                    const int xi = __builtin_bit_cast(int, v);
+                    const auto r = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+                    return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+                };
+                auto xor32 = [](float v) {
+                    const int xi = __builtin_bit_cast(int, v);
+                    const auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+                    return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+                };
+                se = xor32(xor16(se));
+                so = xor32(xor16(so));
+                if (tg == 0) s_qc[li] = make_float2(se + 16.f * so, 1024.f * (se + so));
             }
             if (use_flag) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -443,29 +471,9 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         first_round(3);                    // the service wave's own units: requested only now (its queue was kept clean)
     }
 
-    // per-lane constants of head li: qsum = sum_d q_eff_d and Qoff = sum over the operand of 1024 * q' (the offset that
-    // the 1024+n / 1024+16n operand form adds to the raw dot product); q_eff = what the MFMA effectively multiplies n by
-    float qsum, qoff;
-    for (int rep = 0; rep < ((EXP & 32) ? 2 : 1); ++rep) {   // (trace build: twice - is the first pass slow because its code is cold?)
-        float se = 0.f, so = 0.f;   // sums over lo-form / hi-form operand positions of this lane's 32 dims
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const h8 x = *reinterpret_cast<const h8*>(&s_qp[li & (GP - 1)][32 * tg + 8 * w]);
-            se += (float)x[0] + (float)x[1] + (float)x[4] + (float)x[5];
-            so += (float)x[2] + (float)x[3] + (float)x[6] + (float)x[7];
-        }
-        se += __shfl_xor(se, 16, 64);
-        se += __shfl_xor(se, 32, 64);
-        so += __shfl_xor(so, 16, 64);
-        so += __shfl_xor(so, 32, 64);
-        qsum = se + 16.f * so;
-        qoff = 1024.f * (se + so);
-        if constexpr (EXP & 32) {
-            asm volatile("" : "+v"(qsum), "+v"(qoff) :: "memory");
-            stamp(9 + rep);
-        }
-    }
-    const float nqoff = -qoff;
+    // per-lane constants of head li (summed by the service wave with the operand image)
+    const float2 qc = s_qc[li & (GP - 1)];
+    const float qsum = qc.x, nqoff = -qc.y;
     if constexpr (EXP & 32) {
         float probe = nqoff;
         asm volatile("" : "+v"(probe));
