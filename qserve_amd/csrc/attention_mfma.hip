@@ -153,6 +153,14 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         if (lane < 16) s_stamps[wave * 16 + lane] = 0;
     }
     stamp(0);
+    // Reset of the hand-over flag behind a workgroup barrier, FIRST THING in the kernel (round 4): every wave has ~1 us of length
+    // / page-address latency in front of it anyway, so the barrier is free here - where it used to stand (after the service
+    // wave's entry requests) it held the unit waves' first requests back by ~2 000 cycles.
+    if (!(kflags & 2)) {
+        const u32 fa = (u32)(uintptr_t)(__attribute__((address_space(3))) void*)(&s_flag);
+        if (tid == SVC * 64) asm volatile("ds_write_b32 %0, %1" ::"v"(fa), "v"(0));
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier");
+    }
     // the rows of the new token (wave-uniform addresses: scalar bases of the service wave's entry requests below)
     const _Float16* qb = q + (size_t)b * q_stride0 + (size_t)hkv * G * DH;
     const _Float16* kb = k + (size_t)b * kv_stride0 + (size_t)hkv * DH;
@@ -164,26 +172,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     const uint64_t qb_s = uni_ptr(qb), kb_s = uni_ptr(kb), vb_s = uni_ptr(vb);
     const int64_t* ktab = kv_pointers + (size_t)b * 2 * max_blocks;
     const int64_t* vtab = ktab + max_blocks;
-    // The page addresses of a wave's first two units are requested together with the length (they do not depend on it
-    // when this workgroup starts at unit 0): one memory round trip less on the launch -> first bytes chain.  The wave's
-    // first unit is unit `wave` (page wave / 2), its second one unit wave + 7 when seven waves share the units (the usual
-    // case, see the ownership rule below; with eight the address is fetched when the length is known).
     const bool spec = (nsplit == 1 || blockIdx.z == 0);
-    int64_t kpage0 = 0, vpage0 = 0, kpage7 = 0, vpage7 = 0;
-    if (spec) {
-        const int p0 = wave >> 1, p7 = (wave + NW - 1) >> 1;
-        if (p0 < max_blocks) {
-            kpage0 = ktab[p0];
-            vpage0 = vtab[p0];
-        }
-        if (p7 < max_blocks) {
-            kpage7 = ktab[p7];
-            vpage7 = vtab[p7];
-        }
-    }
-    // (the length and the first-round page addresses are requested FIRST, as scalar loads: anything the compiler cannot
-    // prove store-free in front of them - volatile asm, the loads of the service wave - would make them vector loads)
-    const int tl = lengths ? lengths[b] - 1 : timestep;   // tlength, Template.hpp:901
     // service wave: q / k / v of the new token do not depend on the context length - requested at kernel entry, ahead of
     // every unit DMA of this CU in the memory pipeline (which serves requests in order: loads issued after the burst of
     // the first round would come back ~4 us later); raised issue priority until the operands are published
@@ -192,8 +181,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     // on the compiler's infeasible SVC -> non-SVC path, and its waitcnt pass then drains the unit waves' DMA queue - vmcnt(0) -
     // wherever the shared code reuses one of them)
     if (wave == SVC) {
-        asm volatile("s_setprio 3");       // (asm without a memory clobber: the builtin counts as a possible store and
-                                           //  turns every later page-table lookup into a vector load)
+        asm volatile("s_setprio 3");
         if constexpr (!(EXP & 4)) {
             const u32 lane4 = (u32)lane * 4u;
             auto glds4 = [&](uint64_t sb, const _Float16* dst) {
@@ -207,6 +195,25 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         }
         stamp(5);      // (trace: service wave - entry requests issued)
     }
+    // The length and the page addresses of the wave's first two units, as SCALAR loads in one statement with its own wait
+    // (explicit: behind the volatile statements above the compiler would make them vector loads).  The addresses do not depend
+    // on the length when this workgroup starts at unit 0 - one memory round trip less on the launch -> first bytes chain: the
+    // wave's first unit is unit `wave` (page wave / 2), its second one unit wave + 7 when seven waves share the units (the
+    // usual case, see the ownership rule below; with eight the address is fetched when the length is known).  Entries beyond
+    // the table and a null `lengths` read a valid dummy (entry 0 / the table itself) and are not used.
+    int64_t kpage0, vpage0, kpage7, vpage7;
+    int len_raw;
+    {
+        const int p0 = (wave >> 1) < max_blocks ? (wave >> 1) : 0, p7 = ((wave + NW - 1) >> 1) < max_blocks ? ((wave + NW - 1) >> 1) : 0;
+        const uint64_t a0 = uni_ptr(ktab + p0), a1 = uni_ptr(vtab + p0), a2 = uni_ptr(ktab + p7), a3 = uni_ptr(vtab + p7);
+        const uint64_t a4 = uni_ptr(lengths ? (const void*)(lengths + b) : (const void*)ktab);
+        asm volatile("s_load_dwordx2 %0, %5, 0x0\n\ts_load_dwordx2 %1, %6, 0x0\n\ts_load_dwordx2 %2, %7, 0x0\n\t"
+                     "s_load_dwordx2 %3, %8, 0x0\n\ts_load_dword %4, %9, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(kpage0), "=&s"(vpage0), "=&s"(kpage7), "=&s"(vpage7), "=&s"(len_raw)
+                     : "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4)
+                     : "memory");
+    }
+    const int tl = lengths ? len_raw - 1 : timestep;   // tlength, Template.hpp:901
     if (tl < 0) return;
     stamp(1);
     const float inv_sqrt = 0.08838834764831845f;
@@ -327,14 +334,10 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     // speculative page addresses fit: the first unit always, the second one for the seven-wave round-robin
     const bool spec2 = spec && PS == NW - 1;
     // Hand-over of the operands from the service wave to the unit waves: an LDS flag the unit waves poll after issuing their
-    // first requests (reset behind a start-of-kernel barrier).  Round 4 measured the alternative - ONE raw s_barrier that the
+    // first requests (reset behind the barrier at the top of the kernel).  Round 4 measured the alternative - ONE raw s_barrier that the
     // unit waves enter after their first requests and the service wave when the operands are in LDS, no reset barrier, no
     // polling - at +-0.2 us of this form over 300 ... 2 000 tokens (kflags & 2, qs_set_attention_variant(5)): not adopted.
     const bool use_flag = !(kflags & 2);
-    if (use_flag) {
-        if (tid == SVC * 64) s_flag = 0;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
     // first request of a wave: its unit 0 (4.25 KiB), then - see the call sites for WHEN - its unit 1
     auto first_round = [&](int which) {       // which: 1 = unit 0 only, 2 = unit 1 only, 3 = both
         if (cnt > 0) {
@@ -426,10 +429,13 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
             // 1024 * q' (what the 1024+n / 1024+16n operand form adds to the raw dot product); q_eff = what the MFMA effectively
             // multiplies n by.  Same summation order as before (per lane over its 32 dims, then lanes xor 16, xor 32).
             float se = 0.f, so = 0.f;   // sums over lo-form / hi-form operand positions of this lane's 32 dims
+            h8 xr[4];                   // (all four reads first: one LDS round trip instead of four)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) xr[w] = *reinterpret_cast<const h8*>(&s_q[li < G ? li : 0][32 * tg + 8 * w]);
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                h8 x = {0, 0, 0, 0, 0, 0, 0, 0};                       // heads >= G: zero rows of the operand
-                if (li < G) x = *reinterpret_cast<const h8*>(&s_q[li][32 * tg + 8 * w]);
+                h8 x = xr[w];
+                if (li >= G) x = (h8){0, 0, 0, 0, 0, 0, 0, 0};         // heads >= G: zero rows of the operand
                 const _Float16 s16 = (_Float16)0.0625f;
                 const h8 op = {x[0], x[4], x[1] * s16, x[5] * s16, x[2], x[6], x[3] * s16, x[7] * s16};
                 *reinterpret_cast<h8*>(&s_qp[li][32 * tg + 8 * w]) = op;

@@ -21,12 +21,12 @@ __device__ __forceinline__ void dma16(unsigned voff, const void* sbase, unsigned
 template <int BURST>
 __global__ __launch_bounds__(512, 4) void probe(const unsigned char* __restrict__ src, int reps, int mode, int loaders_on,
                                                 unsigned long long* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[8 * BURST * 1024];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[8 * 8 * 1024];
     __shared__ __attribute__((aligned(16))) unsigned int s_probe[256];
     __shared__ int s_done;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem + wave * BURST * 1024;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem + wave * 8 * 1024;
     if (threadIdx.x < 256) s_probe[threadIdx.x] = threadIdx.x;
     if (threadIdx.x == 0) s_done = 0;
     __syncthreads();
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(512, 4) void probe(const unsigned char* __restrict_
         if (loaders_on) {
             for (int r = 0; r < reps; ++r) {
 #pragma unroll
-                for (int d = 0; d < BURST; ++d) dma16(voff, mine + ((size_t)r * BURST + d) * 1024, lds0 + d * 1024);
+                for (int d = 0; d < BURST; ++d) dma16(voff, mine + ((size_t)r * BURST + d) * 1024, lds0 + (d & 7) * 1024);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
         } else {
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(512, 4) void probe(const unsigned char* __restrict_
         while (*(volatile __attribute__((address_space(3))) int*)(&s_done) < 7) {
             if (mode == 1) {
 #pragma unroll
-                for (int d = 0; d < BURST; ++d) dma16(voff, mine + (size_t)((n * BURST + d) % (reps * BURST)) * 1024, lds0 + d * 1024);
+                for (int d = 0; d < BURST; ++d) dma16(voff, mine + (size_t)((n * BURST + d) % (reps * BURST)) * 1024, lds0 + (d & 7) * 1024);
             }
             // (a) ds_read_b128
             unsigned long long a0 = __builtin_amdgcn_s_memtime();
@@ -85,8 +85,8 @@ __global__ __launch_bounds__(512, 4) void probe(const unsigned char* __restrict_
 }
 
 int main(int argc, char** argv) {
-    const int grid = 512, reps = 6;
-    constexpr int BURST = 8;
+    const int grid = 512, reps = 3;
+    constexpr int BURST = 24;
     size_t bytes = (size_t)grid * 8 * reps * BURST * 1024;
     unsigned char* src;
     unsigned long long* out;
