@@ -297,13 +297,30 @@ def kernel_bench(eng, args, torch, contexts):
     def attn(i):
         fa.single_query_attention(q, k, v, eng.tables[i % nl], eng.lengths, None, 8192, 64, eng.size_per_token,
                                   eng.max_len, 128, eng.cfg["rope_theta"], True, eng.int4, True)
+    # what the step launches when the pair fusions are on: attention + invoke_quant(_fuse_sum) of its output in ONE launch (the
+    # last workgroup of a sequence quantises the row, qserve_amd/fused.py).  The roofline object is computed on this launch -
+    # its time includes the quantiser's seam (~0.7 us), its bytes the int8 row and statistics; the plain kernel is listed too.
+    fused_attn = eng.fuse_pairs and eng.tp_world == 1
+    sums = eng.q_sum if eng.group_size == -1 else None
+
+    def attn_quant(i):
+        from qserve_amd import fused as fz
+        fz.single_query_attention_quant(q, k, v, eng.tables[i % nl], eng.lengths, eng.q_attn, eng.q_scale, 8192, 64,
+                                        eng.size_per_token, eng.max_len, 128, eng.cfg["rope_theta"], True, eng.int4, True,
+                                        quant_sum=sums)
     for j, L in enumerate(contexts):           # context INCLUDING the new token; first entry = the timed step's context
         eng.lengths.fill_(L)
         us = time_kernel(attn, 4 * nl, torch)
         by = attn_bytes(B, eng.H, eng.Hkv, L - 1, eng.int4)
         res.append(dict(kernel=f"decode_attention[B={B} H={eng.H} Hkv={eng.Hkv} L={L}]", family="decode_attention",
                         us=us, bytes=by, gbs=by / us / 1e3, frac_of_hbm_peak=by / us / 1e3 / HBM_PEAK_GBS,
-                        per_step=nl if j == 0 else 0))
+                        per_step=0 if fused_attn else (nl if j == 0 else 0)))
+        if j == 0 and fused_attn:
+            us2 = time_kernel(attn_quant, 4 * nl, torch)
+            by2 = by + B * eng.H * 128 + 4 * B            # + the int8 row and the per-token statistics
+            res.append(dict(kernel=f"decode_attention+quant[B={B} H={eng.H} Hkv={eng.Hkv} L={L}]", family="decode_attention_step",
+                            us=us2, bytes=by2, gbs=by2 / us2 / 1e3, frac_of_hbm_peak=by2 / us2 / 1e3 / HBM_PEAK_GBS,
+                            per_step=nl))
     eng.lengths.copy_(saved)
     return res
 
@@ -687,11 +704,13 @@ def main():
                 return (1, b) if b.startswith("round") else (0, b)
             for cand in sorted(glob.glob(os.path.join(pdir, "*_pmc_traffic.json")), key=_rank, reverse=True):
                 ents = json.load(open(cand))["kernels"]
-                ent = ents.get(dom["kernel"]) or next((v for k, v in ents.items() if k.split(" L=")[0] == dom["kernel"].split(" L=")[0]), None)
+                label = dom["kernel"].replace("decode_attention+quant[", "decode_attention[")   # (the PMC workload launches the plain op)
+                ent = ents.get(label) or next((v for k, v in ents.items() if k.split(" L=")[0] == label.split(" L=")[0]), None)
                 if ent:
                     traffic = ent["hbm_bytes"]
                     traffic_src = (f"profiles/{os.path.basename(cand)} ({ent['kernel_symbol']}, rocprofv3 --pmc, offline "
-                                   f"pass{'' if dom['kernel'] in ents else ' at a neighbouring context length'})")
+                                   f"pass{'' if label in ents else ' at a neighbouring context length'}"
+                                   f"{'; the plain attention launch, the fused quantiser adds the 0.5 MB int8 row' if label != dom['kernel'] else ''})")
                     break
         except (OSError, ValueError, KeyError, IndexError):
             pass
@@ -699,6 +718,11 @@ def main():
                     frac=round(dom["gbs"] / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
                     us_per_launch=round(dom["us"], 2), algorithmic_bytes=dom["bytes"],
                     step_share=round(dom["us"] * dom["per_step"] / (ms * 1e3), 3))
+        if dom["family"] == "decode_attention_step":   # the same kernel without the fused quantiser (what rounds 1-3 quoted)
+            plain = next(r for r in kernels if r["family"] == "decode_attention")
+            roof.update(plain_attention_us=round(plain["us"], 2), plain_attention_frac=round(plain["gbs"] / HBM_PEAK_GBS, 4),
+                        note="timed as the step launches it: attention + invoke_quant(_fuse_sum) of its output in one launch; "
+                             "plain_attention_* = qs_single_query_attention alone (the launch rounds 1-3 quoted)")
         fam = [r for r in step_k if r["family"] == "w4a8_gemm"]
         fb, fu = sum(r["bytes"] for r in fam), sum(r["us"] for r in fam)
         roof_family = dict(bound="hbm", family="w4a8_gemm (the four decode GEMMs of a layer)", achieved=round(fb / fu / 1e3, 1),
