@@ -34,6 +34,10 @@ int g_ring_flags = 0;
 
 namespace {
 
+// epilogue operands staged in LDS (see ring_body): the top 2 KiB of the 160 KiB window
+constexpr int SC_BYTES = 2048;
+constexpr int SC_OFF = 160 * 1024 - SC_BYTES;
+
 __device__ __forceinline__ u32 vadd4(u32 a, u32 b) {
     return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
 }
@@ -310,6 +314,41 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
 #pragma unroll
         for (int cl = 0; cl < 4; ++cl) acc[mt][cl] = (v4i){0, 0, 0, 0};
 
+    // ---- epilogue operands (round 4): the per-channel / per-token scale vectors of the workgroup's tile are requested HERE,
+    // by LDS-DMA into the top 2 KiB of the LDS window (above every ring and reduction area), by wave 0, ahead of the first
+    // ring stage in its in-order queue (the counted ring waits are unaffected: the extra requests are OLDER than any stage).
+    // Before, every lane loaded its own values from memory after the k loop - a dependent memory round trip between the last
+    // MFMA and the epilogue while the other workgroups still stream: 2 000 - 5 600 cycles in the timeline trace (gate_up:
+    // 14 % of the launch).  Layout: [w scale: 64 WN halfs | w scale*zero: 64 WN halfs | token scale: 64 x 4-byte slots | token
+    // sum: 64 slots]; local channel = 64 wn + 32 t + ... (ACT: the 32 WN gate channels, then the 32 WN up channels).
+    uint8_t* const s_sc = smem + SC_OFF;
+    if (OUTK != 1 && wave == 0) {
+        const u32 sc_lds = (u32)(size_t)(lptr_t)s_sc;
+        auto dma4p = [&](const void* src, u32 dst) {
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(dst) : "memory");
+        };
+        constexpr int NCH = 64 * WN;                  // channels of the workgroup's tile
+#pragma unroll
+        for (int i = 0; i < (NCH + 127) / 128; ++i) { // 128 halfs per instruction
+            int lc = 128 * i + 2 * lane;
+            lc = lc < NCH ? lc : NCH - 2;             // surplus lanes repeat a valid address
+            const int gc = ACT ? (lc < 32 * WN ? 32 * unit0 + lc : N / 2 + 32 * unit0 + (lc - 32 * WN)) : unit0 * 64 + lc;
+            dma4p(reinterpret_cast<const _Float16*>(wscales) + gc, sc_lds + 256 * i);
+            if (MODE == 0) dma4p(reinterpret_cast<const _Float16*>(wszs) + gc, sc_lds + 2 * NCH + 256 * i);
+        }
+        {   // token vectors: one half per lane in a 4-byte slot (2-byte requests: no alignment assumption on a [M] vector)
+            int m = m0 + lane;
+            m = m < M ? m : M - 1;
+            const _Float16* sa_p = reinterpret_cast<const _Float16*>(ascales) + m;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off" ::"v"(sa_p), "s"(sc_lds + 4 * NCH) : "memory");
+            if (MODE == 0) {
+                const _Float16* ss_p = reinterpret_cast<const _Float16*>(assums) + m;
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off" ::"v"(ss_p), "s"(sc_lds + 4 * NCH + 256)
+                             : "memory");
+            }
+        }
+    }
+
     // ---- prologue: stages 0..ns-2 in flight, operands of stage 0 in registers ---------------------------------------
     for (int j = 0; j < ns - 1; ++j)
         if (j < nloc) issue(j, j);
@@ -416,6 +455,7 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
 
     // ---- reduce the KG partial tiles through LDS, fused epilogue -----------------------------------------------------
     const int ncol0 = chan32(unit0 + wn, g >> 1) + 4 * (g & 1);
+    const int lcol0 = (ACT ? (g >> 1) * 32 * WN + 32 * wn : 64 * wn + 32 * (g >> 1)) + 4 * (g & 1);   // the same, local to the tile
     constexpr int NP = MT * 4;                         // 16 x 16 result pieces per wave: piece pc = mt*4 + cl
     // DISTRIBUTED form (no K slices): piece pc is finished by K-group pc % KG - every group sums, scales and converts a
     // 1/KG share of the tile instead of groups 1..KG-1 handing everything to group 0 and leaving (timeline trace,
@@ -425,26 +465,8 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
     const bool dist = !(KSPLIT && ksplit > 1);
     if (dist) {
         constexpr int PPG = (NP + KG - 1) / KG;        // pieces per owning group
-        h4 ws4[PPG], wz4[PPG];
-        _Float16 sa_h[PPG], ss_h[PPG];
         __syncthreads();                               // rings are dead (every wave drained its DMA queue)
         QS_STAMP(4);
-        if (OUTK != 1) {                               // scale operands of the OWN pieces, requested here: their latency hides under the exchange below (before the
-                                                       // barrier the k loop's operand buffers are still live and the compiler spills)
-#pragma unroll
-            for (int q = 0; q < PPG; ++q) {
-                const int pc = q * KG + kg;
-                if (pc < NP) {
-                    const int mt = pc >> 2, cl = pc & 3;
-                    ws4[q] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wscales) + ncol0 + 8 * cl);
-                    if (MODE == 0) wz4[q] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wszs) + ncol0 + 8 * cl);
-                    int m = m0 + 16 * mt + li;
-                    m = m < M ? m : M - 1;
-                    sa_h[q] = reinterpret_cast<const _Float16*>(ascales)[m];
-                    if (MODE == 0) ss_h[q] = reinterpret_cast<const _Float16*>(assums)[m];
-                }
-            }
-        }
         // partial of piece pc from group kg -> slot [owner][wn][source index among the other groups][pc / KG][lane]
         v4i* const red4 = reinterpret_cast<v4i*>(smem);
 #pragma unroll
@@ -474,15 +496,19 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
                         const int m = m0 + 16 * mt + li;
                         if (m < M) *reinterpret_cast<v4i*>(reinterpret_cast<int*>(out) + (size_t)m * N + ncol0 + 8 * cl) = sum;
                     } else {
-                        const float sa = (float)sa_h[q];
-                        const float ss = MODE == 0 ? (float)ss_h[q] : 0.f;
+                        // scale operands from the LDS staging area (requested at kernel start, see above)
+                        const int lcol = lcol0 + 8 * cl;
+                        const h4 ws4 = *reinterpret_cast<const h4*>(s_sc + 2 * lcol);
+                        const float sa = (float)*reinterpret_cast<const _Float16*>(s_sc + 4 * (64 * WN) + 4 * (16 * mt + li));
                         h4 o;
                         if (MODE == 0) {
+                            const h4 wz4 = *reinterpret_cast<const h4*>(s_sc + 2 * (64 * WN) + 2 * lcol);
+                            const float ss = (float)*reinterpret_cast<const _Float16*>(s_sc + 4 * (64 * WN) + 256 + 4 * (16 * mt + li));
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(sum[r], (float)ws4[q][r], sa, (float)wz4[q][r], ss);
+                            for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(sum[r], (float)ws4[r], sa, (float)wz4[r], ss);
                         } else {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(sum[r], (float)ws4[q][r], sa);
+                            for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(sum[r], (float)ws4[r], sa);
                         }
                         if (ACT) {
                             // lanes 0-31 hold the gate values, lanes 32-63 the up values of the same (token, channel):
@@ -534,22 +560,6 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
         return;
     }
     if (ACT) return;                                   // (never instantiated with K slices)
-    h4 ws4[4], wz4[4];
-    _Float16 sa_h[MT], ss_h[MT];
-    if (OUTK == 0 && kg == 0) {                        // requested now: their latency overlaps the reduction
-#pragma unroll
-        for (int cl = 0; cl < 4; ++cl) {
-            ws4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wscales) + ncol0 + 8 * cl);
-            if (MODE == 0) wz4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wszs) + ncol0 + 8 * cl);
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            int m = m0 + 16 * mt + li;
-            m = m < M ? m : M - 1;
-            sa_h[mt] = reinterpret_cast<const _Float16*>(ascales)[m];
-            if (MODE == 0) ss_h[mt] = reinterpret_cast<const _Float16*>(assums)[m];
-        }
-    }
     __syncthreads();                                   // rings are dead (every wave drained its DMA queue)
     int* const red = reinterpret_cast<int*>(smem);     // [KG-1][WN][NP*4][64]
     if (kg > 0) {
@@ -644,18 +654,20 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
     uint8_t* const st = smem + (KG - 1) * WN * NP * 4 * 64 * 4 + wn * (16 * MT * RS);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const float sa = (float)sa_h[mt];
-        const float ss = MODE == 0 ? (float)ss_h[mt] : 0.f;
+        const float sa = (float)*reinterpret_cast<const _Float16*>(s_sc + 4 * (64 * WN) + 4 * (16 * mt + li));
+        const float ss = MODE == 0 ? (float)*reinterpret_cast<const _Float16*>(s_sc + 4 * (64 * WN) + 256 + 4 * (16 * mt + li)) : 0.f;
 #pragma unroll
         for (int cl = 0; cl < 4; ++cl) {
             const v4i s = acc[mt][cl];
+            const h4 ws4 = *reinterpret_cast<const h4*>(s_sc + 2 * (lcol0 + 8 * cl));
             h4 o;
             if (MODE == 0) {
+                const h4 wz4 = *reinterpret_cast<const h4*>(s_sc + 2 * (64 * WN) + 2 * (lcol0 + 8 * cl));
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(s[r], (float)ws4[cl][r], sa, (float)wz4[cl][r], ss);
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(s[r], (float)ws4[r], sa, (float)wz4[r], ss);
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(s[r], (float)ws4[cl][r], sa);
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(s[r], (float)ws4[r], sa);
             }
             *reinterpret_cast<h4*>(st + (16 * mt + li) * RS + (32 * (g >> 1) + 8 * cl + 4 * (g & 1)) * 2) = o;
         }
@@ -706,7 +718,7 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
     const int nloc = (K / 64) / ksplit / KG;
     if (ns > nloc + 1) ns = nloc + 1;
     if (const int f = (g_ring_flags >> 8) & 7) {       // A/B: forced depth (sensitivity to the bytes in flight)
-        if (f >= 3 && (size_t)KG * f * GSTAGE <= 160 * 1024 && f <= nloc + 1) ns = f;
+        if (f >= 3 && (size_t)KG * f * GSTAGE <= SC_OFF && f <= nloc + 1) ns = f;
     }
     if (ns < 3) ns = 3;                                // the slot read ahead and the slot refilled must differ
     size_t smem = (size_t)KG * ns * GSTAGE;
@@ -717,6 +729,11 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
         if (tail < t2) tail = t2;
     }
     if (smem < tail) smem = tail;
+    if (smem > (size_t)SC_OFF) {
+        qs_set_error("w4a8 gemm (ring): LDS layout overflow (%zu bytes below the epilogue operands)", smem);
+        return QS_EINVAL;
+    }
+    smem = 160 * 1024;                                 // the epilogue operands sit in the top SC_BYTES of the window
     static size_t configured_dev[QS_MAX_DEVICES] = {};   // per instantiation and device
     size_t& configured = configured_dev[qs_device_slot()];
     if (configured < smem) {
@@ -776,6 +793,11 @@ int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, con
     if (outk == 2 && ksplit > 1) {
         qs_set_error("w4a8 gemm (ring): the activation epilogue has no K-sliced form");
         return QS_ENOSUP;
+    }
+    if (outk != 1 && ((reinterpret_cast<uintptr_t>(wscales) & 3) || (mode == 0 && (reinterpret_cast<uintptr_t>(wszs) & 3)))) {
+        // (the reference reads them as half2, gemm_cuda.cu:581-582: the same requirement)
+        qs_set_error("w4a8 gemm: wscales / w_szs must be 4-byte aligned");
+        return QS_EINVAL;
     }
     const bool ks = ksplit > 1;
 #define QS_R(MTV, WNV, MODEV, OUTV)                                                                                  \
