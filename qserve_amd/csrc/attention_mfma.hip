@@ -330,6 +330,11 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     const bool svc_free = (nu + NW - 2) / (NW - 1) == (nu + NW - 1) / NW;
     const int PS = svc_free ? NW - 1 : NW;                            // unit stride of a wave
     const int u_first = u_begin + wave;
+    // (round 4, measured and dropped - HISTORY.md: two-phase ownership (the second-dispatched waves 4-6 one round fewer, the rest
+    //  over waves 0-3): -0.4-0.6 us at 1 030-1 100 tokens, +0.1-0.5 at 640, equal elsewhere; ownership by SIMD load (wave 3, whose
+    //  SIMD partner is the service wave, also works the service wave's slot): +1 us - a wave's time per unit does not depend on
+    //  what shares its SIMD, it is the back-pressured issue of its own six requests)
+    auto unit_of = [&](int i) -> int { return u_first + i * PS; };
     const int cnt = ((!svc_free || wave != SVC) && wave < nu) ? (nu - wave + PS - 1) / PS : 0;   // units this wave owns
     // speculative page addresses fit: the first unit always, the second one for the seven-wave round-robin
     const bool spec2 = spec && PS == NW - 1;
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         if (cnt > 0) {
             // page addresses: requested together with the length for split 0 (scalar loads, before any asm statement:
             // behind an asm "memory" clobber the compiler falls back to vector loads for kv_pointers)
-            const int u1 = u_first + PS;
+            const int u1 = unit_of(1);
             int64_t kfirst = kpage0, vfirst = vpage0, ksecond = kpage7, vsecond = vpage7;
             // (everything else by the asm scalar loads - compiler-visible loads here would be vector loads whose pending state
             //  reaches the shared code on some path and is drained there with vmcnt(0))
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
 
     int it = 0;          // units this wave has consumed: ring slot = it & 1
     int rem = cnt - 1;   // units this wave still owns after the current one
-    for (int u = u_first; it < cnt; u += PS, ++it, --rem) {
+    for (int u = u_first; it < cnt; ++it, --rem, u = unit_of(it)) {
         const bool has2 = rem >= 2;   // (has1 = rem >= 1)
         // A(u) landed?  Younger VMEM operations of this wave at this point: B(u) (3) and, if it exists, unit u + PS (6).
         // (the wave-uniform choice between the two counted waits is a scalar branch inside the statement)
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         const int slot = it & 1;
         const int valid = min(UT, tl - u * UT);
         const bool full = valid == UT;   // wave-uniform: only the last unit needs masking
-        const int u2 = u + 2 * PS, valid2 = min(UT, tl - u2 * UT);
+        const int u2 = unit_of(it + 2), valid2 = min(UT, tl - u2 * UT);
         int64_t kpage_next = 0, vpage_next = 0;
         if (has2) next_pages(u2 >> 1, kpage_next, vpage_next);
         if constexpr (EXP & 2) {               // timing experiment: memory side only
