@@ -146,6 +146,10 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 // cvt.rni.sat.{s8,u8}.f32 equivalents: round-to-nearest-even then saturate (NaN -> 0)
 // Plan-only mode of the GEMM dispatcher (qs_w4a8_gemm_plan): the launchers record which kernel family / geometry they
 // were asked for and return without touching the device - the selection heuristics become testable on a CPU-only box.
+// K-sliced ring GEMM: the word a slab holds where no partial sum has been delivered (gemm_w4a8_ring.hip, the seam); the workspace
+// is filled with it byte-wise (0x80), and no partial sum of a slice of at most 32 768 k can reach it (128 * 255 * 32768 < 2^30)
+constexpr int QS_SLAB_SENTINEL = (int)0x80808080u;
+
 struct QsGemmPlan {
     int active;   // 1 while qs_w4a8_gemm_plan runs the dispatcher
     int family;   // 1 split-K, 2 LDS-pair, 3 ring, 4 tiled

@@ -304,6 +304,7 @@ namespace {
 // stream is being captured: a failed allocation simply disables cross-block split-K).
 struct Workspace {
     int* slabs = nullptr;
+    int* ring_slabs = nullptr;                    // K-sliced ring kernel: sentinel-filled between launches (QS_SLAB_SENTINEL)
     unsigned* counters = nullptr;
     size_t slab_bytes = 0;
     int ncounters = 0;
@@ -324,10 +325,12 @@ Workspace* get_workspace(hipStream_t stream) {
         w.tried = true;
         const size_t slab_bytes = 48u << 20;
         const int ncnt = 1 << 16;
-        void *a = nullptr, *b = nullptr;
+        void *a = nullptr, *b = nullptr, *c = nullptr;
         if (hipMalloc(&a, slab_bytes) == hipSuccess && hipMalloc(&b, ncnt * sizeof(unsigned)) == hipSuccess &&
+            hipMalloc(&c, slab_bytes) == hipSuccess && hipMemset(c, 0x80, slab_bytes) == hipSuccess &&
             hipMemset(b, 0, ncnt * sizeof(unsigned)) == hipSuccess && hipDeviceSynchronize() == hipSuccess) {
             w.slabs = reinterpret_cast<int*>(a);
+            w.ring_slabs = reinterpret_cast<int*>(c);
             w.counters = reinterpret_cast<unsigned*>(b);
             w.slab_bytes = slab_bytes;
             w.ncounters = ncnt;
@@ -458,7 +461,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         Workspace* ws = get_workspace(stream);
         const size_t tiles = (size_t)units * mb;
         if (!ws || tiles > (size_t)ws->ncounters || tiles * ks * mt * 4096 > ws->slab_bytes) return false;
-        *slabs = ws->slabs;
+        *slabs = ws->ring_slabs;
         *counters = ws->counters;
         return true;
     };
@@ -468,7 +471,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         if (act && ks > 1) return QS_UNFUSED;
         QS_REQUIRE((mt == 1 || mt == 2 || mt == 4) && (wn == 1 || wn == 2 || (wn == 4 && mt == 4)) &&
                        !(mt == 1 && wn == 2) &&
-                       N % (64 * wn) == 0 && (K / 64) % ks == 0 && (K / 64 / ks) % (8 / wn) == 0,
+                       N % (64 * wn) == 0 && (K / 64) % ks == 0 && (K / 64 / ks) % (8 / wn) == 0 && (ks == 1 || K / ks <= 32768),
                    "w4a8 gemm: forced ring geometry mt=%d wn=%d ksplit=%d does not fit M=%d N=%d K=%d", mt, wn, ks, M, N,
                    K);
         int* slabs = nullptr;
@@ -502,6 +505,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
             for (int i = 0; i < 6; ++i) {
                 const int mt = geo[i][0], wn = geo[i][1];
                 if (N % (64 * wn) != 0 || (K / 64) % ks != 0 || (K / 64 / ks) % (8 / wn) != 0) continue;
+                if (ks > 1 && K / ks > 32768) continue;        // the seam's sentinel must stay out of reach of a partial sum
                 const int mb = (mt_all + mt - 1) / mt;
                 if (ks > 1 && (long)mb * (N / (64 * wn)) > 256) continue;   // K slices are for under-filled grids only
                 const long blocks = (long)mb * (N / (64 * wn)) * ks;

@@ -457,13 +457,12 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
     const int ncol0 = chan32(unit0 + wn, g >> 1) + 4 * (g & 1);
     const int lcol0 = (ACT ? (g >> 1) * 32 * WN + 32 * wn : 64 * wn + 32 * (g >> 1)) + 4 * (g & 1);   // the same, local to the tile
     constexpr int NP = MT * 4;                         // 16 x 16 result pieces per wave: piece pc = mt*4 + cl
-    // DISTRIBUTED form (no K slices): piece pc is finished by K-group pc % KG - every group sums, scales and converts a
-    // 1/KG share of the tile instead of groups 1..KG-1 handing everything to group 0 and leaving (timeline trace,
-    // scripts/trace_gemm.py: reduction + epilogue on two of eight waves = 3 us of a 19 us launch at gate_up size).
-    // (in-run A/B against the group-0 form, qs_set_gemm_variant(5002) in the r2 builds: qkv 9.8 -> 8.7, o 7.5 -> 7.2,
-    //  gate_up 19.5 -> 18.1 us; the switch was removed because keeping both forms alive made the kernel spill)
-    const bool dist = !(KSPLIT && ksplit > 1);
-    if (dist) {
+    // DISTRIBUTED: piece pc is finished by K-group pc % KG - every group sums, scales and converts a 1/KG share of the tile
+    // instead of groups 1..KG-1 handing everything to group 0 and leaving (timeline trace, scripts/trace_gemm.py: reduction +
+    // epilogue on two of eight waves = 3 us of a 19 us launch at gate_up size; in-run A/B against the group-0 form in the r2
+    // builds: qkv 9.8 -> 8.7, o 7.5 -> 7.2, gate_up 19.5 -> 18.1 us).  Since round 4 the K-sliced launches take this form as
+    // well: all eight waves carry the seam's traffic (below).
+    {
         constexpr int PPG = (NP + KG - 1) / KG;        // pieces per owning group
         __syncthreads();                               // rings are dead (every wave drained its DMA queue)
         QS_STAMP(4);
@@ -477,60 +476,161 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
                 red4[((((own * WN + wn) * (KG - 1) + src) * PPG + pc / KG) << 6) + lane] = acc[pc >> 2][pc & 3];
             }
         }
+        QS_STAMP(7);
         __syncthreads();
+        QS_STAMP(10);
         constexpr int RS = ACT ? 64 * WN + 16 : 144;   // staged fp16 row: 128 B + 16 (keeps 16-byte alignment); ACT: the
                                                        // workgroup's 32 WN result channels in one row
         uint8_t* const st = smem + (size_t)KG * WN * (KG - 1) * PPG * 1024 + (ACT ? wn * 64 : wn * (16 * MT * RS));
+        // The pieces this wave finishes are pc = q KG + kg, q < PPG.  Their accumulators are picked by wave-uniform SELECTS, not by
+        // branches (round 4: with one basic block per (q, kk) the four pieces of a gate_up wave ran one after the other, each
+        // a chain LDS read -> sum -> scale -> exp / rcp -> LDS write with nothing to overlap it: 4 400 cycles between the two
+        // barriers in the timeline trace; as straight-line code the reads of all pieces are in flight together).
+        v4i sum[PPG];
 #pragma unroll
         for (int q = 0; q < PPG; ++q) {
+            v4i own = acc[(q * KG) >> 2][(q * KG) & 3];
 #pragma unroll
-            for (int kk = 0; kk < KG; ++kk) {          // (static piece index under a wave-uniform branch)
-                const int pc = q * KG + kk;
-                if (pc < NP && kk == kg) {
-                    const int mt = pc >> 2, cl = pc & 3;
-                    v4i sum = acc[mt][cl];
+            for (int kk = 1; kk < KG; ++kk)
+                if (q * KG + kk < NP) own = kg == kk ? acc[(q * KG + kk) >> 2][(q * KG + kk) & 3] : own;
+            sum[q] = own;
+        }
 #pragma unroll
-                    for (int sidx = 0; sidx < KG - 1; ++sidx)
-                        sum += red4[((((kg * WN + wn) * (KG - 1) + sidx) * PPG + q) << 6) + lane];
-                    if (OUTK == 1) {
-                        const int m = m0 + 16 * mt + li;
-                        if (m < M) *reinterpret_cast<v4i*>(reinterpret_cast<int*>(out) + (size_t)m * N + ncol0 + 8 * cl) = sum;
-                    } else {
-                        // scale operands from the LDS staging area (requested at kernel start, see above)
-                        const int lcol = lcol0 + 8 * cl;
-                        const h4 ws4 = *reinterpret_cast<const h4*>(s_sc + 2 * lcol);
-                        const float sa = (float)*reinterpret_cast<const _Float16*>(s_sc + 4 * (64 * WN) + 4 * (16 * mt + li));
-                        h4 o;
-                        if (MODE == 0) {
-                            const h4 wz4 = *reinterpret_cast<const h4*>(s_sc + 2 * (64 * WN) + 2 * lcol);
-                            const float ss = (float)*reinterpret_cast<const _Float16*>(s_sc + 4 * (64 * WN) + 256 + 4 * (16 * mt + li));
+        for (int q = 0; q < PPG; ++q)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(sum[r], (float)ws4[r], sa, (float)wz4[r], ss);
-                        } else {
+            for (int sidx = 0; sidx < KG - 1; ++sidx)
+                sum[q] += red4[((((kg * WN + wn) * (KG - 1) + sidx) * PPG + q) << 6) + lane];
+#ifdef QS_RING_TRACE
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(sum[r], (float)ws4[r], sa);
+        for (int q = 0; q < PPG; ++q) asm volatile("" : "+v"(sum[q]));
+        QS_STAMP(11);
+#endif
+        // ---- K-split seam (per wave: its own pieces of unit wn's tile) ------------------------------------------------------
+        // Round 4: no ticket, and every wave takes part.  The slabs hold a SENTINEL word (QS_SLAB_SENTINEL, a value no partial
+        // sum of an admitted K slice can take) wherever no partial has been delivered.  Slices 0 .. ksplit-2 store their
+        // pieces (system-scope write-through, fire and forget) and leave; the LAST slice - dispatched last, so every slice it
+        // waits for already holds a CU - loads the other slices' pieces with cache-missing loads, repeats the load while any
+        // word still shows the sentinel, adds, and puts the sentinel back for the next launch (ordered by the kernel
+        // boundary).  Before: acknowledged stores -> device-scope ticket -> loads by the last arriver, three dependent round
+        // trips, the last one 48 KB through ONE wave per unit (MI355X_MICROARCH.md handoff-payload: "one wave reading a fresh
+        // 64 KB slot = 4.9 us") - 9 000 cycles in the timeline trace at down's shape.
+        // No fences (an agent-scope release / acquire writes back and invalidates the XCD's whole L2 under every other
+        // workgroup's feet, measured +10 us): the slab traffic bypasses the caches (sc0 sc1), and the data is its own flag - a
+        // word is either the sentinel or final, so torn 16-byte accesses are harmless.
+        if (KSPLIT && ksplit > 1) {
+            const size_t tile = (size_t)(unit0 + wn) * mblocks + mblk;
+            v4i* const slab = reinterpret_cast<v4i*>(slabs) + tile * ksplit * (size_t)(NP * 64) + lane;
+            if (kq != ksplit - 1) {
+#pragma unroll
+                for (int q = 0; q < PPG; ++q) {
+                    const int pc = q * KG + kg;
+                    if (NP % KG != 0 && pc >= NP) continue;
+                    v4i* const dst = slab + ((size_t)kq * NP + pc) * 64;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(sum[q]) : "memory");
+                }
+                return;
+            }
+            constexpr int ZB = PPG <= 4 ? 3 : 1;       // slices requested together (up to 12 x 16 B per lane in flight)
+            const v4i sent = {QS_SLAB_SENTINEL, QS_SLAB_SENTINEL, QS_SLAB_SENTINEL, QS_SLAB_SENTINEL};
+            // cache-missing loads through the buffer BUILTIN (aux 17 = sc0 | sc1): the compiler counts them and waits before
+            // the first use.  An inline-asm load is invisible to it - inside this retry loop the loaded registers are loop-
+            // carried, and hipcc copied them BEFORE the asm's own s_waitcnt (seen in the ISA; the MT = 1 geometry returned
+            // garbage; cdna_hip_programming.md 5.7 item 1)
+            const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, 0x7FFFFFFF, 0x00020000);
+            const u32 sl_off = (u32)((tile * ksplit * (size_t)(NP * 64) + lane) * 16);   // (the workspace is 48 MiB)
+            for (int j0 = 0; j0 < ksplit - 1; j0 += ZB) {
+                v4i t[ZB][PPG];
+                for (;;) {
+#pragma unroll
+                    for (int jb = 0; jb < ZB; ++jb) {
+                        const int z = j0 + jb;
+                        if (z < ksplit - 1) {
+#pragma unroll
+                            for (int q = 0; q < PPG; ++q) {
+                                const int pc = q * KG + kg;
+                                if (NP % KG != 0 && pc >= NP) continue;
+                                t[jb][q] = __builtin_bit_cast(
+                                    v4i, __builtin_amdgcn_raw_buffer_load_b128(srs, sl_off, (z * NP + pc) * 1024, 17));
+                            }
                         }
-                        if (ACT) {
-                            // lanes 0-31 hold the gate values, lanes 32-63 the up values of the same (token, channel):
-                            // silu_and_mul's arithmetic on the fp16-rounded GEMM outputs (activation_kernels.cu:11,21-32)
-                            const v2u ob = __builtin_bit_cast(v2u, o);
-                            // one swap hands every lane the pair it finishes: r[0] = (x of lanes 0-31 | y of lanes 0-31) = gate elements
-                            // 0, 1 for the lower half, 2, 3 for the upper; r[1] = (x | y of lanes 32-63) = the matching up elements
-                            const auto sw = __builtin_amdgcn_permlane32_swap(ob.x, ob.y, false, false);
-                            const h2 gt = __builtin_bit_cast(h2, (u32)sw[0]), up = __builtin_bit_cast(h2, (u32)sw[1]);
-                            const int hh = g >> 1;
-                            h2 a;
-                            a[0] = (_Float16)((float)qs_silu_h((float)gt[0]) * (float)up[0]);
-                            a[1] = (_Float16)((float)qs_silu_h((float)gt[1]) * (float)up[1]);
-                            *reinterpret_cast<h2*>(st + (16 * mt + li) * RS + (8 * cl + 4 * (g & 1) + 2 * hh) * 2) = a;
-                        } else {
-                            *reinterpret_cast<h4*>(st + (16 * mt + li) * RS + (32 * (g >> 1) + 8 * cl + 4 * (g & 1)) * 2) = o;
+                    }
+                    int missing = 0;
+#pragma unroll
+                    for (int jb = 0; jb < ZB; ++jb)
+                        if (j0 + jb < ksplit - 1) {
+#pragma unroll
+                            for (int q = 0; q < PPG; ++q) {
+                                if (NP % KG != 0 && q * KG + kg >= NP) continue;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) missing |= t[jb][q][r] == QS_SLAB_SENTINEL;
+                            }
+                        }
+#ifdef QS_RING_TRACE
+                    if (g_ring_trace && lane == 0) g_ring_trace[((size_t)blockIdx.x * 8 + wave) * 16 + 13] += 1;
+#endif
+                    if (!__builtin_amdgcn_ballot_w64(missing != 0)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+#pragma unroll
+                for (int jb = 0; jb < ZB; ++jb) {
+                    const int z = j0 + jb;
+                    if (z < ksplit - 1) {
+#pragma unroll
+                        for (int q = 0; q < PPG; ++q) {
+                            const int pc = q * KG + kg;
+                            if (NP % KG != 0 && pc >= NP) continue;
+                            sum[q] += t[jb][q];
+                            v4i* const dst = slab + ((size_t)z * NP + pc) * 64;
+                            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(sent) : "memory");
                         }
                     }
                 }
             }
+            QS_STAMP(14);
+        }
+#pragma unroll
+        for (int q = 0; q < PPG; ++q) {
+            const int pc = q * KG + kg;                // wave-uniform
+            if (NP % KG != 0 && pc >= NP) continue;    // (fewer pieces than groups: MT = 1 with eight K-groups)
+            const int mt = pc >> 2, cl = pc & 3;
+            if (OUTK == 1) {
+                const int m = m0 + 16 * mt + li;
+                if (m < M) *reinterpret_cast<v4i*>(reinterpret_cast<int*>(out) + (size_t)m * N + ncol0 + 8 * cl) = sum[q];
+            } else {
+                // scale operands from the LDS staging area (requested at kernel start, see above)
+                const int lcol = lcol0 + 8 * cl;
+                const h4 ws4 = *reinterpret_cast<const h4*>(s_sc + 2 * lcol);
+                const float sa = (float)*reinterpret_cast<const _Float16*>(s_sc + 4 * (64 * WN) + 4 * (16 * mt + li));
+                h4 o;
+                if (MODE == 0) {
+                    const h4 wz4 = *reinterpret_cast<const h4*>(s_sc + 2 * (64 * WN) + 2 * lcol);
+                    const float ss = (float)*reinterpret_cast<const _Float16*>(s_sc + 4 * (64 * WN) + 256 + 4 * (16 * mt + li));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(sum[q][r], (float)ws4[r], sa, (float)wz4[r], ss);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(sum[q][r], (float)ws4[r], sa);
+                }
+                if (ACT) {
+                    // lanes 0-31 hold the gate values, lanes 32-63 the up values of the same (token, channel):
+                    // silu_and_mul's arithmetic on the fp16-rounded GEMM outputs (activation_kernels.cu:11,21-32)
+                    const v2u ob = __builtin_bit_cast(v2u, o);
+                    // one swap hands every lane the pair it finishes: r[0] = (x of lanes 0-31 | y of lanes 0-31) = gate elements
+                    // 0, 1 for the lower half, 2, 3 for the upper; r[1] = (x | y of lanes 32-63) = the matching up elements
+                    const auto sw = __builtin_amdgcn_permlane32_swap(ob.x, ob.y, false, false);
+                    const h2 gt = __builtin_bit_cast(h2, (u32)sw[0]), up = __builtin_bit_cast(h2, (u32)sw[1]);
+                    const int hh = g >> 1;
+                    h2 a;
+                    a[0] = (_Float16)((float)qs_silu_h((float)gt[0]) * (float)up[0]);
+                    a[1] = (_Float16)((float)qs_silu_h((float)gt[1]) * (float)up[1]);
+                    *reinterpret_cast<h2*>(st + (16 * mt + li) * RS + (8 * cl + 4 * (g & 1) + 2 * hh) * 2) = a;
+                } else {
+                    *reinterpret_cast<h4*>(st + (16 * mt + li) * RS + (32 * (g >> 1) + 8 * cl + 4 * (g & 1)) * 2) = o;
+                }
+            }
         }
         if (OUTK == 1) return;
+        QS_STAMP(12);
         __syncthreads();                               // the fp16 tile of every unit is staged
         QS_STAMP(5);
         if (ACT) {                                     // rows of 64 WN bytes, shared by all eight waves
@@ -557,131 +657,7 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
             if (m < M) *reinterpret_cast<v4u*>(orow + (size_t)m * N) = v;
         }
         QS_STAMP(6);
-        return;
     }
-    if (ACT) return;                                   // (never instantiated with K slices)
-    __syncthreads();                                   // rings are dead (every wave drained its DMA queue)
-    int* const red = reinterpret_cast<int*>(smem);     // [KG-1][WN][NP*4][64]
-    if (kg > 0) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int cl = 0; cl < 4; ++cl)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    red[((((kg - 1) * WN + wn) * NP + mt * 4 + cl) * 4 + r) * 64 + lane] = acc[mt][cl][r];
-    }
-    __syncthreads();
-    QS_STAMP(4);
-    if (kg > 0) return;
-#pragma unroll
-    for (int k2 = 0; k2 < KG - 1; ++k2)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int cl = 0; cl < 4; ++cl)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[mt][cl][r] += red[(((k2 * WN + wn) * NP + mt * 4 + cl) * 4 + r) * 64 + lane];
-    // ---- K-split seam (per wave = per 64-channel unit): partial tile -> slab, arrival ticket, the last arriver sums
-    // the other slices' slabs and goes on to the epilogue.  No fences: an agent-scope release / acquire writes back and
-    // invalidates the XCD's whole L2 under every other workgroup's feet (measured: +10 us); instead the slab traffic
-    // itself bypasses the caches (sc0 sc1 = system-scope write-through stores / cache-missing loads), the stores are
-    // acknowledged (vmcnt 0) before the ticket, and the ticket is a device-scope atomic.  The counter is reset by the
-    // last arriver (no host work between launches).
-    if (KSPLIT && ksplit > 1) {
-        const size_t tile = (size_t)(unit0 + wn) * mblocks + mblk;
-        v4i* const slab = reinterpret_cast<v4i*>(slabs) + tile * ksplit * (size_t)(NP * 64);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int cl = 0; cl < 4; ++cl) {
-                v4i* const dst = slab + ((size_t)kq * NP + mt * 4 + cl) * 64 + lane;
-                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(acc[mt][cl]) : "memory");
-            }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned ticket = 0;
-        if (lane == 0) ticket = __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ticket = __builtin_amdgcn_readfirstlane(ticket);
-        if (ticket != (unsigned)(ksplit - 1)) return;
-        if (lane == 0) __hip_atomic_store(counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // the other slices' slabs: all requested before ONE wait while they fit the register budget (mt <= 2, up to 3
-        // slices = 96 VGPRs), slice by slice otherwise - each wait is a full memory round trip
-        constexpr int ZB = MT <= 2 ? 3 : 1;            // slices per batch
-        for (int j0 = 0; j0 < ksplit - 1; j0 += ZB) {
-            v4i t[ZB][MT][4];
-#pragma unroll
-            for (int jb = 0; jb < ZB; ++jb) {
-                const int j = j0 + jb;
-                if (j < ksplit - 1) {
-                    int z = kq + 1 + j;
-                    z = z >= ksplit ? z - ksplit : z;
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int cl = 0; cl < 4; ++cl) {
-                            const v4i* const src = slab + ((size_t)z * NP + mt * 4 + cl) * 64 + lane;
-                            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(t[jb][mt][cl]) : "v"(src) : "memory");
-                        }
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int jb = 0; jb < ZB; ++jb)
-                if (j0 + jb < ksplit - 1) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int cl = 0; cl < 4; ++cl) {
-                            asm volatile("" : "+v"(t[jb][mt][cl]));   // the values exist only after the wait above
-                            acc[mt][cl] += t[jb][mt][cl];
-                        }
-                }
-        }
-    }
-    if (OUTK == 1) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = m0 + 16 * mt + li;
-            if (m >= M) continue;
-#pragma unroll
-            for (int cl = 0; cl < 4; ++cl)
-                *reinterpret_cast<v4i*>(reinterpret_cast<int*>(out) + (size_t)m * N + ncol0 + 8 * cl) = acc[mt][cl];
-        }
-        return;
-    }
-    constexpr int RS = 144;                            // staged fp16 row: 128 B + 16 (keeps 16-byte alignment)
-    uint8_t* const st = smem + (KG - 1) * WN * NP * 4 * 64 * 4 + wn * (16 * MT * RS);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const float sa = (float)*reinterpret_cast<const _Float16*>(s_sc + 4 * (64 * WN) + 4 * (16 * mt + li));
-        const float ss = MODE == 0 ? (float)*reinterpret_cast<const _Float16*>(s_sc + 4 * (64 * WN) + 256 + 4 * (16 * mt + li)) : 0.f;
-#pragma unroll
-        for (int cl = 0; cl < 4; ++cl) {
-            const v4i s = acc[mt][cl];
-            const h4 ws4 = *reinterpret_cast<const h4*>(s_sc + 2 * (lcol0 + 8 * cl));
-            h4 o;
-            if (MODE == 0) {
-                const h4 wz4 = *reinterpret_cast<const h4*>(s_sc + 2 * (64 * WN) + 2 * (lcol0 + 8 * cl));
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(s[r], (float)ws4[r], sa, (float)wz4[r], ss);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(s[r], (float)ws4[r], sa);
-            }
-            *reinterpret_cast<h4*>(st + (16 * mt + li) * RS + (32 * (g >> 1) + 8 * cl + 4 * (g & 1)) * 2) = o;
-        }
-    }
-    QS_STAMP(5);
-    _Float16* const orow = reinterpret_cast<_Float16*>(out) + (unit0 + wn) * 64 + (lane & 7) * 8;
-#pragma unroll
-    for (int i = 0; i < 2 * MT; ++i) {
-        const int r = i * 8 + (lane >> 3);
-        const int m = m0 + r;
-        const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane & 7) * 16);
-        if (m < M) *reinterpret_cast<v4u*>(orow + (size_t)m * N) = v;
-    }
-    QS_STAMP(6);
 }
 
 // MT m-tiles (16 tokens each) per wave = tokens per workgroup / 16; WN units per workgroup; KG = 8 / WN K-groups.

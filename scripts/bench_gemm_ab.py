@@ -61,5 +61,15 @@ for name, N, K, act in (("qkv", 6144, 4096, False), ("o", 4096, 4096, False), ("
             fn = lambda i: fz.gemm_silu_and_mul_per_chn(A, W[i % NL], ws, sa, ws, sa, out, tmp)
         else:
             fn = lambda i: gc.gemm_forward_cuda(A, W[i % NL], ws, sa, ws, sa, out)
+    vs = os.environ.get("VARIANT_" + name.split("+")[0])   # e.g. VARIANT_down=4221,4422: forced geometries (qs_set_gemm_variant)
+    if vs:
+        from qserve_amd._lib import lib
+        res = []
+        for v in vs.split(","):
+            lib.qs_set_gemm_variant(int(v))
+            res.append(f"{v}: {timeit(fn):.2f}")
+            lib.qs_set_gemm_variant(-1)
+        row.append(f"{name} [" + " ".join(res) + "]")
+        continue
     row.append(f"{name} {timeit(fn):6.2f}")
 print(f"M={M}{' g128' if group else ''}: " + "   ".join(row) + " us")

@@ -27,9 +27,13 @@ used = st[:, 0, 0] > 0
 st = st[used]
 print(f"M={M} N={N} K={K}: {used.sum()} workgroups traced")
 t0 = st[:, :, 0].min(axis=1, keepdims=True)
-names = {0: "entry", 1: "prologue issued", 2: "stage 0 landed", 3: "loop done", 4: "reduced (sync)", 5: "epilogue math", 6: "end"}
+names = {0: "entry", 1: "prologue issued", 2: "stage 0 landed", 3: "loop done", 4: "rings dead (sync)", 7: "partials written", 10: "sync", 11: "partials summed", 14: "seam done", 12: "epilogue math", 5: "tile staged (sync)", 6: "end"}
 for i, nm in names.items():
     x = st[:, :, i] - t0
     x = np.where(st[:, :, i] > 0, x, np.nan)
     print(f"  {nm:16s} mean {np.nanmean(x):8.0f}  min {np.nanmin(x):8.0f}  max {np.nanmax(x):8.0f}")
+if st[:, :, 13].max() > 0:
+    fin = st[:, :, 13] > 0
+    print(f"  K-slice seam: {int(fin.sum())} finishing waves, polls per batch-wave mean {st[:, :, 13][fin].mean():.2f} max {st[:, :, 13].max():.0f}; "
+          f"loop done of the finishing waves {np.nanmean(np.where(fin, st[:, :, 3] - t0, np.nan)):.0f} vs the writers {np.nanmean(np.where((~fin) & (st[:, :, 3] > 0), st[:, :, 3] - t0, np.nan)):.0f}")
 print(f"  in-loop: waiting (vmcnt + barrier) mean {st[:, :, 8].mean():8.0f} ticks, rounds (LDS reads + MFMA + DMA issue) mean {st[:, :, 9].mean():8.0f} ticks")
