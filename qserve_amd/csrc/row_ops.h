@@ -227,10 +227,10 @@ __device__ __forceinline__ void norm_quant_row(int8_t* __restrict__ out, _Float1
             for (int c = 0; c < NC; ++c) {
                 const int i = (c * NT + tid + j * 64 * PW) * 8;
                 if (i < hidden) {
-                    if (ADD) {
-                        v[j][c] = v[j][c] + __builtin_bit_cast(h8, dl[j][c]);              // the residual add's fp16 add
-                        *reinterpret_cast<h8*>(hidden_io + i) = v[j][c];
-                    }
+                    // (the sum is written back at the END of the kernel, with the other stores: stored here, the compiler's
+                    //  vmcnt(0) at the next control-flow join - it cannot count across the exec-masked load blocks above -
+                    //  also waited for this store's acknowledgement, a memory round trip in front of the first reduction)
+                    if (ADD) v[j][c] = v[j][c] + __builtin_bit_cast(h8, dl[j][c]);         // the residual add's fp16 add
 #pragma unroll
                     for (int e = 0; e < 8; ++e) s[j] += (float)v[j][c][e];
                 }
@@ -287,6 +287,7 @@ __device__ __forceinline__ void norm_quant_row(int8_t* __restrict__ out, _Float1
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = ln_val((float)v[j][c][e], mean, rstd_e, (float)g[j][c][e]);   // fp32, :315
                     qs_store_q8(out + i, f, mul);
+                    if (ADD) *reinterpret_cast<h8*>(hidden_io + i) = v[j][c];
                 }
             }
     }
