@@ -24,7 +24,8 @@
 #include <type_traits>
 
 // A/B switches (qs_set_gemm_variant(5000 + bits); every setting computes the same results):
-//   1 = weight DMA with the default cache policy instead of non-temporal
+//   1 = weight DMA with the default cache policy everywhere, 2 = non-temporal everywhere (default: non-temporal unless several
+//       token blocks share the weight bytes of a channel block and N <= 8192 - see launch_ring and `issue`)
 //   32 / 64 = (libraries built with -DQS_TIMING only; ignored by the shipped library) timing only, WRONG RESULTS: no MFMA /
 //        no LDS operand reads (what is left is the DMA + barrier pipeline:
 //        gate_up at M = 64 17.5 us -> 16.3 / 16.8, both off 15.9 us = 4.2 us of head and tail + 512 KB per CU at 44 GB/s,
@@ -224,8 +225,14 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
                      : "memory");
     };
-    // weights are read exactly once per launch by exactly one workgroup: non-temporal (MI355X_MICROARCH.md "nt-weights":
-    // issued -> landed -18 %); the activation tile is re-read by every workgroup from L2 and keeps the default policy
+    // weights that exactly ONE workgroup reads (one token block per channel block) are non-temporal (MI355X_MICROARCH.md
+    // "nt-weights": issued -> landed -18 %); with several token blocks the same bytes are wanted again by the neighbours on the
+    // XCD a moment later, and a streamed line may be gone by then: default policy there (launch_ring sets flags bit 0; round 4,
+    // in-run A/B at M = 64: qkv (2 token blocks) 8.45 -> 7.84 us, o (4) 6.66 -> 6.48, down (2 x 4 K slices) 14.05 -> 13.98,
+    // gate_up (1 block) 16.97 -> 17.05 the other way; M = 128: qkv 11.70 -> 11.28, o 7.94 -> 7.70).  Measured exception: the
+    // 28 672-channel gate_up stream stays 2-3 % faster non-temporal at every M, shared or not (M = 128: 24.56 vs 25.06, g128 35.24
+    // vs 36.23; M = 256: 32.55 vs 33.29) - the rule is "several token blocks AND N <= 8192".  The activation tile is re-read by
+    // every workgroup from L2 and always keeps the default policy
     auto dma16_nt = [&](u32 voff, const void* sbase, u32 lds_addr) {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(lds_addr)
                      : "memory");
@@ -725,7 +732,8 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, A, W, zeros, scales8,
                        reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
                        reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K,
-                       mblocks, ns, ksplit, slabs, counters, g_ring_flags);
+                       mblocks, ns, ksplit, slabs, counters,
+                       (g_ring_flags & ~3) | ((g_ring_flags & 1) || (mblocks > 1 && N <= 8192 && !(g_ring_flags & 2)) ? 1 : 0));
     return qs_launch_status("w4a8 gemm (ring)");
 }
 
