@@ -507,8 +507,8 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
                 if (N % (64 * wn) != 0 || (K / 64) % ks != 0 || (K / 64 / ks) % (8 / wn) != 0) continue;
                 if (ks > 1 && K / ks > 32768) continue;        // the seam's sentinel must stay out of reach of a partial sum
                 const int mb = (mt_all + mt - 1) / mt;
-                if (ks > 1 && (long)mb * (N / (64 * wn)) > 256) continue;   // K slices are for under-filled grids only
                 const long blocks = (long)mb * (N / (64 * wn)) * ks;
+                if (ks > 1 && (long)mb * (N / (64 * wn)) > 256) continue;   // K slices are for under-filled grids only
                 // per-group: the level-2 dequant is VALU work per weight byte a workgroup streams (measured at M = 128, g128:
                 // qkv 16.0 us with (4,1) against 18.2 with the equal-bytes (2,2)) - charged as a quarter of the weight bytes
                 const long pg = MODE == 1 && g_variant != 4002 ? 8 * wn : 0;
@@ -516,6 +516,16 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
                                   seam(ks, mt);
                 if (best < 0 || cost < best) best = cost, bmt = mt, bwn = wn, bks = ks;
             }
+        // Measured override of the byte model (round 4, scripts/gpu_plan_check.sh, weights from HBM): where the model takes
+        // <2,2> x 4 K slices over two token blocks and <2,1> x 2 slices fills the chip with the same 256 workgroups, the latter
+        // is 3-7 % faster - a third of the slab traffic (stored, read, restored) on a launch that is HBM-bound, and since round 4
+        // the two token blocks share their weight stream in L2 (default cache policy, gemm_w4a8_ring.hip).  Llama-3-8B down_proj
+        // (N = 4096, K = 14336) at 33-64 tokens: 14.4-14.7 vs 15.3-15.8 us per-channel, 19.6-19.9 vs 20.6-20.9 g128.  The byte
+        // model puts the two 1 KB apart and cannot be tuned to separate them without flipping M = 32 (measured the other way).
+        // (Inside the decode step the two are equal, 2.809 vs 2.813 ms: kept for the traffic - one slab per tile instead of three.)
+        if (best >= 0 && bmt == 2 && bwn == 2 && bks == 4 && (mt_all + 1) / 2 == 2 && (long)2 * (N / 64) * 2 == 256 &&
+            (K / 64) % 2 == 0 && (K / 64 / 2) % 8 == 0 && g_variant != 4003)
+            bwn = 1, bks = 2;
         // the older register-staged split-K kernel takes any K and cuts the tokens down to 16 per workgroup: same byte
         // model, ~20 % slower at equal bytes (measured) - it wins where K leaves the ring kernel only coarse geometries
         // (Llama-2-7B down_proj: K = 11 008 = 172 stages, two-unit workgroups only)

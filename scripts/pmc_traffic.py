@@ -20,7 +20,7 @@ wr = json.load(open(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_WRITE_SIZE.json
 NAMES = {   # bench.py kernel label -> symbol prefix in the counter files
     "w4a8_gemm[gate_up+silu*mul M=64 N=28672 K=4096]": "w4a8_gemm_ring<4, 2, 0, 2, false",
     "w4a8_gemm[qkv M=64 N=6144 K=4096]": "w4a8_gemm_ring<2, 1, 0, 0, false",
-    "w4a8_gemm[down M=64 N=4096 K=14336]": "w4a8_gemm_ring<2, 2, 0, 0, true",    # 4 K slices x 2 token blocks
+    "w4a8_gemm[down M=64 N=4096 K=14336]": "w4a8_gemm_ring<2, 1, 0, 0, true",     # 2 K slices x 2 token blocks (round 4)
     "w4a8_gemm[o M=64 N=4096 K=4096]": "w4a8_gemm_ring<1, 1, 0, 0, false",
     "decode_attention[B=64 H=32 Hkv=8 L=1033]": "decode_attention_mfma_kernel",
 }
