@@ -44,6 +44,9 @@ constexpr int UT = 32;         // tokens per pipeline unit (half a page)
 constexpr int USB = UT * DHB;  // bytes of K (or V) data per unit and KV head
 constexpr int NW = 8;          // waves per workgroup; all of them may own units
 constexpr int NWT = NW;
+typedef u32 v2u __attribute__((ext_vector_type(2)));
+constexpr int QS_ATTNQ_CAP = 4096;   // sequences the attention + quant fusion can hand over (larger batches run the pair)
+constexpr int QS_ATTNQ_ROW = 4096;   // values per row at most (H x 128 <= 4096: quant_kernel's 256-thread mapping)
 constexpr int SVC = NW - 1;    // the service wave (RoPE, operand build, new token) - the wave that owns the fewest units
 constexpr int MAXP = 192;      // longest page table this kernel is dispatched for (dispatcher: max_blocks <= MAXP)
 
@@ -202,15 +205,16 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
     // usual case, see the ownership rule below; with eight the address is fetched when the length is known).  Entries beyond
     // the table and a null `lengths` read a valid dummy (entry 0 / the table itself) and are not used.
     int64_t kpage0, vpage0, kpage7, vpage7;
-    int len_raw;
+    int len_raw, gen_raw;                             // gen_raw: the sequence's hand-off generation (attention + quant fusion, below)
     {
         const int p0 = (wave >> 1) < max_blocks ? (wave >> 1) : 0, p7 = ((wave + NW - 1) >> 1) < max_blocks ? ((wave + NW - 1) >> 1) : 0;
         const uint64_t a0 = uni_ptr(ktab + p0), a1 = uni_ptr(vtab + p0), a2 = uni_ptr(ktab + p7), a3 = uni_ptr(vtab + p7);
         const uint64_t a4 = uni_ptr(lengths ? (const void*)(lengths + b) : (const void*)ktab);
-        asm volatile("s_load_dwordx2 %0, %5, 0x0\n\ts_load_dwordx2 %1, %6, 0x0\n\ts_load_dwordx2 %2, %7, 0x0\n\t"
-                     "s_load_dwordx2 %3, %8, 0x0\n\ts_load_dword %4, %9, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(kpage0), "=&s"(vpage0), "=&s"(kpage7), "=&s"(vpage7), "=&s"(len_raw)
-                     : "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4)
+        const uint64_t a5 = uni_ptr(qcounters ? (const void*)(qcounters + b) : (const void*)ktab);
+        asm volatile("s_load_dwordx2 %0, %6, 0x0\n\ts_load_dwordx2 %1, %7, 0x0\n\ts_load_dwordx2 %2, %8, 0x0\n\t"
+                     "s_load_dwordx2 %3, %9, 0x0\n\ts_load_dword %4, %10, 0x0\n\ts_load_dword %5, %11, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(kpage0), "=&s"(vpage0), "=&s"(kpage7), "=&s"(vpage7), "=&s"(len_raw), "=&s"(gen_raw)
+                     : "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5)
                      : "memory");
     }
     const int tl = lengths ? len_raw - 1 : timestep;   // tlength, Template.hpp:901
@@ -781,45 +785,66 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         }
     }
     // ---- fused invoke_quant(_fuse_sum) of the attention output (qs_single_query_attention_quant) -----------------------
-    // The per-token statistics span all KV heads = all workgroups of the sequence, so the LAST of them to finish does
-    // the row: every workgroup publishes its G x 128 fp16 outputs with write-through (sc0 sc1) 16-byte stores, waits for
-    // their acknowledgement, draws a ticket from a per-sequence counter (device-scope atomic; reset by the last
-    // arriver); the last one re-reads the whole row with cache-missing (sc0 sc1) loads and runs quant_kernel's exact
-    // arithmetic on its first 256 threads - same thread -> element mapping, same shuffle trees, same combination order
-    // over the four waves - so qout / qscale / qsum are BIT-IDENTICAL to invoke_quant(_fuse_sum)(out).  The seam is the
-    // fence-free form of the K-sliced GEMM (gemm_w4a8_ring.hip); it replaces a ~5 us row kernel and a kernel boundary.
+    // The per-token statistics span all KV heads = all workgroups of the sequence.  Round 4: the workgroup of the LAST KV head
+    // (dispatched last: every workgroup it waits for already holds a CU or is done) does the row.  The others hand their
+    // G x 128 fp16 results over as 8-byte granules {two values, tag} - ONE write-through store each, no acknowledgement, no
+    // ticket; tag = the sequence's generation word + 1, read with the kernel's first scalar loads; the finisher polls the
+    // granules with cache-missing loads until every tag is this launch's, runs quant_kernel's exact arithmetic on its first
+    // 256 threads - same thread -> element mapping, same shuffle trees, same combination order over the four waves, so qout /
+    // qscale / qsum are BIT-IDENTICAL to invoke_quant(_fuse_sum)(out) - and advances the generation word (ordered against the
+    // next launch by the kernel boundary).  A granule is written by one store, so data and tag arrive together
+    // (MI355X_MICROARCH.md, hand-off forms: "R2's granule needs no ordering at all"); nothing is reset, nothing can be mistaken
+    // for data (NaN-proof), one hand-off round trip on the critical path.  Before (rounds 2-3): acknowledged stores -> device-
+    // scope ticket -> row re-read by the last arriver, three dependent round trips (+1.0-2.2 us on the launch).
+    // Workspace (qs_attn_quant_counters): [QS_ATTNQ_CAP generation words | QS_ATTNQ_CAP rows of 2048 granules], zeroed once.
     if (nsplit == 1 && qout) {
         __syncthreads();
         const int hidden = num_heads * DH;
-        if (tid2 < G * 16) {
+        const unsigned tag = (unsigned)gen_raw + 1u;
+        if (tid2 < G * 16) {                           // the fp16 result rows, as the plain launch writes them
             const v4u x = reinterpret_cast<const v4u*>(&s_meta[0][0][0])[tid2];
-            _Float16* dst = out + ((size_t)b * num_heads + (size_t)hkv * G) * DH + tid2 * 8;
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(x) : "memory");
+            *reinterpret_cast<v4u*>(out + ((size_t)b * num_heads + (size_t)hkv * G) * DH + tid2 * 8) = x;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid2 == 0) {
-            const unsigned t = __hip_atomic_fetch_add(qcounters + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = t == (unsigned)(num_kv_heads - 1);
-            if (last) __hip_atomic_store(qcounters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *(volatile __attribute__((address_space(3))) int*)(&s_flag) = last;
-        }
-        __syncthreads();
-        if (*(volatile __attribute__((address_space(3))) int*)(&s_flag)) {      // workgroup-uniform
-            float* const sm = reinterpret_cast<float*>(&s_kv[0]);                // 2 x 4 floats
-            const _Float16* row = out + (size_t)b * hidden;
+        v2u* const xrow = reinterpret_cast<v2u*>(qcounters + QS_ATTNQ_CAP) + (size_t)b * (QS_ATTNQ_ROW / 2);
+        const int own_lo = (num_kv_heads - 1) * G * DH;                           // first row element of the finishing workgroup
+        if (hkv != num_kv_heads - 1) {
+            for (int e = tid2; e < G * DH / 2; e += NWT * 64) {
+                v2u gr;
+                gr.x = reinterpret_cast<const u32*>(&s_meta[0][0][0])[e];
+                gr.y = tag;
+                v2u* const dst = xrow + (size_t)hkv * (G * DH / 2) + e;
+                asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(gr) : "memory");
+            }
+        } else {
+            // cache-missing loads through the buffer builtin (the compiler counts them; an asm load inside a retry loop is not
+            // safe - gemm_w4a8_ring.hip, the K-slice seam)
+            const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xrow, 0, QS_ATTNQ_ROW * 4, 0x00020000);
             v4u raw[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-            float amax = 0.f, sum = 0.f;
             if (tid2 < 256) {
+                for (;;) {
+                    int missing = 0;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int i = (c * 256 + tid2) * 8;   // quant_kernel: thread t owns row elements (c 256 + t) 8 .. + 7
+                        if (i < own_lo) {                       // = granules i/2 .. i/2 + 3 = 32 bytes of the exchange row
+                            const v4u g0 = __builtin_amdgcn_raw_buffer_load_b128(xrs, i * 4, 0, 17);
+                            const v4u g1 = __builtin_amdgcn_raw_buffer_load_b128(xrs, i * 4 + 16, 0, 17);
+                            missing |= (g0.y != tag) | (g0.w != tag) | (g1.y != tag) | (g1.w != tag);
+                            raw[c] = (v4u){g0.x, g0.z, g1.x, g1.z};
+                        }
+                    }
+                    if (!__builtin_amdgcn_ballot_w64(missing != 0)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const int i = (c * 256 + tid2) * 8;
-                    if (i < hidden) {
-                        const _Float16* src = row + i;
-                        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(raw[c]) : "v"(src) : "memory");
-                    }
+                    if (i >= own_lo && i < hidden) raw[c] = reinterpret_cast<const v4u*>(&s_meta[0][0][0])[(i - own_lo) >> 3];
                 }
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1])::"memory");
+            }
+            float* const sm = reinterpret_cast<float*>(&s_kv[0]);                // 2 x 4 floats (the rings are dead)
+            float amax = 0.f, sum = 0.f;
+            if (tid2 < 256) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const int i = (c * 256 + tid2) * 8;
@@ -851,6 +876,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
                 if (tid2 == 0) {
                     qscale[b] = __float2half_rn(r / 127.0f);                     // fused_kernels.cu:72
                     if (qrowsum) qrowsum[b] = __float2half_rn(s2);                     // :121
+                    qcounters[b] = tag;                                          // the next launch hands over under tag + 1
                 }
                 const float mul = 127.0f / r;                                     // :78 (unrounded fp32 amax)
 #pragma unroll
@@ -990,15 +1016,16 @@ extern "C" int qs_debug_copy_split_workspace(void* dst, size_t bytes) {
     return (int)hipMemcpy(dst, g_ws[dev].p, bytes, hipMemcpyDeviceToDevice);
 }
 
-// per-sequence arrival counters of the attention + quant fusion: one fixed allocation per device (65536 sequences),
-// zeroed once, self-resetting (the last arriver of every sequence writes 0), never freed; nullptr while it cannot be
-// allocated (first use inside a stream capture): the caller then runs the un-fused pair
+// workspace of the attention + quant fusion: one fixed allocation per device - QS_ATTNQ_CAP generation words followed by
+// QS_ATTNQ_CAP exchange rows of QS_ATTNQ_ROW / 2 granules (8 bytes: two fp16 values + the generation tag) -, zeroed once
+// (generation 0, every tag stale), never freed; nullptr for larger batches or while it cannot be allocated (first use inside
+// a stream capture): the caller then runs the un-fused pair
 namespace {
 unsigned* g_qcounters[16];
 }
 unsigned* qs_attn_quant_counters(hipStream_t st, int batch) {
     int dev = 0;
-    if (batch > 65536 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (batch > QS_ATTNQ_CAP || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     if (g_qcounters[dev]) return g_qcounters[dev];
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
@@ -1006,9 +1033,9 @@ unsigned* qs_attn_quant_counters(hipStream_t st, int batch) {
         return nullptr;
     }
     void* p = nullptr;
+    const size_t bytes = (size_t)QS_ATTNQ_CAP * 4 + (size_t)QS_ATTNQ_CAP * QS_ATTNQ_ROW * 4;
     // (the memset runs on the NULL stream: synchronise, or a launch on a non-blocking stream could overtake it)
-    if (hipMalloc(&p, 65536 * sizeof(unsigned)) != hipSuccess || hipMemset(p, 0, 65536 * sizeof(unsigned)) != hipSuccess ||
-        hipDeviceSynchronize() != hipSuccess) {
+    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }

@@ -67,6 +67,12 @@ for L in LS:
     ROUNDS = int(os.environ.get("ROUNDS", "5"))
     res = {i: [] for i in range(len(VARS))}
     call = lambda i: fa.single_query_attention(q, k, v, tables[i % NL], lens, None, 8192, 64, Hkv * dhb, L, 128, 5e5, True, int4, True)
+    if os.environ.get("FUSED"):       # FUSED=1: the attention + invoke_quant_fuse_sum launch the decode step uses
+        from qserve_amd import fused as fz
+        qq = torch.empty((B, H * 128), dtype=torch.int8, device=dev)
+        qsc, qsm = torch.empty((B,), dtype=torch.float16, device=dev), torch.empty((B,), dtype=torch.float16, device=dev)
+        call = lambda i: fz.single_query_attention_quant(q, k, v, tables[i % NL], lens, qq, qsc, 8192, 64, Hkv * dhb, L, 128, 5e5,
+                                                         True, int4, True, quant_sum=qsm)
     timeit(call, reps=16)                                  # warm-up of clocks and caches, discarded
     for _ in range(ROUNDS):
         for i, var in enumerate(VARS):
