@@ -15,14 +15,17 @@
  *   - return value: 0 on success, a negative QS_E* code on rejected arguments (nothing was launched),
  *     a positive hipError_t if the launch failed.  qs_last_error() returns a thread-local message;
  *   - callers own every tensor buffer (ownership rules of the reference, SURVEY.md 8(b) "Conventions"); the library
- *     keeps a few small device scratch areas of its own (RoPE cos/sin tables, split-KV partials, split-K slabs, the split
- *     argmax's keys / tickets, the arrival words of the fused attention quantiser).  Each
+ *     keeps a few device scratch areas of its own (RoPE cos/sin tables, split-KV partials, split-K slabs - 2 x 48 MiB, one of
+ *     them sentinel-filled between launches -, the split argmax's keys / tickets, the generation words and exchange rows of
+ *     the fused attention quantiser - 64 MiB, batches up to 4096 sequences, larger ones run the un-fused pair).  Each
  *     is a fixed-size allocation made lazily on a first EAGER call (never while the stream is being captured into a
  *     graph: such a call runs the variant that needs no scratch) and is NEVER freed, moved or grown afterwards, so a
  *     hipGraph that captured its address stays valid for the life of the process.  Requests beyond the fixed capacity
  *     fall back to the un-split variants.  The scratch areas are per device (the CURRENT device of the calling thread):
  *     launches that use them (split-KV attention, K-sliced GEMMs, the split argmax, the fused attention quantiser's
- *     tickets) must not run concurrently on different streams of one device (the reference's engine is single-stream).
+ *     hand-over) must not run concurrently on different streams of one device (the reference's engine is single-stream).
+ *     A launch that is ABORTED mid-way (device reset) may leave the K-slice slabs without their sentinel or an exchange row
+ *     half-tagged: the process must not reuse the library after a failed launch (qs_launch_status reports it).
  */
 #ifndef QSERVE_AMD_H
 #define QSERVE_AMD_H

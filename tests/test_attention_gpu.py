@@ -351,7 +351,7 @@ def test_attention_quant_fusion_is_bit_identical_to_the_pair(gpu, B, H, Hkv, L, 
         fk.invoke_quant_fuse_sum(q1, out1.reshape(B, -1), m1, s1)
     else:
         fk.invoke_quant(q1, out1.reshape(B, -1), s1)
-    # the fused call, twice (the arrival counters must have reset themselves)
+    # the fused call, twice (the second launch hands over under the next generation tag)
     for rep in range(2):
         p2 = fresh()
         ptr2 = p2.pointers(tables)
