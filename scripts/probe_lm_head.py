@@ -30,3 +30,4 @@ for _ in range(5):
     res.append(e0.elapsed_time(e1) * 1e3 / 32)
 us = sorted(res)[2]
 print(f"lm_head B={B} {'tuned' if os.environ.get('TUNE') else 'default'}: {us:.1f} us = {128256*4096*2/us/1e6:.2f} TB/s")
+
