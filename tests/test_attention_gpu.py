@@ -310,12 +310,13 @@ def test_decode_valu_kernel_still_correct(gpu, int4):
 
 @pytest.mark.parametrize("int4", [True, False], ids=["kv4", "kv8"])
 @pytest.mark.parametrize("with_sum", [True, False])
-@pytest.mark.parametrize("B,H,Hkv,L", [(64, 32, 8, 1033), (5, 8, 2, 300), (3, 8, 8, 130), (2, 16, 2, 70), (8, 32, 8, 4000)])
+@pytest.mark.parametrize("B,H,Hkv,L", [(64, 32, 8, 1033), (5, 8, 2, 300), (3, 8, 8, 130), (2, 16, 2, 70), (8, 32, 8, 4000),
+                                      (4100, 8, 2, 70)])   # (more sequences than the hand-over workspace holds: the pair runs)
 def test_attention_quant_fusion_is_bit_identical_to_the_pair(gpu, B, H, Hkv, L, with_sum, int4):
     """qserve_amd.fused.single_query_attention_quant == single_query_attention ; invoke_quant(_fuse_sum): the fp16
     output, the int8 row, the fp16 scale (and row sum) and every cache byte, bit for bit - in-kernel fusion (KV4, no KV
-    split: the last-arriving workgroup of a sequence finishes the row), split-KV launches (B=8, L=4000) and the KV8 /
-    other fall-back paths alike."""
+    split: the workgroup of the last KV head finishes the row from the others' tagged granules), split-KV launches (B=8,
+    L=4000), batches beyond the hand-over workspace (4100 sequences) and the KV8 / other fall-back paths alike."""
     import qserve_backend.fused_attention as fa
     import qserve_backend.fused_kernels as fk
     from qserve_amd import fused
