@@ -1082,7 +1082,7 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
     }
     grid.z = nsplit;
     // attention + invoke_quant fusion (qs_single_query_attention_quant): un-split launches over rows of <= 4096 values
-    // (quant_kernel's 256-thread mapping is what the last arriver reproduces bit for bit)
+    // (quant_kernel's 256-thread mapping is what the finishing workgroup reproduces bit for bit)
     int8_t* qout = nullptr;
     __half *qscale = nullptr, *qsum = nullptr;
     unsigned* qcnt = nullptr;

@@ -490,7 +490,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         const int mt_all = (M + 15) / 16;
         static const int geo[6][2] = {{4, 2}, {2, 2}, {4, 1}, {2, 1}, {1, 1}, {4, 4}};   // 4 units (2 K-groups): fewer bytes per CU where two-unit
         // workgroups need a second round - M = 128 x N = 28 672: 26.8 vs 32.4 us (per-group 41.0 vs 47.0), M = 64 x 49 152: 48.9 vs 58.4
-        // K slices (ksplit 2 / 4, int32 partial tiles meeting in a workspace, last arriver finishes): fewer bytes per
+        // K slices (ksplit 2 / 4, int32 partial tiles meeting in a workspace, the last-dispatched slice finishes): fewer bytes per
         // CU when neither tokens nor channels can be cut further, against the seam's cost; variant 4001
         // keeps ksplit = 1 (A/B)
         // seam cost in bytes of streaming, calibrated on scripts/bench_gemm_shard.py (VARIANTS=4001,-1): slab stores ->

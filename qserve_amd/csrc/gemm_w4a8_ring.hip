@@ -156,7 +156,7 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
     // workgroup -> (channel block, token block); token blocks of one channel block sit on ONE XCD (b % 8) so that the
     // weights are fetched from HBM once and re-served by that XCD's L2
     // K split (ksplit > 1): the K range is cut into ksplit slices handled by different workgroups (same XCD as well);
-    // the int32 partial tiles meet in a workspace, the last arriver finishes (see the seam below).
+    // the int32 partial tiles meet in a workspace, the last-dispatched slice finishes (see the seam below).
     const RingCoords rc = ring_coords(blockIdx.x, N, WN, mblocks, ksplit);
     const int nblk = rc.nblk, mblk = rc.mblk, kq = rc.kq;
     const int unit0 = nblk * WN;                      // first 64-channel unit of the workgroup

@@ -242,7 +242,7 @@ def test_tiled_kernel_equals_decode_kernel(gpu):
 RING = [(4111, 16, 64, 1024), (4111, 40, 512, 2048), (4121, 23, 64, 1024), (4121, 64, 512, 1024),
         (4141, 50, 64, 2048), (4141, 100, 512, 1024), (4122, 32, 128, 512), (4122, 20, 256, 1024),
         (4142, 64, 128, 512), (4142, 37, 384, 1536),
-        # K slices (4100 + 100*(ksplit-1) + ...): partial tiles meet in the workspace, last arriver finishes
+        # K slices (4100 + 100*(ksplit-1) + ...): partial tiles meet in the sentinel-filled workspace, the last slice finishes
         (4211, 16, 64, 2048), (4221, 23, 64, 2048), (4241, 50, 128, 4096), (4222, 20, 256, 1024),
         (4422, 32, 256, 2048), (4442, 64, 128, 4096), (4411, 9, 192, 4096),
         # odd numbers of stages per K-group (K/64 not a multiple of 2*groups), down to a single stage
