@@ -94,6 +94,19 @@ int qs_w4a8_per_chn_gemm_acc(const int8_t* in_feats, const int8_t* kernel, int32
 int qs_w4a8_per_group_gemm_acc(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros,
                                const int8_t* scales_i8, int32_t* acc_out, int M, int N, int K, qs_stream_t stream);
 
+/* K-slice PLANES (engine-side pair fusion, round 4): the row-parallel GEMMs of a layer (o_proj, down_proj) are followed by a row
+ * kernel that reads their whole output (residual add + norm + quant, llama_w4a8_unpad.py:345-361).  In this form the GEMM leaves
+ * the int32 partial sums of its K slices as planes [k_slices][M][N] - no cross-workgroup reduction, no epilogue - and
+ * qs_add_residual_rms_norm_general_planes (below) sums them and applies the GEMM's epilogue arithmetic itself, bit for bit.
+ *   qs_w4a8_gemm_planes_plan: plan4 = {k_slices, m_tiles, units, token_blocks} the planes launch of this shape will use;
+ *                             k_slices == 0: no such launch for this shape (run the ordinary pair).  Deterministic in the shape.
+ *   planes: int32 [k_slices][M][N], 16-byte aligned; every element of every plane is written. */
+int qs_w4a8_gemm_planes_plan(int per_group, int M, int N, int K, int* plan4);
+int qs_w4a8_per_chn_gemm_planes(const int8_t* in_feats, const int8_t* kernel, int32_t* planes, int M, int N, int K,
+                                qs_stream_t stream);
+int qs_w4a8_per_group_gemm_planes(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros, const int8_t* scales_i8,
+                                  int32_t* planes, int M, int N, int K, qs_stream_t stream);
+
 /* W8A8 GEMM (importable-module requirement only).
  * Replaces qserve_backend.qgemm_w8a8.w8a8_gemm_forward_cuda (kernels/csrc/qgemm/w8a8/w8a8_gemm_cuda.h:11).
  *   kernel int8 [N,K] row-major.  out = float(acc) * (wscale[n]*ascale[m]).  N % 16 == 0, K % 64 == 0. */
@@ -224,6 +237,15 @@ void qs_debug_argmax_split(int split);
 int qs_add_residual_rms_norm_general(int8_t* out, void* hidden_io, const void* delta, const void* weight,
                                      void* input_sum, void* scaling, float epsilon, int num_tokens, int hidden,
                                      qs_stream_t stream);
+/*   == qs_w4a8_*_gemm(in, kernel, ..., delta) ; qs_add_residual_rms_norm_general(out, hidden_io, delta, ...) where the GEMM ran as
+ *   qs_w4a8_*_gemm_planes: delta[t][n] = fp16(epilogue(sum over the k_slices planes)) is formed inside the row kernel.
+ *   wscales / w_szs fp16 [hidden] and ascales / a_ssums fp16 [num_tokens] are the GEMM's epilogue operands (w_szs and a_ssums
+ *   NULL together = per-group epilogue); ascales / a_ssums MAY alias scaling / input_sum (a row reads its own values first).
+ *   plane_stride = elements between planes (>= num_tokens * hidden); hidden <= 4096. */
+int qs_add_residual_rms_norm_general_planes(int8_t* out, void* hidden_io, const int32_t* planes, int k_slices,
+                                            int64_t plane_stride, const void* wscales, const void* w_szs, const void* ascales,
+                                            const void* a_ssums, const void* weight, void* input_sum, void* scaling,
+                                            float epsilon, int num_tokens, int hidden, qs_stream_t stream);
 int qs_silu_and_mul_quant(int8_t* out, const void* input, void* input_sum, void* scale, int num_tokens, int d,
                           qs_stream_t stream);
 

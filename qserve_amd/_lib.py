@@ -25,6 +25,9 @@ SIGNATURES = {
     "qs_w8a8_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_set_gemm_variant": (None, [_i]),
     "qs_w4a8_gemm_plan": (_i, [_i, _i, _i, _i, _vp]),
+    "qs_w4a8_gemm_planes_plan": (_i, [_i, _i, _i, _i, _vp]),
+    "qs_w4a8_per_chn_gemm_planes": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "qs_w4a8_per_group_gemm_planes": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_set_attention_variant": (None, [_i]),
     "qs_attention_plan": (_i, [_i, _i, _i, _i, _i, _i, _vp]),
     "qs_single_query_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _i, _i, _i, _i,
@@ -42,6 +45,7 @@ SIGNATURES = {
     "qs_argmax_rows": (_i, [_vp, _vp, _i, _i, _i64, _vp]),
     "qs_debug_argmax_split": (None, [_i]),
     "qs_add_residual_rms_norm_general": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
+    "qs_add_residual_rms_norm_general_planes": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "qs_silu_and_mul_quant": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "qs_debug_wave_reduce_selftest": (_i, [_vp, _vp, _i, _vp]),
     "qs_comm_create": (_i, [_i, _i, _i64, C.POINTER(C.c_void_p), _vp]),

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(TPB) void residual_add_kernel(_Float16* __restrict_
 // the intermediate fp16 rounding of the op pair they replace, i.e. they are bit-identical to calling the two ops.
 //
 //   add_residual_norm_quant : hidden += delta (fp16 add, written back) ; rms_norm_general(_fuse_sum)(hidden)
-template <int NC>
+template <int NC, bool FULL>
 __global__ __launch_bounds__(TPB) void add_residual_norm_quant_kernel(int8_t* __restrict__ out,
                                                                       _Float16* __restrict__ hidden_io,
                                                                       const _Float16* __restrict__ delta,
@@ -174,9 +174,32 @@ __global__ __launch_bounds__(TPB) void add_residual_norm_quant_kernel(int8_t* __
                                                                       int hidden) {
     __shared__ float sm[4 * (TPB / 64)];
     const size_t base = (size_t)blockIdx.x * hidden;
-    qs_row::norm_quant_row<NC, TPB / 64, TPB / 64, true, false>(
+    qs_row::norm_quant_row<NC, TPB / 64, TPB / 64, true, false, qs_row::NoHook, qs_row::FromRow, FULL>(
         out + base, hidden_io + base, delta + base, gamma, sum_out ? sum_out + blockIdx.x : nullptr,
         scale_out + blockIdx.x, eps, hidden, sm, (int)threadIdx.x);
+}
+
+//   add_residual_norm_quant over K-slice PLANES (round 4): the residual branch arrives as the int32 planes a W4A8 GEMM left
+//   (qs_w4a8_*_gemm_planes) instead of its fp16 output; delta = fp16(GEMM epilogue(sum of the planes)) is formed here, bit for
+//   bit what the GEMM would have stored, then everything is add_residual_norm_quant.  `ascale` / `asum` are the activation scale /
+//   sum the GEMM's INPUT was quantised with; they may alias scale_out / sum_out (a row reads its own values before it writes).
+template <int NC, int KS, int MODE, bool FULL>
+__global__ __launch_bounds__(TPB) void add_residual_norm_quant_planes_kernel(
+    int8_t* __restrict__ out, _Float16* __restrict__ hidden_io, const int* __restrict__ planes, size_t pstride,
+    const _Float16* __restrict__ wscales, const _Float16* __restrict__ wszs, const __half* ascale, const __half* asum,
+    const _Float16* __restrict__ gamma, __half* sum_out, __half* scale_out, float eps, int hidden) {
+    __shared__ float sm[4 * (TPB / 64)];
+    const size_t base = (size_t)blockIdx.x * hidden;
+    qs_row::FromPlanes<KS, MODE> dfn;
+    dfn.row0 = planes + base;
+    dfn.pstride = pstride;
+    dfn.ws = wscales;
+    dfn.wz = wszs;
+    dfn.sa = __half2float(ascale[blockIdx.x]);
+    dfn.ss = MODE == 0 ? __half2float(asum[blockIdx.x]) : 0.f;
+    qs_row::norm_quant_row<NC, TPB / 64, TPB / 64, true, false, qs_row::NoHook, qs_row::FromPlanes<KS, MODE>, FULL>(
+        out + base, hidden_io + base, nullptr, gamma, sum_out ? sum_out + blockIdx.x : nullptr, scale_out + blockIdx.x, eps,
+        hidden, sm, (int)threadIdx.x, qs_row::NoHook(), dfn);
 }
 
 //   silu_mul_quant : act = silu_and_mul(input) rounded to fp16 (never written) ; invoke_quant(_fuse_sum)(act)
@@ -525,9 +548,16 @@ extern "C" int qs_add_residual_rms_norm_general(int8_t* out, void* hidden_io, co
                8 * TPB * 8);
     const int nc = (hidden + TPB * 8 - 1) / (TPB * 8);
 #define QS_N(NC)                                                                                                      \
-    hipLaunchKernelGGL(add_residual_norm_quant_kernel<NC>, dim3(num_tokens), dim3(TPB), 0, (hipStream_t)stream, out,   \
-                       (_Float16*)hidden_io, (const _Float16*)delta, (const _Float16*)weight, (__half*)input_sum,      \
-                       (__half*)scaling, epsilon, hidden)
+    do {                                                                                                              \
+        if (hidden == NC * TPB * 8)                                                                                   \
+            hipLaunchKernelGGL((add_residual_norm_quant_kernel<NC, true>), dim3(num_tokens), dim3(TPB), 0,            \
+                               (hipStream_t)stream, out, (_Float16*)hidden_io, (const _Float16*)delta,                \
+                               (const _Float16*)weight, (__half*)input_sum, (__half*)scaling, epsilon, hidden);       \
+        else                                                                                                          \
+            hipLaunchKernelGGL((add_residual_norm_quant_kernel<NC, false>), dim3(num_tokens), dim3(TPB), 0,           \
+                               (hipStream_t)stream, out, (_Float16*)hidden_io, (const _Float16*)delta,                \
+                               (const _Float16*)weight, (__half*)input_sum, (__half*)scaling, epsilon, hidden);       \
+    } while (0)
     switch (nc) {
         case 1: QS_N(1); break;
         case 2: QS_N(2); break;
@@ -536,6 +566,59 @@ extern "C" int qs_add_residual_rms_norm_general(int8_t* out, void* hidden_io, co
     }
 #undef QS_N
     return qs_launch_status("add_residual_rms_norm_general");
+}
+
+extern "C" int qs_add_residual_rms_norm_general_planes(int8_t* out, void* hidden_io, const int32_t* planes, int k_slices,
+                                                       int64_t plane_stride, const void* wscales, const void* w_szs,
+                                                       const void* ascales, const void* a_ssums, const void* weight,
+                                                       void* input_sum, void* scaling, float epsilon, int num_tokens,
+                                                       int hidden, qs_stream_t stream) {
+    QS_REQUIRE(out && hidden_io && planes && wscales && ascales && weight && scaling,
+               "add_residual_rms_norm_general_planes: null pointer");
+    QS_REQUIRE((w_szs == nullptr) == (a_ssums == nullptr),
+               "add_residual_rms_norm_general_planes: w_szs and a_ssums come together (per-channel) or not at all (per-group)");
+    QS_REQUIRE(k_slices == 1 || k_slices == 2 || k_slices == 4, "add_residual_rms_norm_general_planes: k_slices=%d not in {1, 2, 4}",
+               k_slices);
+    QS_REQUIRE(hidden > 0 && hidden % 8 == 0 && plane_stride >= (int64_t)num_tokens * hidden && plane_stride % 4 == 0,
+               "add_residual_rms_norm_general_planes: hidden=%d (multiple of 8) / plane stride %lld", hidden, (long long)plane_stride);
+    QS_REQUIRE(!((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(wscales) | reinterpret_cast<uintptr_t>(w_szs)) & 15),
+               "add_residual_rms_norm_general_planes: planes / wscales / w_szs must be 16-byte aligned");
+    if (num_tokens <= 0) return QS_OK;
+    QS_REQUIRE(hidden <= 2 * TPB * 8, "add_residual_rms_norm_general_planes: hidden=%d larger than %d is not supported", hidden,
+               2 * TPB * 8);
+    const int nc = (hidden + TPB * 8 - 1) / (TPB * 8);
+#define QS_P(NC, KS, MODE)                                                                                                \
+    hipLaunchKernelGGL((add_residual_norm_quant_planes_kernel<NC, KS, MODE, FULLV>), dim3(num_tokens), dim3(TPB), 0,        \
+                       (hipStream_t)stream, out, (_Float16*)hidden_io, planes, (size_t)plane_stride, (const _Float16*)wscales, \
+                       (const _Float16*)w_szs, (const __half*)ascales, (const __half*)a_ssums, (const _Float16*)weight,     \
+                       (__half*)input_sum, (__half*)scaling, epsilon, hidden)
+#define QS_PF(NC, KS, MODE)                                       \
+    do {                                                          \
+        if (hidden == NC * TPB * 8) {                             \
+            constexpr bool FULLV = true;                          \
+            QS_P(NC, KS, MODE);                                   \
+        } else {                                                  \
+            constexpr bool FULLV = false;                         \
+            QS_P(NC, KS, MODE);                                   \
+        }                                                         \
+    } while (0)
+#define QS_PK(NC, MODE)                         \
+    do {                                        \
+        if (k_slices == 1) QS_PF(NC, 1, MODE);  \
+        else if (k_slices == 2) QS_PF(NC, 2, MODE); \
+        else QS_PF(NC, 4, MODE);                \
+    } while (0)
+    if (w_szs) {
+        if (nc == 1) QS_PK(1, 0);
+        else QS_PK(2, 0);
+    } else {
+        if (nc == 1) QS_PK(1, 1);
+        else QS_PK(2, 1);
+    }
+#undef QS_PK
+#undef QS_PF
+#undef QS_P
+    return qs_launch_status("add_residual_rms_norm_general_planes");
 }
 
 extern "C" int qs_silu_and_mul_quant(int8_t* out, const void* input, void* input_sum, void* scale, int num_tokens,

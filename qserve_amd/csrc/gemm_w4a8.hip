@@ -699,6 +699,69 @@ extern "C" int qs_w4a8_per_group_gemm_silu_mul(const int8_t* in_feats, const int
                            stream);
 }
 
+// ---- K-slice planes (round 4) ---------------------------------------------------------------------------------------------
+// The row-parallel GEMMs of a layer (o, down) are followed by a ROW kernel that reads their whole output anyway (residual add
+// + norm + quant).  In this form the GEMM leaves its K slices as int32 planes [k_slices][M][N] - no cross-workgroup seam, no
+// epilogue - and qs_add_residual_rms_norm_general_planes sums the planes and applies the GEMM's epilogue arithmetic itself:
+// the kernel boundary that is there anyway is the hand-off (in-launch it costs a 2.4-3 us round trip under load, see
+// gemm_w4a8_ring.hip).  Geometry by the ring kernel's byte model with the seam replaced by the planes' traffic (written once,
+// read once: 8 bytes per element and slice, weighted by the CU : HBM rate ratio).
+namespace {
+struct PlanesGeo {
+    int mt, wn, ks, mb;
+};
+bool planes_geometry(int mode, int M, int N, int K, PlanesGeo& g) {
+    if (M < 1 || M > 1024 || N < 64 || N % 64 || K < 1024 || K % 128 || (size_t)M * K >= (1ull << 32) ||
+        (size_t)N * K / 2 >= (1ull << 32))
+        return false;
+    const int mt_all = (M + 15) / 16;
+    static const int geo[6][2] = {{4, 2}, {2, 2}, {4, 1}, {2, 1}, {1, 1}, {4, 4}};
+    const int force = g_variant >= 4600 && g_variant < 5000 ? g_variant - 4600 : -1;   // tests / A-B: 4600 + 100*(ks-1) + 10*mt + wn
+    long best = -1;
+    for (int ks = 1; ks <= 4; ks *= 2)
+        for (int i = 0; i < 6; ++i) {
+            const int mt = geo[i][0], wn = geo[i][1];
+            if (N % (64 * wn) != 0 || (K / 64) % ks != 0 || (K / 64 / ks) % (8 / wn) != 0) continue;
+            if (force >= 0 && force != 100 * (ks - 1) + 10 * mt + wn) continue;
+            const int mb = (mt_all + mt - 1) / mt;
+            const long blocks = (long)mb * (N / (64 * wn)) * ks;
+            const long pg = mode == 1 ? 8 * wn : 0;
+            const long planes = (long)ks * M * N * 8 / 256 * 23 / 10;
+            const long cost = ((blocks + 255) / 256) * (16 * mt + 32 * wn + pg) * (long)(K / ks) * (ks > 1 ? 11 : 10) / 10 + planes;
+            if (best < 0 || cost < best) best = cost, g = {mt, wn, ks, mb};
+        }
+    return best >= 0;
+}
+template <int MODE>
+int gemm_planes(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t* scales8, int32_t* planes, int M, int N,
+                int K, qs_stream_t stream) {
+    QS_REQUIRE(A && W && planes && (MODE == 0 || (zeros && scales8)), "w4a8 gemm (planes): null pointer");
+    PlanesGeo g;
+    if (!planes_geometry(MODE, M, N, K, g)) {
+        qs_set_error("w4a8 gemm (planes): no ring geometry for M=%d N=%d K=%d (ask qs_w4a8_gemm_planes_plan first)", M, N, K);
+        return QS_ENOSUP;
+    }
+    return qs_launch_gemm_ring(MODE, 3, g.mt, g.wn, A, reinterpret_cast<const uint8_t*>(W), zeros, scales8, nullptr, nullptr,
+                               nullptr, nullptr, planes, M, N, K, g.mb, g.ks, nullptr, nullptr, (hipStream_t)stream);
+}
+}  // namespace
+
+extern "C" int qs_w4a8_gemm_planes_plan(int per_group, int M, int N, int K, int* plan4) {
+    QS_REQUIRE(plan4, "w4a8 gemm planes plan: null output");
+    PlanesGeo g = {0, 0, 0, 0};
+    if (!planes_geometry(per_group ? 1 : 0, M, N, K, g)) g = {0, 0, 0, 0};      // k_slices == 0: not available, run the pair
+    plan4[0] = g.ks, plan4[1] = g.mt, plan4[2] = g.wn, plan4[3] = g.mb;
+    return QS_OK;
+}
+extern "C" int qs_w4a8_per_chn_gemm_planes(const int8_t* in_feats, const int8_t* kernel, int32_t* planes, int M, int N, int K,
+                                           qs_stream_t stream) {
+    return gemm_planes<0>(in_feats, kernel, nullptr, nullptr, planes, M, N, K, stream);
+}
+extern "C" int qs_w4a8_per_group_gemm_planes(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros,
+                                             const int8_t* scales_i8, int32_t* planes, int M, int N, int K, qs_stream_t stream) {
+    return gemm_planes<1>(in_feats, kernel, zeros, scales_i8, planes, M, N, K, stream);
+}
+
 extern "C" int qs_w4a8_per_chn_gemm_acc(const int8_t* in_feats, const int8_t* kernel, int32_t* acc_out, int M, int N,
                                         int K, qs_stream_t stream) {
     return dispatch<0, 1>(in_feats, kernel, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, acc_out, M, N, K,

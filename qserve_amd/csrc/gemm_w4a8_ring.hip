@@ -329,7 +329,7 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
     // 14 % of the launch).  Layout: [w scale: 64 WN halfs | w scale*zero: 64 WN halfs | token scale: 64 x 4-byte slots | token
     // sum: 64 slots]; local channel = 64 wn + 32 t + ... (ACT: the 32 WN gate channels, then the 32 WN up channels).
     uint8_t* const s_sc = smem + SC_OFF;
-    if (OUTK != 1 && wave == 0) {
+    if ((OUTK == 0 || OUTK == 2) && wave == 0) {
         const u32 sc_lds = (u32)(size_t)(lptr_t)s_sc;
         auto dma4p = [&](const void* src, u32 dst) {
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(dst) : "memory");
@@ -524,7 +524,7 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
         // No fences (an agent-scope release / acquire writes back and invalidates the XCD's whole L2 under every other
         // workgroup's feet, measured +10 us): the slab traffic bypasses the caches (sc0 sc1), and the data is its own flag - a
         // word is either the sentinel or final, so torn 16-byte accesses are harmless.
-        if (KSPLIT && ksplit > 1) {
+        if (KSPLIT && OUTK != 3 && ksplit > 1) {
             const size_t tile = (size_t)(unit0 + wn) * mblocks + mblk;
             v4i* const slab = reinterpret_cast<v4i*>(slabs) + tile * ksplit * (size_t)(NP * 64) + lane;
             if (kq != ksplit - 1) {
@@ -600,9 +600,13 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
             const int pc = q * KG + kg;                // wave-uniform
             if (NP % KG != 0 && pc >= NP) continue;    // (fewer pieces than groups: MT = 1 with eight K-groups)
             const int mt = pc >> 2, cl = pc & 3;
-            if (OUTK == 1) {
+            if (OUTK == 1 || OUTK == 3) {
+                // OUTK == 3 (round 4): K-slice PLANES - every slice leaves its own int32 partial tile in plane kq of
+                // out [ksplit][M][N]; no seam at all: the consumer (the row kernel that follows, qs_add_residual_rms_norm_general_planes)
+                // sums the planes and applies this kernel's epilogue itself, and the kernel boundary is the hand-off
                 const int m = m0 + 16 * mt + li;
-                if (m < M) *reinterpret_cast<v4i*>(reinterpret_cast<int*>(out) + (size_t)m * N + ncol0 + 8 * cl) = sum[q];
+                int* const plane = reinterpret_cast<int*>(out) + (OUTK == 3 ? (size_t)kq * M * N : (size_t)0);
+                if (m < M) *reinterpret_cast<v4i*>(plane + (size_t)m * N + ncol0 + 8 * cl) = sum[q];
             } else {
                 // scale operands from the LDS staging area (requested at kernel start, see above)
                 const int lcol = lcol0 + 8 * cl;
@@ -636,7 +640,7 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
                 }
             }
         }
-        if (OUTK == 1) return;
+        if (OUTK == 1 || OUTK == 3) return;
         QS_STAMP(12);
         __syncthreads();                               // the fp16 tile of every unit is staged
         QS_STAMP(5);
@@ -751,13 +755,18 @@ template <int MT, int WN, int MODE, int OUTK>
 int ring_go(bool ks, const int8_t* A, const uint8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
             const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K, int mblocks,
             int ksplit, int* slabs, unsigned* counters, hipStream_t stream) {
-    if constexpr (OUTK != 2) {
-        if (ks)
-            return launch_ring<MT, WN, MODE, OUTK, true>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,
-                                                         mblocks, ksplit, slabs, counters, stream);
+    if constexpr (OUTK == 3) {                        // planes exist in the K-sliced instantiation only (one slice = OUTK 1)
+        return launch_ring<MT, WN, MODE, OUTK, true>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, mblocks,
+                                                     ksplit, nullptr, nullptr, stream);
+    } else {
+        if constexpr (OUTK != 2) {
+            if (ks)
+                return launch_ring<MT, WN, MODE, OUTK, true>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,
+                                                             mblocks, ksplit, slabs, counters, stream);
+        }
+        return launch_ring<MT, WN, MODE, OUTK, false>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,
+                                                      mblocks, 1, nullptr, nullptr, stream);
     }
-    return launch_ring<MT, WN, MODE, OUTK, false>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, mblocks,
-                                                  1, nullptr, nullptr, stream);
 }
 }  // namespace
 
@@ -778,7 +787,7 @@ int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, con
         qs_set_error("w4a8 gemm (ring): the activation epilogue has no K-sliced form");
         return QS_ENOSUP;
     }
-    if (outk != 1 && ((reinterpret_cast<uintptr_t>(wscales) & 3) || (mode == 0 && (reinterpret_cast<uintptr_t>(wszs) & 3)))) {
+    if ((outk == 0 || outk == 2) && ((reinterpret_cast<uintptr_t>(wscales) & 3) || (mode == 0 && (reinterpret_cast<uintptr_t>(wszs) & 3)))) {
         // (the reference reads them as half2, gemm_cuda.cu:581-582: the same requirement)
         qs_set_error("w4a8 gemm: wscales / w_szs must be 4-byte aligned");
         return QS_EINVAL;
@@ -806,6 +815,8 @@ int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, con
     if (mode == 1 && outk == 0) QS_RM(1, 0);
     if (mode == 1 && outk == 1) QS_RM(1, 1);
     if (mode == 1 && outk == 2) QS_RM(1, 2);
+    if (mode == 0 && outk == 3) QS_RM(0, 3);
+    if (mode == 1 && outk == 3) QS_RM(1, 3);
 #undef QS_RM
 #undef QS_R
     qs_set_error("w4a8 gemm (ring): unsupported geometry mt=%d wn=%d", mt, wn);

@@ -16,8 +16,16 @@
 // stand-alone kernel (NVW = PW = 4) and a 512-thread GEMM workgroup running the same (NVW, NC) produce identical bits.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace qs_row {
+
+// The fp32 row statistics are DEFINED as sequential sums over a virtual thread's elements (what the numpy oracle computes).  The
+// compiler must not see two consecutive additions of a chain at once: in the branch-free (FULL) instantiations of round 4 it
+// packed the chain into v_pk_add_f32 - two interleaved partial sums - and a row sum came out one fp16 ulp away from the
+// branchy instantiation of the same source.  An empty asm with the accumulator as in-out operand costs no instruction and makes
+// every addition opaque to the vectoriser.
+#define QS_SEQ(x) asm volatile("" : "+v"(x))
 
 // rows wider than this use the 1024-virtual-thread layout (same rule for invoke_quant and silu_and_mul_quant, so the
 // two associate their fp32 statistics identically)
@@ -50,6 +58,69 @@ __device__ __forceinline__ float ln_val(float x, float mean, float rstd, float g
 
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
+};
+
+// the W4A8 GEMMs' fused epilogues (gemm_w4a8*.hip: epi_per_chn / epi_per_group - the same statements, the same roundings)
+__device__ __forceinline__ float gemm_epi_per_chn(int acc, float ws, float sa, float wz, float ss) {
+#pragma clang fp contract(off)
+    float t = (float)acc * ws;
+    t = t * sa;
+    const float u = wz * ss;
+    return t - u;
+}
+__device__ __forceinline__ float gemm_epi_per_group(int acc, float ws, float sa) {
+#pragma clang fp contract(off)
+    const float sc = ws * sa;
+    return (float)acc * sc;
+}
+
+// `delta` of norm_quant_row, by where it comes from.  FromRow: an fp16 row in memory (the residual branch's GEMM output).
+// FromPlanes (round 4): the K-slice planes a W4A8 GEMM left instead of its output (qs_w4a8_*_gemm_planes: int32 [KS][M][N]) -
+// the 8 values of a chunk are the planes' sums pushed through the GEMM's own epilogue, rounded to fp16 exactly as the GEMM would
+// have stored them, so everything downstream sees the same bits.
+struct FromRow {
+    const _Float16* row;
+    struct Raw {
+        v4u d;
+    };
+    __device__ __forceinline__ Raw load(int i) const { return Raw{__builtin_bit_cast(v4u, load8(row + i))}; }
+    __device__ __forceinline__ v4u finish(const Raw& r) const { return r.d; }
+};
+template <int KS, int MODE>
+struct FromPlanes {
+    const int* row0;          // this token's row in plane 0
+    size_t pstride;           // elements between planes (M * N)
+    const _Float16 *ws, *wz;  // per-channel weight scale, scale * zero (MODE 0 only)
+    float sa, ss;             // the token's activation scale / sum as the GEMM saw them
+    // two phases, so that every request of a row is out before the first value is needed (one memory round trip)
+    struct Raw {
+        v4i a[KS][2];
+        h8 wsv, wzv;
+    };
+    __device__ __forceinline__ Raw load(int i) const {
+        Raw r;
+#pragma unroll
+        for (int z = 0; z < KS; ++z) {
+            r.a[z][0] = *reinterpret_cast<const v4i*>(row0 + z * pstride + i);
+            r.a[z][1] = *reinterpret_cast<const v4i*>(row0 + z * pstride + i + 4);
+        }
+        r.wsv = load8(ws + i);
+        if (MODE == 0) r.wzv = load8(wz + i);
+        return r;
+    }
+    __device__ __forceinline__ v4u finish(const Raw& r) const {
+        v4i a0 = r.a[0][0], a1 = r.a[0][1];
+#pragma unroll
+        for (int z = 1; z < KS; ++z) a0 += r.a[z][0], a1 += r.a[z][1];
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int acc = e < 4 ? a0[e & 3] : a1[e & 3];
+            o[e] = MODE == 0 ? (_Float16)gemm_epi_per_chn(acc, (float)r.wsv[e], sa, (float)r.wzv[e], ss)
+                             : (_Float16)gemm_epi_per_group(acc, (float)r.wsv[e], sa);
+        }
+        return __builtin_bit_cast(v4u, o);
+    }
 };
 
 // ---- block reductions over the NVW virtual waves (one barrier each; every round has its own LDS slots) ----------------
@@ -109,7 +180,9 @@ __device__ __forceinline__ void quant_row(int8_t* __restrict__ out, const _Float
     constexpr int VPW = NVW / PW, NT = 64 * NVW;
     static_assert(NVW % PW == 0, "virtual waves must split evenly over the physical waves");
     const int wave = tid >> 6, lane = tid & 63;
-    const bool active = tid < 64 * PW;
+    constexpr bool active = true;   // (every thread of the workgroup owns elements: the launch has exactly 64 PW threads.  The
+                                    //  round-3 GEMM tails ran these functions on a subset of a larger workgroup; as a run-time
+                                    //  test the compiler zero-fills and copies every loaded register at the join - with a wait)
     ready();
     v4u raw[VPW][NC];
     if (active) {
@@ -140,6 +213,7 @@ __device__ __forceinline__ void quant_row(int8_t* __restrict__ out, const _Float
                     for (int e = 0; e < 8; ++e) {
                         const float f = (float)v[e];
                         sum[j] += f;
+                        QS_SEQ(sum[j]);
                         amax[j] = fmaxf(amax[j], fabsf(f));
                     }
                 }
@@ -174,11 +248,14 @@ __device__ __forceinline__ void quant_row(int8_t* __restrict__ out, const _Float
 // ADD = false: no residual (plain general_norm_quant; `delta` unused, hidden_io read only).  sm: 4 * NVW floats of LDS.
 // SC: `delta` was published by other workgroups of this launch.  `ready` runs after the loads of hidden / gamma were
 // requested and before the first load of `delta`.
-template <int NC, int NVW, int PW, bool ADD, bool SC, class Hook = NoHook>
+template <int NC, int NVW, int PW, bool ADD, bool SC, class Hook = NoHook, class DeltaFn = FromRow, bool FULL = false>
 __device__ __forceinline__ void norm_quant_row(int8_t* __restrict__ out, _Float16* __restrict__ hidden_io,
                                                const _Float16* __restrict__ delta, const _Float16* __restrict__ gamma,
                                                __half* __restrict__ sum_out, __half* __restrict__ scale_out, float eps,
-                                               int hidden, float* sm, int tid, Hook ready = Hook()) {
+                                               int hidden, float* sm, int tid, Hook ready = Hook(), DeltaFn dfn = DeltaFn()) {
+    // FULL: the row is exactly NC * NT * 8 values wide (every chunk of every thread exists): no exec-masked blocks, so the compiler
+    // can count the outstanding loads across them and issue the final stores back to back (round 4: with the masks it put a
+    // vmcnt(0) - a store acknowledgement - between the two chunks' stores).
     // No FMA contraction anywhere in the statistics: `vs += d * d` summed over a row may be fused as fma(d1, d1, round(d0 * d0))
     // or as fma(d0, d0, round(d1 * d1)) - both are legal contractions and hipcc picks differently from one instantiation to
     // the next (seen: the 256-thread kernel vs the same code inlined into a GEMM tail differed in one row sum by one fp16
@@ -187,7 +264,9 @@ __device__ __forceinline__ void norm_quant_row(int8_t* __restrict__ out, _Float1
     constexpr int VPW = NVW / PW, NT = 64 * NVW;
     static_assert(NVW % PW == 0, "virtual waves must split evenly over the physical waves");
     const int wave = tid >> 6, lane = tid & 63;
-    const bool active = tid < 64 * PW;
+    constexpr bool active = true;   // (every thread of the workgroup owns elements: the launch has exactly 64 PW threads.  The
+                                    //  round-3 GEMM tails ran these functions on a subset of a larger workgroup; as a run-time
+                                    //  test the compiler zero-fills and copies every loaded register at the join - with a wait)
     h8 v[VPW][NC], g[VPW][NC];
     v4u dl[VPW][NC];
     // every load of the row is requested before the first one is used (with load and use in one loop body the second
@@ -198,7 +277,7 @@ __device__ __forceinline__ void norm_quant_row(int8_t* __restrict__ out, _Float1
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int i = (c * NT + tid + j * 64 * PW) * 8;
-                if (i < hidden) {
+                if (FULL || i < hidden) {
                     v[j][c] = load8(hidden_io + i);
                     g[j][c] = load8(gamma + i);
                 }
@@ -206,17 +285,39 @@ __device__ __forceinline__ void norm_quant_row(int8_t* __restrict__ out, _Float1
     }
     ready();
     if (ADD && active) {
-        const ScRow sc(delta, SC ? hidden : 0);
+        if constexpr (std::is_same<DeltaFn, FromRow>::value) {
+            const ScRow sc(delta, SC ? hidden : 0);
 #pragma unroll
-        for (int j = 0; j < VPW; ++j)
+            for (int j = 0; j < VPW; ++j)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int i = (c * NT + tid + j * 64 * PW) * 8;
-                if (i < hidden) {
-                    if (SC) dl[j][c] = sc.load8(i);
-                    else dl[j][c] = __builtin_bit_cast(v4u, load8(delta + i));
+                for (int c = 0; c < NC; ++c) {
+                    const int i = (c * NT + tid + j * 64 * PW) * 8;
+                    if (FULL || i < hidden) {
+                        if (SC) dl[j][c] = sc.load8(i);
+                        else dl[j][c] = __builtin_bit_cast(v4u, load8(delta + i));
+                    }
                 }
-            }
+            if (FULL) __builtin_amdgcn_sched_barrier(0);   // every request of the row is out before the first value is used
+        } else {
+            typename DeltaFn::Raw raw[VPW][NC];
+#pragma unroll
+            for (int j = 0; j < VPW; ++j)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const int i = (c * NT + tid + j * 64 * PW) * 8;
+                    if (FULL || i < hidden) raw[j][c] = dfn.load(i);
+                }
+            // (without the exec-masked blocks the scheduler is free to sink a chunk's requests behind the previous chunk's
+            //  arithmetic - seen in the ISA: one memory round trip per chunk; nothing may cross this point)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < VPW; ++j)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const int i = (c * NT + tid + j * 64 * PW) * 8;
+                    if (FULL || i < hidden) dl[j][c] = dfn.finish(raw[j][c]);
+                }
+        }
     }
     float s[VPW];
 #pragma unroll
@@ -226,13 +327,16 @@ __device__ __forceinline__ void norm_quant_row(int8_t* __restrict__ out, _Float1
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int i = (c * NT + tid + j * 64 * PW) * 8;
-                if (i < hidden) {
+                if (FULL || i < hidden) {
                     // (the sum is written back at the END of the kernel, with the other stores: stored here, the compiler's
                     //  vmcnt(0) at the next control-flow join - it cannot count across the exec-masked load blocks above -
                     //  also waited for this store's acknowledgement, a memory round trip in front of the first reduction)
                     if (ADD) v[j][c] = v[j][c] + __builtin_bit_cast(h8, dl[j][c]);         // the residual add's fp16 add
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) s[j] += (float)v[j][c][e];
+                    for (int e = 0; e < 8; ++e) {
+                        s[j] += (float)v[j][c][e];
+                        QS_SEQ(s[j]);
+                    }
                 }
             }
         }
@@ -245,11 +349,12 @@ __device__ __forceinline__ void norm_quant_row(int8_t* __restrict__ out, _Float1
         if (active) {
 #pragma unroll
             for (int c = 0; c < NC; ++c)
-                if ((c * NT + tid + j * 64 * PW) * 8 < hidden) {
+                if (FULL || (c * NT + tid + j * 64 * PW) * 8 < hidden) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float d = (float)v[j][c][e] - mean;
                         vs[j] += d * d;
+                        QS_SEQ(vs[j]);
                     }
                 }
         }
@@ -263,12 +368,18 @@ __device__ __forceinline__ void norm_quant_row(int8_t* __restrict__ out, _Float1
         if (active) {
 #pragma unroll
             for (int c = 0; c < NC; ++c)
-                if ((c * NT + tid + j * 64 * PW) * 8 < hidden) {
+                if (FULL || (c * NT + tid + j * 64 * PW) * 8 < hidden) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const _Float16 hv = (_Float16)ln_val((float)v[j][c][e], mean, rstd_e, (float)g[j][c][e]);   // cast to half, :292
+                        // (the fp32 value is made opaque before the conversion: left to itself the compiler turns "multiply,
+                        //  convert" into ONE v_fma_mixlo_f16 - a single rounding - in some instantiations and into v_mul + v_cvt
+                        //  in others; the row statistics then differ by an fp16 ulp between kernels that share this source)
+                        float hvf = ln_val((float)v[j][c][e], mean, rstd_e, (float)g[j][c][e]);
+                        QS_SEQ(hvf);
+                        const _Float16 hv = (_Float16)hvf;                                                     // cast to half, :292
                         amax[j] = fmaxf(amax[j], fabsf((float)hv));
                         sum[j] += (float)hv;
+                        QS_SEQ(sum[j]);
                     }
                 }
         }
@@ -282,7 +393,7 @@ __device__ __forceinline__ void norm_quant_row(int8_t* __restrict__ out, _Float1
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int i = (c * NT + tid + j * 64 * PW) * 8;
-                if (i < hidden) {
+                if (FULL || i < hidden) {
                     float f[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = ln_val((float)v[j][c][e], mean, rstd_e, (float)g[j][c][e]);   // fp32, :315

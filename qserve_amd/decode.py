@@ -16,6 +16,8 @@ served from cache); the KV cache is filled by the prefill writer.  Tensor parall
 H/tp query heads, Hkv/tp KV heads and the matching column / row shards; the partial outputs of o_proj and
 down_proj are summed with one RCCL all-reduce each.
 """
+import os
+
 import torch
 
 import qserve_backend.activation_ops as activation_ops
@@ -101,6 +103,29 @@ class W4A8Linear:
         if self.bias is not None and not self.defer_bias:
             out += self.bias
 
+    def planes_slices(self, tokens):
+        """K slices of the planes form of this projection at `tokens` rows (0: not available / has a bias: run the pair)."""
+        if self.bias is not None:
+            return 0
+        return fusedmod.gemm_planes_plan(tokens, self.n, self.k, self.group_size != -1)
+
+    def planes(self, x, planes):
+        """The GEMM as K-slice planes (int32 [k_slices, T, n]); its epilogue runs inside the row kernel that follows
+        (`add_norm_quant_planes`)."""
+        if self.group_size == -1:
+            fusedmod.gemm_planes(x, self.qweight, planes)
+        else:
+            fusedmod.gemm_planes(x, self.qweight, planes, self.s2_zeros, self.s2_scales)
+
+    def add_norm_quant_planes(self, out, hidden, planes, input_scales, input_sum, weight, scaling, eps, out_sum):
+        """hidden += this projection's output (from its planes) ; out / scaling (/ out_sum) = rms_norm_general(hidden)."""
+        if self.group_size == -1:
+            fusedmod.add_residual_rms_norm_general_planes(out, hidden, planes, self.s1_scales, input_scales, weight, scaling, eps,
+                                                          w_szs=self.s1_szeros, a_ssums=input_sum, input_sum=out_sum)
+        else:
+            fusedmod.add_residual_rms_norm_general_planes(out, hidden, planes, self.s1_scales, input_scales, weight, scaling, eps,
+                                                          input_sum=out_sum)
+
     def silu_mul(self, x, input_scales, input_sum, out_act, tmp):
         """gate_up projection + silu_and_mul as one op (qserve_amd.fused.gemm_silu_and_mul_*): out_act [T, n/2].  Only for
         a stacked gate_up weight without bias (the bias would have to be added between the two ops)."""
@@ -115,7 +140,7 @@ class W4A8Linear:
 
 class DecodeEngine:
     def __init__(self, cfg, batch, prompt_len, max_new, group_size=-1, int4_kv=True, device="cuda:0", seed=0,
-                 tp_rank=0, tp_world=1, with_lm_head=True, fuse_pairs=True, weights=None, vocab_parallel=True,
+                 tp_rank=0, tp_world=1, with_lm_head=True, fuse_pairs=True, weights=None, vocab_parallel=True, planes=None,
                  direct_allreduce=None):
         """weights: None = synthetic random-quantised tensors of the right shapes; otherwise this rank's tensors as
         qserve_amd.loader.load_llama_w4a8 returns them (checkpoint path)."""
@@ -205,6 +230,17 @@ class DecodeEngine:
         self.gate_up_buf = torch.empty((B, 2 * inter), dtype=f16, device=self.dev)
         self.mlp_act = torch.empty((B, inter), dtype=f16, device=self.dev)
         self.final = torch.empty((B, hid), dtype=f16, device=self.dev)
+        # K-slice planes (qserve_amd.fused.gemm_planes): the row-parallel projections named in `planes` (default: QS_PLANES or
+        # "down") leave int32 partial sums per K slice and the add + norm + quant launch behind them finishes the GEMM - where
+        # the pair fusions are on, on one GPU, for shapes the library has such a launch for
+        if planes is None:
+            planes = tuple(x for x in os.environ.get("QS_PLANES", "down").split(",") if x)
+        self.planes = {}
+        if fuse_pairs and tp_world == 1 and hid <= 4096 and hid % 2048 == 0:
+            for name in planes:
+                ks = self.layers[0][name].planes_slices(B)
+                if ks:
+                    self.planes[name] = torch.empty((ks, B, hid), dtype=torch.int32, device=self.dev)
         self.lengths = torch.full((B,), prompt_len, dtype=torch.int32, device=self.dev)   # context incl. new token
         self.tokens = torch.randint(0, cfg["vocab"], (B,), device=self.dev, generator=gen)
         # Tensor parallel: the (un-quantised) lm_head is cut over the vocabulary - rank r multiplies rows [v0, v0 + V/N)
@@ -364,6 +400,17 @@ class DecodeEngine:
                 residual_add_(x, delta)
                 norm_quant(x, w)
 
+        # (row-parallel GEMM, add + norm + quant) as K-slice planes: the GEMM leaves int32 partial sums per K slice, the row
+        # kernel that follows sums them and applies the GEMM's epilogue (bit-identical pair fusion; single GPU only - under
+        # tensor parallelism the all-reduce sits between the two)
+        def proj_add_norm_quant(lin, name, xq, x, w):
+            pl = self.planes.get(name) if fuse and self.tp_world == 1 else None
+            if pl is not None:
+                lin.planes(xq, pl)
+                lin.add_norm_quant_planes(qa, x, pl, self.q_scale, self.q_sum, w, self.q_scale, cfg["eps"], sums)
+                return True
+            return False
+
         nl = len(self.layers)
         for li, L in enumerate(self.layers):
             if li == 0:
@@ -385,14 +432,15 @@ class DecodeEngine:
                     fused_kernels.invoke_quant_fuse_sum(qo, attn, self.q_sum, self.q_scale)
                 else:
                     fused_kernels.invoke_quant(qo, attn, self.q_scale)
-            L["o"](qo, self.q_scale, self.q_sum, self.proj_out)
-            res = self.proj_out
-            if self.tp_world > 1:
-                yield self.proj_out
-                res = self.proj_res
-                if L["o"].defer_bias and L["o"].bias is not None:
-                    res += L["o"].bias                    # once, after the reduce
-            add_norm_quant(h, res, L["ln2"])
+            if not proj_add_norm_quant(L["o"], "o", qo, h, L["ln2"]):
+                L["o"](qo, self.q_scale, self.q_sum, self.proj_out)
+                res = self.proj_out
+                if self.tp_world > 1:
+                    yield self.proj_out
+                    res = self.proj_res
+                    if L["o"].defer_bias and L["o"].bias is not None:
+                        res += L["o"].bias                    # once, after the reduce
+                add_norm_quant(h, res, L["ln2"])
             if fuse and L["gate_up"].bias is None:     # gate_up GEMM with the silu * mul epilogue, then the quantiser
                 L["gate_up"].silu_mul(qa, self.q_scale, self.q_sum, self.mlp_act, self.gate_up_buf)
             else:
@@ -406,6 +454,8 @@ class DecodeEngine:
                     fused_kernels.invoke_quant_fuse_sum(self.q_mlp, self.mlp_act, self.q_sum, self.q_scale)
                 else:
                     fused_kernels.invoke_quant(self.q_mlp, self.mlp_act, self.q_scale)
+            if li + 1 < nl and proj_add_norm_quant(L["down"], "down", self.q_mlp, h, self.layers[li + 1]["ln1"]):
+                continue                                             # (next layer's input norm done from the planes)
             L["down"](self.q_mlp, self.q_scale, self.q_sum, self.proj_out)
             res = self.proj_out
             if self.tp_world > 1:

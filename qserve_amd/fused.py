@@ -126,3 +126,57 @@ def _gemm_common(per_group, in_feats, kernel, rest):
     if kernel.size(1) * 2 != K:
         raise RuntimeError(f"w4a8 gemm: kernel {tuple(kernel.shape)} does not match K={K}")
     return M, N, K
+
+
+# ---- K-slice planes: (row-parallel GEMM, add + norm + quant) with the GEMM's cross-workgroup reduction and epilogue moved into
+# the row kernel that follows it anyway (include/qserve_amd.h, "K-slice PLANES") ------------------------------------------------
+def gemm_planes_plan(M, N, K, per_group=False):
+    """-> number of K slices the planes launch of this shape uses (0: no such launch, run the ordinary pair)."""
+    import ctypes as C
+    buf = (C.c_int * 4)()
+    check(lib.qs_w4a8_gemm_planes_plan(int(bool(per_group)), int(M), int(N), int(K), C.cast(buf, C.c_void_p)), "fused.gemm_planes_plan")
+    return int(buf[0])
+
+
+def gemm_planes(in_feats, kernel, planes, zeros=None, scales_i8=None):
+    """planes int32 [k_slices, M, N] (k_slices = gemm_planes_plan(M, N, K)): the W4A8 GEMM's partial sums per K slice,
+    per-channel (zeros / scales_i8 None) or per-group."""
+    per_group = zeros is not None
+    M, N, K = _gemm_common(per_group, in_feats, kernel, (zeros, scales_i8) if per_group else ())
+    expect(planes, torch.int32, "planes")
+    ks = gemm_planes_plan(M, N, K, per_group)
+    if ks == 0 or tuple(planes.shape) != (ks, M, N):
+        raise RuntimeError(f"gemm_planes: planes {tuple(planes.shape)} but this shape runs as {ks} x [{M}, {N}]")
+    with guard(in_feats):
+        if per_group:
+            check(lib.qs_w4a8_per_group_gemm_planes(ptr(in_feats), ptr(kernel), ptr(zeros), ptr(scales_i8), ptr(planes), M, N, K,
+                                                    stream()), "fused.gemm_planes")
+        else:
+            check(lib.qs_w4a8_per_chn_gemm_planes(ptr(in_feats), ptr(kernel), ptr(planes), M, N, K, stream()), "fused.gemm_planes")
+
+
+def add_residual_rms_norm_general_planes(out, hidden, planes, wscales, ascales, weight, scaling, epsilon, w_szs=None,
+                                         a_ssums=None, input_sum=None):
+    """== gemm(..., delta) ; add_residual_rms_norm_general(out, hidden, delta, weight, scaling, epsilon, input_sum) where the GEMM
+    ran as gemm_planes: wscales / w_szs [hidden] and ascales / a_ssums [T] are that GEMM's epilogue operands (w_szs and a_ssums
+    None together = per-group).  ascales / a_ssums may be the very tensors scaling / input_sum are written to."""
+    expect(out, torch.int8, "out")
+    expect(hidden, torch.float16, "hidden")
+    expect(planes, torch.int32, "planes")
+    for n, t in (("wscales", wscales), ("ascales", ascales), ("weight", weight), ("scaling", scaling)):
+        expect(t, torch.float16, n)
+    if (w_szs is None) != (a_ssums is None):
+        raise RuntimeError("add_residual_rms_norm_general_planes: w_szs and a_ssums come together or not at all")
+    for n, t in (("w_szs", w_szs), ("a_ssums", a_ssums), ("input_sum", input_sum)):
+        if t is not None:
+            expect(t, torch.float16, n)
+    hid = hidden.size(-1)
+    T = hidden.numel() // hid
+    if planes.dim() != 3 or planes.size(1) != T or planes.size(2) != hid:
+        raise RuntimeError(f"add_residual_rms_norm_general_planes: planes {tuple(planes.shape)} vs hidden [{T}, {hid}]")
+    with guard(out):
+        check(lib.qs_add_residual_rms_norm_general_planes(
+            ptr(out), ptr(hidden), ptr(planes), planes.size(0), planes.stride(0), ptr(wscales),
+            ptr(w_szs) if w_szs is not None else 0, ptr(ascales), ptr(a_ssums) if a_ssums is not None else 0, ptr(weight),
+            ptr(input_sum) if input_sum is not None else 0, ptr(scaling), float(epsilon), T, hid, stream()),
+            "fused.add_residual_rms_norm_general_planes")

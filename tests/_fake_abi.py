@@ -163,6 +163,51 @@ def qs_add_residual_rms_norm_general(out, hidden_io, delta, weight, input_sum, s
     return qs_rms_norm_general(out, hidden_io, weight, input_sum, scaling, eps, T, hidden, stream)
 
 
+# ---- K-slice planes: the GEMM leaves int32 partial sums per slice, the row kernel finishes it (include/qserve_amd.h) --------------
+FAKE_PLANE_SLICES = 2
+
+
+def qs_w4a8_gemm_planes_plan(per_group, M, N, K, plan4):
+    p = _arr(plan4, (4,), np.int32)
+    p[:] = (FAKE_PLANE_SLICES if K >= 1024 and N % 64 == 0 and K % 128 == 0 else 0, 2, 1, (M + 31) // 32)
+    return 0
+
+
+def _split_planes(acc, planes, M, N):
+    """the exact sum in `FAKE_PLANE_SLICES` unequal integer parts (the product must sum them, whatever the split)"""
+    pl = _arr(planes, (FAKE_PLANE_SLICES, M, N), np.int32)
+    pl[1:] = 7
+    pl[0] = acc - 7 * (FAKE_PLANE_SLICES - 1)
+
+
+def qs_w4a8_per_chn_gemm_planes(in_feats, kernel, planes, M, N, K, stream):
+    CALLS.append(("qs_w4a8_per_chn_gemm_planes", M, N, K))
+    _split_planes(w4a8.gemm_per_chn_acc(_arr(in_feats, (M, K), np.int8), _arr(kernel, (N, K // 2), np.int8)), planes, M, N)
+    return 0
+
+
+def qs_w4a8_per_group_gemm_planes(in_feats, kernel, zeros, scales_i8, planes, M, N, K, stream):
+    CALLS.append(("qs_w4a8_per_group_gemm_planes", M, N, K))
+    acc = w4a8.gemm_per_group_acc(_arr(in_feats, (M, K), np.int8), _arr(kernel, (N, K // 2), np.int8),
+                                  _arr(zeros, (K // 128, N), np.int8), _arr(scales_i8, (K // 128, N), np.int8))
+    _split_planes(acc, planes, M, N)
+    return 0
+
+
+def qs_add_residual_rms_norm_general_planes(out, hidden_io, planes, k_slices, plane_stride, wscales, w_szs, ascales, a_ssums,
+                                            weight, input_sum, scaling, eps, T, hidden, stream):
+    CALLS.append(("qs_add_residual_rms_norm_general_planes", k_slices, T, hidden))
+    assert plane_stride == T * hidden
+    acc = _arr(planes, (k_slices, T, hidden), np.int32).astype(np.int64).sum(axis=0).astype(np.int32)
+    ws, sa = _arr(wscales, (hidden,), np.float16), _arr(ascales, (T,), np.float16).copy()
+    if w_szs:
+        delta = w4a8.epilogue_per_chn(acc, ws, sa, _arr(w_szs, (hidden,), np.float16), _arr(a_ssums, (T,), np.float16).copy())
+    else:
+        delta = w4a8.epilogue_per_group(acc, ws, sa)
+    delta = np.ascontiguousarray(delta)
+    return qs_add_residual_rms_norm_general(out, hidden_io, delta.ctypes.data, weight, input_sum, scaling, eps, T, hidden, stream)
+
+
 def qs_silu_and_mul_quant(out, inp, input_sum, scale, T, d, stream):
     tmp = np.empty((T, d), np.float16)
     tmp[:] = ofused.silu_and_mul(_arr(inp, (T, 2 * d), np.float16))
@@ -244,6 +289,7 @@ SYMBOLS = {f.__name__: f for f in (
     qs_w4a8_per_chn_gemm, qs_w4a8_per_group_gemm, qs_w4a8_per_chn_gemm_silu_mul, qs_w4a8_per_group_gemm_silu_mul,
     qs_invoke_quant, qs_rms_norm_general, qs_rms_norm, qs_silu_and_mul,
     qs_residual_add, qs_argmax_rows, qs_add_residual_rms_norm_general, qs_silu_and_mul_quant, qs_compute_padding_offsets,
+    qs_w4a8_gemm_planes_plan, qs_w4a8_per_chn_gemm_planes, qs_w4a8_per_group_gemm_planes, qs_add_residual_rms_norm_general_planes,
     qs_apply_bias_rope_update_kv_cache, qs_single_query_attention, qs_single_query_attention_quant,
     qs_flash_attn_varlen_fwd)}
 
