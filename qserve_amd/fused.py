@@ -130,12 +130,21 @@ def _gemm_common(per_group, in_feats, kernel, rest):
 
 # ---- K-slice planes: (row-parallel GEMM, add + norm + quant) with the GEMM's cross-workgroup reduction and epilogue moved into
 # the row kernel that follows it anyway (include/qserve_amd.h, "K-slice PLANES") ------------------------------------------------
+_PLANES_PLAN = {}
+
+
 def gemm_planes_plan(M, N, K, per_group=False):
-    """-> number of K slices the planes launch of this shape uses (0: no such launch, run the ordinary pair)."""
+    """-> number of K slices the planes launch of this shape uses (0: no such launch, run the ordinary pair).  Deterministic
+    in the shape (and in the library's A/B switch, which tests change): cached per shape while the switch is at its default."""
     import ctypes as C
-    buf = (C.c_int * 4)()
-    check(lib.qs_w4a8_gemm_planes_plan(int(bool(per_group)), int(M), int(N), int(K), C.cast(buf, C.c_void_p)), "fused.gemm_planes_plan")
-    return int(buf[0])
+    key = (int(M), int(N), int(K), bool(per_group))
+    ks = _PLANES_PLAN.get(key)
+    if ks is None or _PLANES_PLAN.get("nocache"):
+        buf = (C.c_int * 4)()
+        check(lib.qs_w4a8_gemm_planes_plan(int(key[3]), key[0], key[1], key[2], C.cast(buf, C.c_void_p)), "fused.gemm_planes_plan")
+        ks = int(buf[0])
+        _PLANES_PLAN[key] = ks
+    return ks
 
 
 def gemm_planes(in_feats, kernel, planes, zeros=None, scales_i8=None):
@@ -144,8 +153,10 @@ def gemm_planes(in_feats, kernel, planes, zeros=None, scales_i8=None):
     per_group = zeros is not None
     M, N, K = _gemm_common(per_group, in_feats, kernel, (zeros, scales_i8) if per_group else ())
     expect(planes, torch.int32, "planes")
+    if planes.dim() != 3 or planes.size(1) != M or planes.size(2) != N or not planes.is_contiguous():
+        raise RuntimeError(f"gemm_planes: planes {tuple(planes.shape)} for a [{M}, {N}] product")
     ks = gemm_planes_plan(M, N, K, per_group)
-    if ks == 0 or tuple(planes.shape) != (ks, M, N):
+    if ks == 0 or planes.size(0) != ks:
         raise RuntimeError(f"gemm_planes: planes {tuple(planes.shape)} but this shape runs as {ks} x [{M}, {N}]")
     with guard(in_feats):
         if per_group:

@@ -56,6 +56,7 @@ def test_planes_pair_is_bit_identical_to_the_ordinary_pair(gpu, M, N, K, variant
     h1, q1, sc1, sm1 = _pair(t, per_group, hidden, gamma, M, N)
     try:
         _lib.lib.qs_set_gemm_variant(variant)
+        fused._PLANES_PLAN["nocache"] = True            # (the plan depends on the A/B switch this test turns)
         ks = fused.gemm_planes_plan(M, N, K, per_group)
         assert ks in (1, 2, 4)
         if variant >= 4600:
@@ -67,6 +68,7 @@ def test_planes_pair_is_bit_identical_to_the_ordinary_pair(gpu, M, N, K, variant
             fused.gemm_planes(t["A"], t["qweight"], planes)
     finally:
         _lib.lib.qs_set_gemm_variant(-1)
+        fused._PLANES_PLAN.clear()
     assert np.array_equal(planes.sum(dim=0, dtype=torch.int64).cpu().numpy(), acc.astype(np.int64)), "planes do not sum to the accumulators"
     h2 = hidden.clone()
     q2 = torch.empty((M, N), dtype=torch.int8, device=gpu)
