@@ -777,7 +777,10 @@ def main():
                        "layers": cfg["layers"],
                        "op_sequence": "reference ops one by one" if args.op_by_op else
                        ("reference ops; (residual add, layer norm), (gate_up GEMM, silu_and_mul) and (attention, quant) "
-                        "issued as bit-identical fused pairs (qserve_amd/fused.py)"),
+                        "issued as bit-identical fused pairs (qserve_amd/fused.py)" +
+                        ("; K-slice planes: " + ", ".join(f"{n}_proj leaves int32 partial sums per K slice ({p.size(0)}), the add + "
+                                                          "norm + quant launch behind it finishes the GEMM" for n, p in eng.planes.items())
+                         if getattr(eng, "planes", None) else "")),
                        "launches_per_layer": 8 if not args.op_by_op else 12,
                        "value_context": f"decode steps at context {start_len + args.warmup}..{start_len + args.warmup + args.steps - 1} "
                                         "(start of the 1024 -> +512 generation); mid / end of generation: "
