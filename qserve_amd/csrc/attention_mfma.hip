@@ -764,7 +764,9 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
 #pragma unroll
         for (int w = 0; w < NW; ++w) M = fmaxf(M, s_m[w][h]);
         const float pc = z == 0 ? __builtin_amdgcn_exp2f(s_cur[h] - M) : 0.f;      // the new token's own term (split 0 only)
-        float num = pc * (float)vb[d], den = pc;
+        // the new token's raw v from the LDS copy the service wave fetched at kernel entry (round 4: read from memory here it
+        // was a memory round trip between the merge barrier and the result - every thread's first instruction of the tail)
+        float num = pc * (float)((EXP & 4) ? vb[d] : s_vnew[d]), den = pc;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             const float f = __builtin_amdgcn_exp2f(s_m[w][h] - M);
@@ -821,26 +823,28 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
             const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xrow, 0, QS_ATTNQ_ROW * 4, 0x00020000);
             v4u raw[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
             if (tid2 < 256) {
+                // quant_kernel: thread t owns row elements (c 256 + t) 8 .. + 7, c = 0, 1 = granules i/2 .. i/2 + 3 = 32 bytes of the
+                // exchange row.  All four requests of a poll go out together, whatever the thread needs of them: a chunk that
+                // belongs to this workgroup's own heads (or lies beyond the row) is requested at an offset beyond the buffer - no
+                // memory access, zeros - instead of being skipped under an exec mask (with one masked block per chunk the compiler
+                // waited for chunk 0 before it requested chunk 1: two dependent round trips per poll)
+                const int i0 = tid2 * 8, i1 = (256 + tid2) * 8;
+                const bool p0 = i0 < own_lo, p1 = i1 < own_lo;
+                const u32 o0 = p0 ? (u32)i0 * 4u : 0xFFFFFF00u, o1 = p1 ? (u32)i1 * 4u : 0xFFFFFF00u;
                 for (;;) {
-                    int missing = 0;
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const int i = (c * 256 + tid2) * 8;   // quant_kernel: thread t owns row elements (c 256 + t) 8 .. + 7
-                        if (i < own_lo) {                       // = granules i/2 .. i/2 + 3 = 32 bytes of the exchange row
-                            const v4u g0 = __builtin_amdgcn_raw_buffer_load_b128(xrs, i * 4, 0, 17);
-                            const v4u g1 = __builtin_amdgcn_raw_buffer_load_b128(xrs, i * 4 + 16, 0, 17);
-                            missing |= (g0.y != tag) | (g0.w != tag) | (g1.y != tag) | (g1.w != tag);
-                            raw[c] = (v4u){g0.x, g0.z, g1.x, g1.z};
-                        }
-                    }
-                    if (!__builtin_amdgcn_ballot_w64(missing != 0)) break;
+                    const v4u g00 = __builtin_amdgcn_raw_buffer_load_b128(xrs, o0, 0, 17);
+                    const v4u g01 = __builtin_amdgcn_raw_buffer_load_b128(xrs, o0, 16, 17);
+                    const v4u g10 = __builtin_amdgcn_raw_buffer_load_b128(xrs, o1, 0, 17);
+                    const v4u g11 = __builtin_amdgcn_raw_buffer_load_b128(xrs, o1, 16, 17);
+                    const int m0 = (g00.y != tag) | (g00.w != tag) | (g01.y != tag) | (g01.w != tag);
+                    const int m1 = (g10.y != tag) | (g10.w != tag) | (g11.y != tag) | (g11.w != tag);
+                    raw[0] = (v4u){g00.x, g00.z, g01.x, g01.z};
+                    raw[1] = (v4u){g10.x, g10.z, g11.x, g11.z};
+                    if (!__builtin_amdgcn_ballot_w64((p0 && m0) || (p1 && m1))) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int i = (c * 256 + tid2) * 8;
-                    if (i >= own_lo && i < hidden) raw[c] = reinterpret_cast<const v4u*>(&s_meta[0][0][0])[(i - own_lo) >> 3];
-                }
+                if (!p0 && i0 < hidden) raw[0] = reinterpret_cast<const v4u*>(&s_meta[0][0][0])[(i0 - own_lo) >> 3];
+                if (!p1 && i1 < hidden) raw[1] = reinterpret_cast<const v4u*>(&s_meta[0][0][0])[(i1 - own_lo) >> 3];
             }
             float* const sm = reinterpret_cast<float*>(&s_kv[0]);                // 2 x 4 floats (the rings are dead)
             float amax = 0.f, sum = 0.f;
