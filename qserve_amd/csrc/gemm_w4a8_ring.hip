@@ -106,23 +106,33 @@ constexpr int ring_gstage() {
 struct RingCoords {
     int nblk, mblk, kq;
 };
+// wave-uniform unsigned division by a small run-time divisor that is almost always a power of two (token blocks, K slices): a
+// shift then; the general form costs ~35 dependent scalar / vector instructions each - three of them stood in front of a
+// workgroup's first memory request (round 4, timeline trace: 1 200-1 400 cycles from kernel entry to the first request)
+__device__ __forceinline__ unsigned udivmod(unsigned x, unsigned d, unsigned& rem) {
+    if ((d & (d - 1)) == 0) {
+        const unsigned sh = (unsigned)__builtin_ctz(d);
+        rem = x & (d - 1);
+        return x >> sh;
+    }
+    rem = x % d;
+    return x / d;
+}
 __device__ __forceinline__ RingCoords ring_coords(int b, int N, int wn, int mblocks, int ksplit) {
     RingCoords c = {b, 0, 0};
     const int per = mblocks * ksplit;                 // workgroups per channel block
     if (per > 1) {
         const int n8 = (N / (64 * wn)) & ~7;          // channel blocks covered by whole groups of 8 (one per XCD)
-        int sub;
+        unsigned sub, mb;
         if (b < n8 * per) {
             const int slot = b >> 3;
-            sub = slot % per;
-            c.nblk = (slot / per) * 8 + (b & 7);
+            c.nblk = (int)udivmod((unsigned)slot, (unsigned)per, sub) * 8 + (b & 7);
         } else {                                      // remainder (< 8 channel blocks): plain order
             const int r = b - n8 * per;
-            sub = r % per;
-            c.nblk = n8 + r / per;
+            c.nblk = n8 + (int)udivmod((unsigned)r, (unsigned)per, sub);
         }
-        c.mblk = sub % mblocks;
-        c.kq = sub / mblocks;
+        c.kq = (int)udivmod(sub, (unsigned)mblocks, mb);
+        c.mblk = (int)mb;
     }
     return c;
 }
@@ -169,7 +179,8 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
     auto chan32 = [&](int unit, int t) { return ACT ? (t ? N / 2 + 32 * unit : 32 * unit) : unit * 64 + 32 * t; };
     const int m0 = mblk * (16 * MT);
     const int KT = K >> 5;
-    const int nst = (K >> 6) / ksplit;                // 64-k stages of this workgroup's K slice
+    unsigned nst_rem;
+    const int nst = (int)udivmod((unsigned)(K >> 6), (unsigned)ksplit, nst_rem);   // 64-k stages of this workgroup's K slice
     const int u0 = kq * nst;                          // first global stage
     const int nloc = nst / KG;                        // stages per group (dispatcher: (K/64/ksplit) % KG == 0)
 
@@ -255,6 +266,51 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
         }
     };
 
+    // ---- epilogue operands (round 4): the per-channel / per-token scale vectors of the workgroup's tile are requested HERE,
+    // by LDS-DMA into the top 2 KiB of the LDS window (above every ring and reduction area), by wave 0, ahead of the first
+    // ring stage in its in-order queue (the counted ring waits are unaffected: the extra requests are OLDER than any stage).
+    // Before, every lane loaded its own values from memory after the k loop - a dependent memory round trip between the last
+    // MFMA and the epilogue while the other workgroups still stream: 2 000 - 5 600 cycles in the timeline trace (gate_up:
+    // 14 % of the launch).  Layout: [w scale: 64 WN halfs | w scale*zero: 64 WN halfs | token scale: 64 x 4-byte slots | token
+    // sum: 64 slots]; local channel = 64 wn + 32 t + ... (ACT: the 32 WN gate channels, then the 32 WN up channels).
+    uint8_t* const s_sc = smem + SC_OFF;
+    if ((OUTK == 0 || OUTK == 2) && wave == 0) {
+        const u32 sc_lds = (u32)(size_t)(lptr_t)s_sc;
+        auto dma4p = [&](const void* src, u32 dst) {
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(dst) : "memory");
+        };
+        constexpr int NCH = 64 * WN;                  // channels of the workgroup's tile
+#pragma unroll
+        for (int i = 0; i < (NCH + 127) / 128; ++i) { // 128 halfs per instruction
+            int lc = 128 * i + 2 * lane;
+            lc = lc < NCH ? lc : NCH - 2;             // surplus lanes repeat a valid address
+            const int gc = ACT ? (lc < 32 * WN ? 32 * unit0 + lc : N / 2 + 32 * unit0 + (lc - 32 * WN)) : unit0 * 64 + lc;
+            dma4p(reinterpret_cast<const _Float16*>(wscales) + gc, sc_lds + 256 * i);
+            if (MODE == 0) dma4p(reinterpret_cast<const _Float16*>(wszs) + gc, sc_lds + 2 * NCH + 256 * i);
+        }
+        {   // token vectors: one half per lane in a 4-byte slot (2-byte requests: no alignment assumption on a [M] vector)
+            int m = m0 + lane;
+            m = m < M ? m : M - 1;
+            const _Float16* sa_p = reinterpret_cast<const _Float16*>(ascales) + m;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off" ::"v"(sa_p), "s"(sc_lds + 4 * NCH) : "memory");
+            if (MODE == 0) {
+                const _Float16* ss_p = reinterpret_cast<const _Float16*>(assums) + m;
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off" ::"v"(ss_p), "s"(sc_lds + 4 * NCH + 256)
+                             : "memory");
+            }
+        }
+    }
+
+    // ---- prologue: stages 0..ns-2 in flight, operands of stage 0 in registers ---------------------------------------
+    QS_STAMP(15);
+    for (int j = 0; j < ns - 1; ++j)
+        if (j < nloc) issue(j, j);
+    QS_STAMP(1);
+    // Everything the k loop needs but the first requests do not - operand reader addresses, accumulators - is computed BEHIND
+    // the prologue (round 4, timeline trace: the first request left 1 200-1 400 cycles after kernel entry; with two waves per
+    // SIMD every instruction in front of it costs 4-5 cycles of a launch whose data is ~2.5 us away).  Nothing may be hoisted
+    // back above the requests:
+    __builtin_amdgcn_sched_barrier(0);
     // ---- LDS operand readers -------------------------------------------------------------------------------------
     // activation operand of m-tile mt = rows 16 mt + li: pieces 2 mt + (li >> 3) of the pair image
     int a_rd[MT];
@@ -321,45 +377,6 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
 #pragma unroll
         for (int cl = 0; cl < 4; ++cl) acc[mt][cl] = (v4i){0, 0, 0, 0};
 
-    // ---- epilogue operands (round 4): the per-channel / per-token scale vectors of the workgroup's tile are requested HERE,
-    // by LDS-DMA into the top 2 KiB of the LDS window (above every ring and reduction area), by wave 0, ahead of the first
-    // ring stage in its in-order queue (the counted ring waits are unaffected: the extra requests are OLDER than any stage).
-    // Before, every lane loaded its own values from memory after the k loop - a dependent memory round trip between the last
-    // MFMA and the epilogue while the other workgroups still stream: 2 000 - 5 600 cycles in the timeline trace (gate_up:
-    // 14 % of the launch).  Layout: [w scale: 64 WN halfs | w scale*zero: 64 WN halfs | token scale: 64 x 4-byte slots | token
-    // sum: 64 slots]; local channel = 64 wn + 32 t + ... (ACT: the 32 WN gate channels, then the 32 WN up channels).
-    uint8_t* const s_sc = smem + SC_OFF;
-    if ((OUTK == 0 || OUTK == 2) && wave == 0) {
-        const u32 sc_lds = (u32)(size_t)(lptr_t)s_sc;
-        auto dma4p = [&](const void* src, u32 dst) {
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(dst) : "memory");
-        };
-        constexpr int NCH = 64 * WN;                  // channels of the workgroup's tile
-#pragma unroll
-        for (int i = 0; i < (NCH + 127) / 128; ++i) { // 128 halfs per instruction
-            int lc = 128 * i + 2 * lane;
-            lc = lc < NCH ? lc : NCH - 2;             // surplus lanes repeat a valid address
-            const int gc = ACT ? (lc < 32 * WN ? 32 * unit0 + lc : N / 2 + 32 * unit0 + (lc - 32 * WN)) : unit0 * 64 + lc;
-            dma4p(reinterpret_cast<const _Float16*>(wscales) + gc, sc_lds + 256 * i);
-            if (MODE == 0) dma4p(reinterpret_cast<const _Float16*>(wszs) + gc, sc_lds + 2 * NCH + 256 * i);
-        }
-        {   // token vectors: one half per lane in a 4-byte slot (2-byte requests: no alignment assumption on a [M] vector)
-            int m = m0 + lane;
-            m = m < M ? m : M - 1;
-            const _Float16* sa_p = reinterpret_cast<const _Float16*>(ascales) + m;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off" ::"v"(sa_p), "s"(sc_lds + 4 * NCH) : "memory");
-            if (MODE == 0) {
-                const _Float16* ss_p = reinterpret_cast<const _Float16*>(assums) + m;
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off" ::"v"(ss_p), "s"(sc_lds + 4 * NCH + 256)
-                             : "memory");
-            }
-        }
-    }
-
-    // ---- prologue: stages 0..ns-2 in flight, operands of stage 0 in registers ---------------------------------------
-    for (int j = 0; j < ns - 1; ++j)
-        if (j < nloc) issue(j, j);
-    QS_STAMP(1);
     // wait for stage 0: younger stages outstanding = min(ns-1, nloc) - 1
     {
         const int young = (nloc < ns - 1 ? nloc : ns - 1) - 1;

@@ -27,7 +27,7 @@ used = st[:, 0, 0] > 0
 st = st[used]
 print(f"M={M} N={N} K={K}: {used.sum()} workgroups traced")
 t0 = st[:, :, 0].min(axis=1, keepdims=True)
-names = {0: "entry", 1: "prologue issued", 2: "stage 0 landed", 3: "loop done", 4: "rings dead (sync)", 7: "partials written", 10: "sync", 11: "partials summed", 14: "seam done", 12: "epilogue math", 5: "tile staged (sync)", 6: "end"}
+names = {0: "entry", 15: "first request", 1: "prologue issued", 2: "stage 0 landed", 3: "loop done", 4: "rings dead (sync)", 7: "partials written", 10: "sync", 11: "partials summed", 14: "seam done", 12: "epilogue math", 5: "tile staged (sync)", 6: "end"}
 for i, nm in names.items():
     x = st[:, :, i] - t0
     x = np.where(st[:, :, i] > 0, x, np.nan)
