@@ -22,6 +22,8 @@ NAMES = {   # bench.py kernel label -> symbol prefix in the counter files
     "w4a8_gemm[qkv M=64 N=6144 K=4096]": "w4a8_gemm_ring<2, 1, 0, 0, false",
     "w4a8_gemm[down M=64 N=4096 K=14336]": "w4a8_gemm_ring<2, 1, 0, 0, true",     # 2 K slices x 2 token blocks (round 4)
     "w4a8_gemm[o M=64 N=4096 K=4096]": "w4a8_gemm_ring<1, 1, 0, 0, false",
+    "w4a8_gemm[down as K-slice planes M=64 N=4096 K=14336]": "w4a8_gemm_ring<2, 2, 0, 3, true",   # what the fused step launches
+    "add_residual_norm_quant over 4 planes [64 x 4096]": "add_residual_norm_quant_planes_kernel",
     "decode_attention[B=64 H=32 Hkv=8 L=1033]": "decode_attention_mfma_kernel",
 }
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only), "

@@ -26,6 +26,12 @@ for rep in range(2):
         L["gate_up"].silu_mul(eng.q_act, eng.q_scale, eng.q_sum, eng.mlp_act, eng.gate_up_buf)   # what the step launches
         L["down"](eng.q_mlp, eng.q_scale, eng.q_sum, eng.proj_out)
         L["o"](eng.q_attn, eng.q_scale, eng.q_sum, eng.proj_out)
+        if "down" in eng.planes and i + 1 < nl:   # the form the fused step launches: K-slice planes + the row kernel that finishes them
+            L["down"].planes(eng.q_mlp, eng.planes["down"])
+            L["down"].add_norm_quant_planes(eng.q_act, eng.hidden, eng.planes["down"], eng.q_scale, eng.q_sum,
+                                            eng.layers[i + 1]["ln1"], eng.q_scale, eng.cfg["eps"], eng.q_sum)
+            eng.q_scale.fill_(0.01)
+            eng.q_sum.fill_(1.0)
         fa.single_query_attention(q, k, v, eng.tables[i], eng.lengths, None, 8192, 64, eng.size_per_token,
                                   eng.max_len, 128, eng.cfg["rope_theta"], True, eng.int4, True)
 torch.cuda.synchronize()
