@@ -21,6 +21,7 @@ from oracle import kvattn, w4a8
 
 def _arr(addr, shape, dtype):
     """numpy view of host memory at `addr` (what a device pointer is on the real library)."""
+    addr = getattr(addr, "value", addr)            # (a ctypes.c_void_p the caller cast itself)
     n = int(np.prod(shape)) * np.dtype(dtype).itemsize
     if n == 0:
         return np.zeros(shape, dtype)

@@ -149,6 +149,28 @@ def test_decode_step_fused_pairs_equals_op_by_op(gpu):
             assert torch.equal(a, b)
 
 
+def test_decode_step_with_k_slice_planes_equals_op_by_op(gpu):
+    """The same at a width the K-slice planes form exists for (hidden 2048: down_proj leaves int32 planes, the next layer's add +
+    norm + quant finishes it - qserve_amd/decode.py `proj_add_norm_quant`), planes for down and for down + o."""
+    from qserve_amd.decode import TINY, DecodeEngine
+    cfg = dict(TINY, hidden=2048, heads=16, kv_heads=4, inter=4096, layers=3)
+    for gs in (-1, 128):
+        outs = []
+        for fuse, planes in ((False, ()), (True, ("down",)), (True, ("down", "o"))):
+            eng = DecodeEngine(cfg, batch=5, prompt_len=70, max_new=4, group_size=gs, device="cuda:0", seed=3, fuse_pairs=fuse,
+                               planes=planes)
+            assert set(eng.planes) == set(planes)
+            eng.prefill_cache(70)
+            toks = []
+            for _ in range(3):
+                eng.step()
+                toks.append(eng.tokens.clone())
+            outs.append((eng.hidden.clone(), eng.final.clone(), torch.stack(toks)))
+        for other in outs[1:]:
+            for a, b in zip(outs[0], other):
+                assert torch.equal(a, b)
+
+
 def test_prefill_batched_equals_per_sequence(gpu):
     """Real prefill (norm+quant -> W4A8 GEMMs -> RoPE + quantised cache write -> causal flash attention -> ...) of a
     4-sequence batch equals the same sequences prefilled one by one, bit for bit: per-token ops, integer-exact GEMMs

@@ -199,6 +199,31 @@ def test_tp2_matches_tp1_host_simulator(built_lib, monkeypatch, group_size, bias
     _tp_case("cpu", group_size, bias)
 
 
+@pytest.mark.parametrize("group_size", [-1, 128])
+def test_k_slice_planes_step_matches_op_by_op_host_simulator(built_lib, monkeypatch, group_size):
+    """The planes plumbing of the decode engine (which projection hands which buffers to which entry, the aliasing of the
+    activation scale / sum with the row kernel's outputs) against the oracle-backed simulator: a fused engine with planes for
+    down and o produces the same tokens and hidden states as the op-by-op engine."""
+    import _fake_abi
+    from qserve_amd import decode as D
+    _fake_abi.install(monkeypatch)
+    cfg = dict(D.TINY, hidden=2048, heads=16, kv_heads=4, inter=2048, layers=2, vocab=256)
+    outs = []
+    for fuse, planes in ((False, ()), (True, ("down", "o"))):
+        _fake_abi.CALLS.clear()
+        eng = D.DecodeEngine(cfg, batch=3, prompt_len=20, max_new=3, group_size=group_size, device="cpu", seed=4, fuse_pairs=fuse,
+                             planes=planes)
+        assert set(eng.planes) == set(planes)
+        eng.prefill(20)
+        eng.step()
+        eng.step()
+        outs.append((eng.hidden.clone(), eng.final.clone(), eng.tokens.clone()))
+        names = [c[0] for c in _fake_abi.CALLS]
+        assert ("qs_add_residual_rms_norm_general_planes" in names) == fuse
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_tp4_with_replicated_kv_heads_host_simulator(built_lib, monkeypatch):
     """More ranks than KV heads (the reference's rule for that case, loader.py kv_rep): ranks 2h, 2h+1 hold KV head h; the
     engine takes the loader's shards as they are."""
