@@ -171,6 +171,48 @@ def test_decode_step_with_k_slice_planes_equals_op_by_op(gpu):
                 assert torch.equal(a, b)
 
 
+def test_llama3_shape_steps_are_deterministic_and_equal_op_by_op(gpu):
+    """The production geometry (Llama-3-8B widths, bs = 64, context 1033.., 4 layers): 48 hipGraph-replayed steps of the fused
+    engine (pair fusions, K-slice planes, granule hand-over in the attention) give the same tokens on a second engine built
+    from the same seed - the in-launch hand-offs cannot depend on timing -, and its first steps equal the op-by-op engine's bit for
+    bit (tokens, residual stream, final norm)."""
+    from qserve_amd.decode import LLAMA3_8B, DecodeEngine
+    cfg = dict(LLAMA3_8B, layers=4)
+
+    def make(fuse):
+        e = DecodeEngine(cfg, batch=64, prompt_len=1024, max_new=64, device="cuda:0", seed=11, fuse_pairs=fuse)
+        e.prefill_cache(1024 + 8)
+        e.lengths.fill_(1033)
+        return e
+    runs = []
+    for _ in range(2):
+        e = make(True)
+        assert "down" in e.planes
+        e.capture()
+        e.lengths.fill_(1033)
+        toks = []
+        for _ in range(48):
+            e.run()
+            toks.append(e.tokens.clone())
+        torch.cuda.synchronize()
+        runs.append((torch.stack(toks), e.hidden.clone()))
+        del e
+        torch.cuda.empty_cache()
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]), "fused steps are not reproducible"
+    outs = []
+    for fuse in (True, False):
+        e = make(fuse)
+        toks = []
+        for _ in range(4):
+            e.step()
+            toks.append(e.tokens.clone())
+        outs.append((torch.stack(toks), e.hidden.clone(), e.final.clone()))
+        del e
+        torch.cuda.empty_cache()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_prefill_batched_equals_per_sequence(gpu):
     """Real prefill (norm+quant -> W4A8 GEMMs -> RoPE + quantised cache write -> causal flash attention -> ...) of a
     4-sequence batch equals the same sequences prefilled one by one, bit for bit: per-token ops, integer-exact GEMMs
