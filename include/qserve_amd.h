@@ -130,6 +130,17 @@ int qs_w8a8_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscal
  *   3100 + bits ... [QS_TIMING builds only] kernel parts of the tiled kernel switched off. */
 void qs_set_gemm_variant(int variant);
 
+/* Per-channel epilogue CONVENTION (process-wide; read at launch time by every per-channel W4A8 GEMM launch and by
+ * qs_add_residual_rms_norm_general_planes, which finishes such a GEMM).  The reference statement
+ *   (float(acc) * wscale) * ascale - w_sz * a_ssum          (w4a8_per_chn/gemm_cuda.cu:586-587)
+ * is compiled there with nvcc's default --fmad=true, which may contract it; the CUDA binary cannot be produced here, so the
+ * convention is selectable:  0 [default] = every operation rounded separately (the statement as written),
+ *   1 = fmaf(float(acc) * wscale, ascale, -(w_sz * a_ssum)) - the fold of the last multiply into the subtraction that nvcc most
+ *   plausibly performs (oracle/w4a8.py epilogue_per_chn(fma=True); differs on ~3.5e-4 of the outputs at Llama-3-8B shapes).
+ * Returns QS_EINVAL for any other value.  Per-group GEMMs have no subtraction and are unaffected. */
+int qs_set_gemm_epilogue(int convention);
+int qs_get_gemm_epilogue(void);
+
 /* Plan only: runs the W4A8 GEMM dispatcher for an (M, N, K) problem without touching the device and reports its choice
  * in plan5 = {family, p0, p1, p2, p3}: family 1 = split-K kernel (m_tiles, waves, cross-block slices, xcd mapping),
  * 2 = LDS-pair kernel, 3 = ring kernel (m_tiles, units, token blocks, K slices), 4 = tiled kernel (8 = 256-token tile,

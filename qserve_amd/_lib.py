@@ -24,6 +24,8 @@ SIGNATURES = {
     "qs_w4a8_per_group_gemm_acc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_w8a8_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qs_set_gemm_variant": (None, [_i]),
+    "qs_set_gemm_epilogue": (_i, [_i]),
+    "qs_get_gemm_epilogue": (_i, []),
     "qs_w4a8_gemm_plan": (_i, [_i, _i, _i, _i, _vp]),
     "qs_w4a8_gemm_planes_plan": (_i, [_i, _i, _i, _i, _vp]),
     "qs_w4a8_per_chn_gemm_planes": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

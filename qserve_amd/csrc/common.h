@@ -50,6 +50,46 @@ __device__ __forceinline__ _Float16 qs_silu_h(float xf) {
     return (_Float16)(xf * __builtin_amdgcn_rcpf(1.0f + e));
 }
 
+// ---- W4A8 arithmetic shared by every GEMM kernel (gemm_w4a8*.hip) and by the row kernel that finishes K-slice planes -------
+// per-byte wrapping add (__vadd4 semantics, w4a8_per_group/gemm_cuda.cu:302)
+__device__ __forceinline__ u32 vadd4(u32 a, u32 b) {
+    return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
+}
+// four packed nibbles -> four operand bytes; MODE 1 (per-group): level-2 dequant = 32-bit multiply (byte products carry into
+// their neighbours exactly as in the reference, gemm_cuda.cu:300-301) + per-byte wrapping add of the zero byte
+template <int MODE>
+__device__ __forceinline__ u32 unpack_lo(u32 raw, u32 s, u32 zb) {
+    u32 u = raw & 0x0F0F0F0Fu;
+    if (MODE == 1) u = vadd4(u * s, zb);
+    return u;
+}
+template <int MODE>
+__device__ __forceinline__ u32 unpack_hi(u32 raw, u32 s, u32 zb) {
+    u32 u = (raw >> 4) & 0x0F0F0F0Fu;
+    if (MODE == 1) u = vadd4(u * s, zb);
+    return u;
+}
+// fp32 epilogues with the reference's evaluation order (oracle/w4a8.py epilogue_*).
+// per-channel, w4a8_per_chn/gemm_cuda.cu:586-587: (acc * wscale) * ascale - w_sz * a_ssum.  `fma` selects the CONVENTION
+// (qs_set_gemm_epilogue, include/qserve_amd.h): 0 = every operation rounded separately (the library's default; what the
+// source statement says without contraction), 1 = fmaf(acc * wscale, ascale, -(w_sz * a_ssum)) - what nvcc's default
+// --fmad=true most plausibly makes of that line (oracle epilogue_per_chn(fma=True)).  Wave-uniform.
+__device__ __forceinline__ float epi_per_chn(int acc, float ws, float sa, float wz, float ss, int fma = 0) {
+#pragma clang fp contract(off)
+    float t = (float)acc * ws;
+    const float u = wz * ss;
+    if (fma) return __builtin_fmaf(t, sa, -u);
+    t = t * sa;
+    return t - u;
+}
+// per-group, w4a8_per_group/gemm_cuda.cu:620-621: acc * (wscale * ascale)
+__device__ __forceinline__ float epi_per_group(int acc, float ws, float sa) {
+#pragma clang fp contract(off)
+    const float sc = ws * sa;
+    return (float)acc * sc;
+}
+extern int g_epi_fma;   // gemm_w4a8.hip: qs_set_gemm_epilogue
+
 // compute units of the current device (cached per device; 256 on MI355X)
 static inline int qs_num_cus() {
     static int cus[QS_MAX_DEVICES] = {};

@@ -187,10 +187,11 @@ template <int NC, int KS, int MODE, bool FULL>
 __global__ __launch_bounds__(TPB) void add_residual_norm_quant_planes_kernel(
     int8_t* __restrict__ out, _Float16* __restrict__ hidden_io, const int* __restrict__ planes, size_t pstride,
     const _Float16* __restrict__ wscales, const _Float16* __restrict__ wszs, const __half* ascale, const __half* asum,
-    const _Float16* __restrict__ gamma, __half* sum_out, __half* scale_out, float eps, int hidden) {
+    const _Float16* __restrict__ gamma, __half* sum_out, __half* scale_out, float eps, int hidden, int epi_fma) {
     __shared__ float sm[4 * (TPB / 64)];
     const size_t base = (size_t)blockIdx.x * hidden;
     qs_row::FromPlanes<KS, MODE> dfn;
+    dfn.fma = epi_fma;
     dfn.row0 = planes + base;
     dfn.pstride = pstride;
     dfn.ws = wscales;
@@ -591,7 +592,7 @@ extern "C" int qs_add_residual_rms_norm_general_planes(int8_t* out, void* hidden
     hipLaunchKernelGGL((add_residual_norm_quant_planes_kernel<NC, KS, MODE, FULLV>), dim3(num_tokens), dim3(TPB), 0,        \
                        (hipStream_t)stream, out, (_Float16*)hidden_io, planes, (size_t)plane_stride, (const _Float16*)wscales, \
                        (const _Float16*)w_szs, (const __half*)ascales, (const __half*)a_ssums, (const _Float16*)weight,     \
-                       (__half*)input_sum, (__half*)scaling, epsilon, hidden)
+                       (__half*)input_sum, (__half*)scaling, epsilon, hidden, g_epi_fma)
 #define QS_PF(NC, KS, MODE)                                       \
     do {                                                          \
         if (hidden == NC * TPB * 8) {                             \

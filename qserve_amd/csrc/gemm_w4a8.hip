@@ -33,37 +33,6 @@
 
 namespace {
 
-__device__ __forceinline__ u32 vadd4(u32 a, u32 b) {
-    // per-byte wrapping add (__vadd4 semantics, per_group/gemm_cuda.cu:302)
-    return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
-}
-
-template <int MODE>
-__device__ __forceinline__ u32 unpack_lo(u32 raw, u32 s, u32 zb) {
-    u32 u = raw & 0x0F0F0F0Fu;
-    if (MODE == 1) u = vadd4(u * s, zb);   // 32-bit multiply, byte carries as in the reference (:300-301)
-    return u;
-}
-template <int MODE>
-__device__ __forceinline__ u32 unpack_hi(u32 raw, u32 s, u32 zb) {
-    u32 u = (raw >> 4) & 0x0F0F0F0Fu;
-    if (MODE == 1) u = vadd4(u * s, zb);
-    return u;
-}
-
-// fp32 epilogues with the reference's evaluation order and NO fma contraction (oracle/w4a8.py epilogue_*).
-__device__ __forceinline__ float epi_per_chn(int acc, float ws, float sa, float wz, float ss) {
-#pragma clang fp contract(off)
-    float t = (float)acc * ws;   // per_chn/gemm_cuda.cu:586
-    t = t * sa;
-    const float u = wz * ss;
-    return t - u;
-}
-__device__ __forceinline__ float epi_per_group(int acc, float ws, float sa) {
-#pragma clang fp contract(off)
-    const float sc = ws * sa;    // per_group/gemm_cuda.cu:620
-    return (float)acc * sc;
-}
 
 // MODE 0 = per-channel, 1 = per-group(128).  OUTK 0 = fp16 epilogue, 1 = raw int32 accumulators.
 //
@@ -90,7 +59,7 @@ __global__ __launch_bounds__(MT <= 2 ? 512 : 256, 2) void w4a8_gemm_splitk(const
                                                         const __half* __restrict__ wszs,
                                                         const __half* __restrict__ assums, void* __restrict__ out,
                                                         int* __restrict__ slabs, unsigned* __restrict__ counters,
-                                                        int M, int N, int K, int mblocks) {
+                                                        int M, int N, int K, int mblocks, int epi_fma) {
     extern __shared__ __attribute__((aligned(16))) int red[];   // [NW][MT*16][64] ; red[0] doubles as the "last" flag
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -283,7 +252,7 @@ __global__ __launch_bounds__(MT <= 2 ? 512 : 256, 2) void w4a8_gemm_splitk(const
                         const h4 wz4 = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wszs) + n);
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            o[r] = (_Float16)epi_per_chn(s[r], (float)ws4[r], sa, (float)wz4[r], ss);
+                            o[r] = (_Float16)epi_per_chn(s[r], (float)ws4[r], sa, (float)wz4[r], ss, epi_fma);
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(s[r], (float)ws4[r], sa);
@@ -385,7 +354,7 @@ int launch_splitk(const int8_t* A, const uint8_t* W, const int8_t* zeros, const 
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, stream, A, W, zeros, scales8,
                        reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
                        reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, slabs,
-                       counters, M, N, K, mblocks);
+                       counters, M, N, K, mblocks, g_epi_fma);
     return qs_launch_status("w4a8 gemm");
 }
 
@@ -634,6 +603,17 @@ extern "C" void qs_set_gemm_variant(int variant) {
     }
     g_variant = variant;
 }
+
+// Per-channel epilogue convention (include/qserve_amd.h): 0 = (acc*ws)*sa - wz*ss with every operation rounded separately
+// (default), 1 = fmaf(acc*ws, sa, -(wz*ss)).  Process-wide, read at launch time by every W4A8 per-channel GEMM launch and by
+// qs_add_residual_rms_norm_general_planes (which finishes such a GEMM).
+int g_epi_fma = 0;
+extern "C" int qs_set_gemm_epilogue(int convention) {
+    QS_REQUIRE(convention == 0 || convention == 1, "qs_set_gemm_epilogue: convention %d not in {0, 1}", convention);
+    g_epi_fma = convention;
+    return QS_OK;
+}
+extern "C" int qs_get_gemm_epilogue(void) { return g_epi_fma; }
 
 extern "C" int qs_w4a8_gemm_plan(int per_group, int M, int N, int K, int* plan5) {
     QS_REQUIRE(plan5, "w4a8 gemm plan: null output");

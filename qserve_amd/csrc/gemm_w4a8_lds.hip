@@ -23,33 +23,6 @@ constexpr int NS = 4;                 // ring depth (k-steps)
 constexpr int WBYTES = 4096;          // weight bytes of one unit per k-step
 constexpr int MAXM = 64;              // tokens per workgroup
 
-__device__ __forceinline__ u32 vadd4(u32 a, u32 b) {
-    return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
-}
-template <int MODE>
-__device__ __forceinline__ u32 unpack_lo(u32 raw, u32 s, u32 zb) {
-    u32 u = raw & 0x0F0F0F0Fu;
-    if (MODE == 1) u = vadd4(u * s, zb);
-    return u;
-}
-template <int MODE>
-__device__ __forceinline__ u32 unpack_hi(u32 raw, u32 s, u32 zb) {
-    u32 u = (raw >> 4) & 0x0F0F0F0Fu;
-    if (MODE == 1) u = vadd4(u * s, zb);
-    return u;
-}
-__device__ __forceinline__ float epi_per_chn(int acc, float ws, float sa, float wz, float ss) {
-#pragma clang fp contract(off)
-    float t = (float)acc * ws;
-    t = t * sa;
-    const float u = wz * ss;
-    return t - u;
-}
-__device__ __forceinline__ float epi_per_group(int acc, float ws, float sa) {
-#pragma clang fp contract(off)
-    const float sc = ws * sa;
-    return (float)acc * sc;
-}
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -73,7 +46,7 @@ __global__ __launch_bounds__(256, 1) void w4a8_gemm_pair(const int8_t* __restric
                                                          const __half* __restrict__ ascales,
                                                          const __half* __restrict__ wszs,
                                                          const __half* __restrict__ assums, void* __restrict__ out,
-                                                         int M, int N, int K) {
+                                                         int M, int N, int K, int epi_fma) {
     constexpr int ATILE = 16 * MT * 128;          // activation bytes per k-step
     constexpr int APART = MT;                     // 1 KiB DMA instructions per wave for its half of the tile
     constexpr int NDMA = APART + 4 + (MODE == 1 ? 1 : 0);   // VMEM instructions per wave per k-step
@@ -278,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void w4a8_gemm_pair(const int8_t* __restric
             h4 o;
             if (MODE == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(s[r], (float)ws4[cl][r], sa, (float)wz4[cl][r], ss);
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(s[r], (float)ws4[cl][r], sa, (float)wz4[cl][r], ss, epi_fma);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(s[r], (float)ws4[cl][r], sa);
@@ -316,7 +289,7 @@ int launch_pair(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
     dim3 grid(N / 128, (M + 16 * MT - 1) / (16 * MT));
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, A, W, zeros, scales8,
                        reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
-                       reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K);
+                       reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K, g_epi_fma);
     return qs_launch_status("w4a8 gemm (lds)");
 }
 

@@ -30,6 +30,7 @@
 //        no LDS operand reads (what is left is the DMA + barrier pipeline:
 //        gate_up at M = 64 17.5 us -> 16.3 / 16.8, both off 15.9 us = 4.2 us of head and tail + 512 KB per CU at 44 GB/s,
 //        the rate scripts/microbench_cufill.hip measures for this L2 + HBM mix with nothing else going on)
+//   16 = (set by the launcher, not by the variant) per-channel epilogue convention qs_set_gemm_epilogue(1): fmaf form
 //   256 * d = ring depth d (3..6, if 160 KiB allow): sensitivity to the bytes in flight
 int g_ring_flags = 0;
 
@@ -39,33 +40,6 @@ namespace {
 constexpr int SC_BYTES = 2048;
 constexpr int SC_OFF = 160 * 1024 - SC_BYTES;
 
-__device__ __forceinline__ u32 vadd4(u32 a, u32 b) {
-    return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
-}
-template <int MODE>
-__device__ __forceinline__ u32 unpack_lo(u32 raw, u32 s, u32 zb) {
-    u32 u = raw & 0x0F0F0F0Fu;
-    if (MODE == 1) u = vadd4(u * s, zb);
-    return u;
-}
-template <int MODE>
-__device__ __forceinline__ u32 unpack_hi(u32 raw, u32 s, u32 zb) {
-    u32 u = (raw >> 4) & 0x0F0F0F0Fu;
-    if (MODE == 1) u = vadd4(u * s, zb);
-    return u;
-}
-__device__ __forceinline__ float epi_per_chn(int acc, float ws, float sa, float wz, float ss) {
-#pragma clang fp contract(off)
-    float t = (float)acc * ws;
-    t = t * sa;
-    const float u = wz * ss;
-    return t - u;
-}
-__device__ __forceinline__ float epi_per_group(int acc, float ws, float sa) {
-#pragma clang fp contract(off)
-    const float sc = ws * sa;
-    return (float)acc * sc;
-}
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef u32 v2u __attribute__((ext_vector_type(2)));
@@ -634,7 +608,7 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
                     const h4 wz4 = *reinterpret_cast<const h4*>(s_sc + 2 * (64 * WN) + 2 * lcol);
                     const float ss = (float)*reinterpret_cast<const _Float16*>(s_sc + 4 * (64 * WN) + 256 + 4 * (16 * mt + li));
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(sum[q][r], (float)ws4[r], sa, (float)wz4[r], ss);
+                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(sum[q][r], (float)ws4[r], sa, (float)wz4[r], ss, flags & 16);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(sum[q][r], (float)ws4[r], sa);
@@ -754,7 +728,7 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
                        reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
                        reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K,
                        mblocks, ns, ksplit, slabs, counters,
-                       (g_ring_flags & ~3) | ((g_ring_flags & 1) || (mblocks > 1 && N <= 8192 && !(g_ring_flags & 2)) ? 1 : 0));
+                       (g_ring_flags & ~(3 | 16)) | (g_epi_fma ? 16 : 0) | ((g_ring_flags & 1) || (mblocks > 1 && N <= 8192 && !(g_ring_flags & 2)) ? 1 : 0));
     return qs_launch_status("w4a8 gemm (ring)");
 }
 

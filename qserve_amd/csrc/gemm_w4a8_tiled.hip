@@ -32,33 +32,6 @@ constexpr int PD = 4;                      // operand LDS reads run this many m-
 constexpr int BN = 256;                    // channels per workgroup (4 units)
 constexpr int WSTAGE = BN * 32;            // packed weight bytes per stage = 8 KiB
 
-__device__ __forceinline__ u32 vadd4(u32 a, u32 b) {
-    return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
-}
-template <int MODE>
-__device__ __forceinline__ u32 unpack_lo(u32 raw, u32 s, u32 zb) {
-    u32 u = raw & 0x0F0F0F0Fu;
-    if (MODE == 1) u = vadd4(u * s, zb);
-    return u;
-}
-template <int MODE>
-__device__ __forceinline__ u32 unpack_hi(u32 raw, u32 s, u32 zb) {
-    u32 u = (raw >> 4) & 0x0F0F0F0Fu;
-    if (MODE == 1) u = vadd4(u * s, zb);
-    return u;
-}
-__device__ __forceinline__ float epi_per_chn(int acc, float ws, float sa, float wz, float ss) {
-#pragma clang fp contract(off)
-    float t = (float)acc * ws;
-    t = t * sa;
-    const float u = wz * ss;
-    return t - u;
-}
-__device__ __forceinline__ float epi_per_group(int acc, float ws, float sa) {
-#pragma clang fp contract(off)
-    const float sc = ws * sa;
-    return (float)acc * sc;
-}
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -94,7 +67,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
                                                           const __half* __restrict__ ascales,
                                                           const __half* __restrict__ wszs,
                                                           const __half* __restrict__ assums, void* __restrict__ out,
-                                                          int M, int N, int K, int nbm, int order) {
+                                                          int M, int N, int K, int nbm, int order, int epi_fma) {
     constexpr int BM = 32 * MT;                       // tokens per workgroup
     constexpr int APAIR = BM * 128;                   // activation bytes per stage pair (128 k)
     constexpr int NA2 = APAIR / 8192;                 // 8 KiB all-thread DMA instructions per activation pair
@@ -464,7 +437,7 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
                 h4 o;
                 if (MODE == 0) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(s[r], (float)ws4[cl][r], sa, (float)wz4[cl][r], ss);
+                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(s[r], (float)ws4[cl][r], sa, (float)wz4[cl][r], ss, epi_fma);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(s[r], (float)ws4[cl][r], sa);
@@ -533,7 +506,7 @@ int launch_tiled(const int8_t* A, const uint8_t* W, const int8_t* zeros, const i
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, A, W, zeros, scales8,
                        reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
                        reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K,
-                       nbm, g_tiled_order % 10);
+                       nbm, g_tiled_order % 10, g_epi_fma);
     return qs_launch_status("w4a8 gemm (tiled)");
 }
 

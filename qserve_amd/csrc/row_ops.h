@@ -60,20 +60,6 @@ struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
 
-// the W4A8 GEMMs' fused epilogues (gemm_w4a8*.hip: epi_per_chn / epi_per_group - the same statements, the same roundings)
-__device__ __forceinline__ float gemm_epi_per_chn(int acc, float ws, float sa, float wz, float ss) {
-#pragma clang fp contract(off)
-    float t = (float)acc * ws;
-    t = t * sa;
-    const float u = wz * ss;
-    return t - u;
-}
-__device__ __forceinline__ float gemm_epi_per_group(int acc, float ws, float sa) {
-#pragma clang fp contract(off)
-    const float sc = ws * sa;
-    return (float)acc * sc;
-}
-
 // `delta` of norm_quant_row, by where it comes from.  FromRow: an fp16 row in memory (the residual branch's GEMM output).
 // FromPlanes (round 4): the K-slice planes a W4A8 GEMM left instead of its output (qs_w4a8_*_gemm_planes: int32 [KS][M][N]) -
 // the 8 values of a chunk are the planes' sums pushed through the GEMM's own epilogue, rounded to fp16 exactly as the GEMM would
@@ -92,6 +78,7 @@ struct FromPlanes {
     size_t pstride;           // elements between planes (M * N)
     const _Float16 *ws, *wz;  // per-channel weight scale, scale * zero (MODE 0 only)
     float sa, ss;             // the token's activation scale / sum as the GEMM saw them
+    int fma = 0;              // per-channel epilogue convention (common.h epi_per_chn; the same the GEMM launches use)
     // two phases, so that every request of a row is out before the first value is needed (one memory round trip)
     struct Raw {
         v4i a[KS][2];
@@ -116,8 +103,8 @@ struct FromPlanes {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int acc = e < 4 ? a0[e & 3] : a1[e & 3];
-            o[e] = MODE == 0 ? (_Float16)gemm_epi_per_chn(acc, (float)r.wsv[e], sa, (float)r.wzv[e], ss)
-                             : (_Float16)gemm_epi_per_group(acc, (float)r.wsv[e], sa);
+            o[e] = MODE == 0 ? (_Float16)epi_per_chn(acc, (float)r.wsv[e], sa, (float)r.wzv[e], ss, fma)
+                             : (_Float16)epi_per_group(acc, (float)r.wsv[e], sa);
         }
         return __builtin_bit_cast(v4u, o);
     }
