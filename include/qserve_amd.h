@@ -25,7 +25,8 @@
  *     launches that use them (split-KV attention, K-sliced GEMMs, the split argmax, the fused attention quantiser's
  *     hand-over) must not run concurrently on different streams of one device (the reference's engine is single-stream).
  *     A launch that is ABORTED mid-way (device reset) may leave the K-slice slabs without their sentinel or an exchange row
- *     half-tagged: the process must not reuse the library after a failed launch (qs_launch_status reports it).
+ *     half-tagged: call qs_device_reset() before the library is used again.  The in-launch waits on these areas are BOUNDED
+ *     (round 5): a violated assumption yields a status bit (qs_device_status) and an invalid result, never a hung GPU.
  */
 #ifndef QSERVE_AMD_H
 #define QSERVE_AMD_H
@@ -299,6 +300,28 @@ int qs_comm_all_reduce_f16(void* comm, int64_t numel, qs_stream_t stream);
 int qs_comm_all_reduce_f16_group(void* const* comms, int world, int64_t numel, qs_stream_t stream);
 int qs_comm_error(void* comm);
 int qs_comm_destroy(void* comm);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Bounded in-launch waits (no reference counterpart).  Two launches of this library contain a cross-workgroup hand-off that
+ * polls inside the launch: the K-slice seam of the decode W4A8 GEMMs and the finisher of qs_single_query_attention_quant.  They
+ * rely on in-order workgroup dispatch and on single-stream use of the per-device scratch (see the header comment).  Every such
+ * wait is BOUNDED: after ~1e6 polls (seconds) the waiting wave gives up, sets a bit in a per-device error word and finishes
+ * the launch with what it has - results of that launch are invalid, the GPU is not hung.
+ *   qs_device_status   error_bits = OR of 1 (K-slice seam gave up), 2 (attention + quant hand-over gave up) on the CURRENT
+ *                      device since the last reset; blocking (a device-to-host copy behind the work launched so far) - call it
+ *                      at checkpoints, not per launch.  Returns QS_OK when the word could be read; a non-zero word also sets
+ *                      qs_last_error().
+ *   qs_device_reset    synchronises the device, clears the word and puts the hand-off scratch back into its initial state
+ *                      (K-slice slabs sentinel-filled, exchange rows / generation words zeroed).  Required after a non-zero
+ *                      status and after an aborted launch before the library is used again; replayed hipGraphs stay valid
+ *                      (no address changes).
+ *   qs_debug_inject_fault  tests only: arms a ONE-SHOT fault - bit 0: the next K-sliced ring GEMM launch, bit 1: the next
+ *                      fused attention + quant launch runs with one producer that never delivers (and a short poll bound), so
+ *                      that the give-up path, the status word and the recovery can be exercised.  The results of THAT launch
+ *                      are wrong by design; 0 disarms. */
+int qs_device_status(int* error_bits);
+int qs_device_reset(void);
+int qs_debug_inject_fault(int what);
 
 /* Device self-test (tests/test_fused_gpu.py): the DPP / permlane wave reductions every row kernel uses round exactly like
  * the shuffle butterfly they replace.  in: float [n] (n % 64 == 0); out: float [n/64][4] = {sum, sum by shuffles, max, max

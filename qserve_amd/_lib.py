@@ -50,6 +50,9 @@ SIGNATURES = {
     "qs_add_residual_rms_norm_general_planes": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "qs_silu_and_mul_quant": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "qs_debug_wave_reduce_selftest": (_i, [_vp, _vp, _i, _vp]),
+    "qs_device_status": (_i, [C.POINTER(C.c_int)]),
+    "qs_device_reset": (_i, []),
+    "qs_debug_inject_fault": (_i, [_i]),
     "qs_comm_create": (_i, [_i, _i, _i64, C.POINTER(C.c_void_p), _vp]),
     "qs_comm_connect": (_i, [_vp, _vp]),
     "qs_comm_connect_local": (_i, [_vp, C.POINTER(C.c_void_p)]),
@@ -80,6 +83,16 @@ def _load():
 
 
 lib = _load()
+
+
+def device_status():
+    """Error bits of the bounded in-launch waits on the current device (0 = healthy); blocking.  include/qserve_amd.h."""
+    bits = C.c_int(0)
+    rc = lib.qs_device_status(C.byref(bits))
+    if rc != 0:
+        msg = lib.qs_last_error()
+        raise RuntimeError(f"qs_device_status: {msg.decode() if msg else 'error'} (code {rc})")
+    return bits.value
 
 
 def check(rc, what):

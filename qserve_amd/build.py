@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libqserve_amd.so")
-SOURCES = ["lib.hip", "gemm_w4a8.hip", "gemm_w4a8_lds.hip", "gemm_w4a8_tiled.hip", "gemm_w4a8_ring.hip", "gemm_w8a8.hip", "attention.hip", "attention_mfma.hip", "attention_mfma8.hip", "flash_prefill.hip", "fused_small.hip", "direct_allreduce.hip"]
+SOURCES = ["lib.hip", "gemm_w4a8.hip", "gemm_w4a8_lds.hip", "gemm_w4a8_tiled.hip", "gemm_w4a8_wide.hip", "gemm_w4a8_ring.hip", "gemm_w8a8.hip", "attention.hip", "attention_mfma.hip", "attention_mfma8.hip", "flash_prefill.hip", "fused_small.hip", "direct_allreduce.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]

@@ -810,7 +810,8 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         v2u* const xrow = reinterpret_cast<v2u*>(qcounters + QS_ATTNQ_CAP) + (size_t)b * (QS_ATTNQ_ROW / 2);
         const int own_lo = (num_kv_heads - 1) * G * DH;                           // first row element of the finishing workgroup
         if (hkv != num_kv_heads - 1) {
-            for (int e = tid2; e < G * DH / 2; e += NWT * 64) {
+            // (kflags & 64: the armed one-shot fault of qs_debug_inject_fault - sequence 0's KV head 0 never delivers)
+            for (int e = tid2; e < G * DH / 2 && !((kflags & 64) && b == 0 && hkv == 0); e += NWT * 64) {
                 v2u gr;
                 gr.x = reinterpret_cast<const u32*>(&s_meta[0][0][0])[e];
                 gr.y = tag;
@@ -831,6 +832,11 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
                 const int i0 = tid2 * 8, i1 = (256 + tid2) * 8;
                 const bool p0 = i0 < own_lo, p1 = i1 < own_lo;
                 const u32 o0 = p0 ? (u32)i0 * 4u : 0xFFFFFF00u, o1 = p1 ? (u32)i1 * 4u : 0xFFFFFF00u;
+                // BOUNDED (round 5): after spin_cap polls the wave stops waiting, sets QS_ERR_ATTN_HANDOVER in the device error word
+                // (the word behind the exchange rows) and quantises what it has - a wrong row and a status bit instead of a hung
+                // GPU.  The generation still advances, so the NEXT launch is clean by itself (a late granule carries a stale tag).
+                const int spin_cap = (kflags & 64) ? 4096 : QS_SPIN_CAP;
+                int polls = 0;
                 for (;;) {
                     const v4u g00 = __builtin_amdgcn_raw_buffer_load_b128(xrs, o0, 0, 17);
                     const v4u g01 = __builtin_amdgcn_raw_buffer_load_b128(xrs, o0, 16, 17);
@@ -841,6 +847,11 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
                     raw[0] = (v4u){g00.x, g00.z, g01.x, g01.z};
                     raw[1] = (v4u){g10.x, g10.z, g11.x, g11.z};
                     if (!__builtin_amdgcn_ballot_w64((p0 && m0) || (p1 && m1))) break;
+                    if (++polls >= spin_cap) {
+                        if ((tid2 & 63) == 0)
+                            atomicOr(qcounters + QS_ATTNQ_CAP + (size_t)QS_ATTNQ_CAP * QS_ATTNQ_ROW, QS_ERR_ATTN_HANDOVER);
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (!p0 && i0 < hidden) raw[0] = reinterpret_cast<const v4u*>(&s_meta[0][0][0])[(i0 - own_lo) >> 3];
@@ -1037,7 +1048,7 @@ unsigned* qs_attn_quant_counters(hipStream_t st, int batch) {
         return nullptr;
     }
     void* p = nullptr;
-    const size_t bytes = (size_t)QS_ATTNQ_CAP * 4 + (size_t)QS_ATTNQ_CAP * QS_ATTNQ_ROW * 4;
+    const size_t bytes = (size_t)QS_ATTNQ_CAP * 4 + (size_t)QS_ATTNQ_CAP * QS_ATTNQ_ROW * 4 + 64;   // + the device error word
     // (the memset runs on the NULL stream: synchronise, or a launch on a non-blocking stream could overtake it)
     if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         (void)hipGetLastError();
@@ -1045,6 +1056,24 @@ unsigned* qs_attn_quant_counters(hipStream_t st, int batch) {
     }
     g_qcounters[dev] = reinterpret_cast<unsigned*>(p);
     return g_qcounters[dev];
+}
+
+unsigned* qs_attn_error_word() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !g_qcounters[dev]) return nullptr;
+    return g_qcounters[dev] + QS_ATTNQ_CAP + (size_t)QS_ATTNQ_CAP * QS_ATTNQ_ROW;
+}
+int qs_attn_reset_handoff() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !g_qcounters[dev]) return QS_OK;
+    const size_t bytes = (size_t)QS_ATTNQ_CAP * 4 + (size_t)QS_ATTNQ_CAP * QS_ATTNQ_ROW * 4 + 64;
+    hipError_t e = hipMemset(g_qcounters[dev], 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        qs_set_error("qs_device_reset (attention): %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return QS_OK;
 }
 
 // called from attention.hip's dispatcher for KV4.  force_split: 0 = heuristic, n > 0 = exactly n splits (tests)
@@ -1095,6 +1124,7 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
         qscale = reinterpret_cast<__half*>(g_qs_attn_quant.qscale);
         qsum = reinterpret_cast<__half*>(g_qs_attn_quant.qsum);
         g_qs_attn_quant.done = 1;
+        if (g_inject_fault & 2) kflags |= 64, g_inject_fault &= ~2;   // one-shot (qs_debug_inject_fault)
     }
 #define QS_LAUNCH_G(GG)                                                                                             \
     hipLaunchKernelGGL((decode_attention_mfma_kernel<GG>), grid, dim3(NWT * 64), 0, st, q, k, v, kvp, len, out, H, Hkv, \

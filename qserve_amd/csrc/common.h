@@ -190,6 +190,20 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 // is filled with it byte-wise (0x80), and no partial sum of a slice of at most 32 768 k can reach it (128 * 255 * 32768 < 2^30)
 constexpr int QS_SLAB_SENTINEL = (int)0x80808080u;
 
+// Bounded in-launch waits (round 5).  The two cross-workgroup hand-offs that poll inside a launch - the K-slice seam of the ring
+// GEMM and the finisher of the attention + quant fusion - give up after QS_SPIN_CAP polls (each poll is a memory round trip of
+// ~1 us plus a sleep: seconds, i.e. never in a healthy launch), OR a bit into a per-device error word and finish with whatever
+// they have; qs_device_status() reads the word, qs_device_reset() clears it and puts the hand-off areas back into their
+// initial state.  qs_debug_inject_fault() arms a one-shot fault (a producer that never delivers) so that the path is testable.
+constexpr int QS_SPIN_CAP = 1 << 20;
+constexpr unsigned QS_ERR_GEMM_SEAM = 1u;     // K-slice seam: a partial tile never arrived
+constexpr unsigned QS_ERR_ATTN_HANDOVER = 2u; // attention + quant: a KV head's result row never arrived
+extern int g_inject_fault;                    // lib.hip: bit 0 next K-sliced ring GEMM launch, bit 1 next attention + quant launch
+unsigned* qs_gemm_error_word();               // gemm_w4a8.hip: nullptr until the split-K workspace exists
+unsigned* qs_attn_error_word();               // attention_mfma.hip: nullptr until the hand-over workspace exists
+int qs_gemm_reset_handoff();                  // gemm_w4a8.hip: sentinel-fill the K-slice slabs, clear the error word
+int qs_attn_reset_handoff();                  // attention_mfma.hip: zero generation words / exchange rows, clear the error word
+
 struct QsGemmPlan {
     int active;   // 1 while qs_w4a8_gemm_plan runs the dispatcher
     int family;   // 1 split-K, 2 LDS-pair, 3 ring, 4 tiled

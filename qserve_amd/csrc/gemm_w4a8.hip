@@ -309,6 +309,29 @@ Workspace* get_workspace(hipStream_t stream) {
     }
     return w.slabs ? &w : nullptr;
 }
+}  // namespace
+// the device error word of the GEMM hand-offs: the LAST ticket counter (never used as a ticket: see ring_ws / launch_splitk)
+unsigned* qs_gemm_error_word() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    Workspace& w = g_ws[dev];
+    return w.slabs ? w.counters + (w.ncounters - 1) : nullptr;
+}
+int qs_gemm_reset_handoff() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return QS_OK;
+    Workspace& w = g_ws[dev];
+    if (!w.slabs) return QS_OK;
+    hipError_t e = hipMemset(w.ring_slabs, 0x80, w.slab_bytes);
+    if (e == hipSuccess) e = hipMemset(w.counters, 0, (size_t)w.ncounters * sizeof(unsigned));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        qs_set_error("qs_device_reset (gemm): %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return QS_OK;
+}
+namespace {
 
 template <int MT, int MODE, int OUTK, int NSTAGE>
 int launch_splitk(const int8_t* A, const uint8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
@@ -345,7 +368,7 @@ int launch_splitk(const int8_t* A, const uint8_t* W, const int8_t* zeros, const 
         Workspace* ws = get_workspace(stream);
         const size_t tiles = (size_t)grid.x * grid.y;
         const size_t need = tiles * S * (size_t)(MT * 4 * 64) * 16;
-        if (ws && need <= ws->slab_bytes && tiles <= (size_t)ws->ncounters) {
+        if (ws && need <= ws->slab_bytes && tiles < (size_t)ws->ncounters) {     // (the last counter is the error word)
             slabs = ws->slabs;
             counters = ws->counters;
             grid.z = S;
@@ -372,6 +395,11 @@ int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, con
 int qs_launch_gemm_tiled(int mode, int outk, const int8_t* A, const uint8_t* W, const int8_t* zeros,
                          const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
                          const void* assums, void* out, int M, int N, int K, int mtile, hipStream_t stream);
+// compute-bound kernel, four-wave tile (gemm_w4a8_wide.hip)
+int qs_launch_gemm_wide(int mode, int outk, const int8_t* A, const uint8_t* W, const int8_t* zeros,
+                        const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
+                        const void* assums, void* out, int M, int N, int K, int persist_mode, hipStream_t stream);
+extern int g_tiled_order;   // gemm_w4a8_tiled.hip
 namespace {
 
 constexpr int QS_UNFUSED = 1 << 20;   // internal: the chosen kernel has no activation epilogue
@@ -405,9 +433,9 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
     // tiles fill the chip; variant 3000 disables it, 3001 / 3002 force the 256- / 128-token tile
     if (N % 256 == 0 && K >= 256 && K < (1 << 24) && (size_t)M * K < (1ull << 32) && (size_t)N * K / 2 < (1ull << 32)) {
         int tmt = 0;
-        if (g_variant == 3001) tmt = 8;
+        if (g_variant == 3001 || g_variant == 3003) tmt = 8;
         else if (g_variant == 3002) tmt = 4;
-        else if (g_variant < 1000 || g_variant > 3002) {
+        else if (g_variant < 1000 || g_variant > 3003) {
             const long nb = N / 256;
             // measured crossovers (scripts/bench_gemm_big.py, N=4096..28672): the tiles must (nearly) fill 256 CUs
             // (M >= 192: a 256-token tile must be mostly real tokens - without this bound every N >= 49 152 took the tiled
@@ -415,6 +443,11 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
             if (M >= 192 && ((M + 255) / 256) * nb >= 192) tmt = 8;
             else if (M >= 256 && ((M + 127) / 128) * nb >= (MODE == 0 ? 96 : 192)) tmt = 4;
         }
+        // 256-token tiles: the four-wave kernel (gemm_w4a8_wide.hip; round 5) unless variant 3001 asks for the eight-wave one
+        // (A/B, tests); 3003 forces it for any M
+        if (tmt == 8 && g_variant != 3001)
+            return qs_launch_gemm_wide(MODE, outk, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,
+                                       g_tiled_order / 10, stream);
         if (tmt)
             return qs_launch_gemm_tiled(MODE, outk, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,
                                         tmt, stream);
@@ -429,7 +462,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         if (g_qs_plan.active) return true;      // plan-only: assume the workspace exists
         Workspace* ws = get_workspace(stream);
         const size_t tiles = (size_t)units * mb;
-        if (!ws || tiles > (size_t)ws->ncounters || tiles * ks * mt * 4096 > ws->slab_bytes) return false;
+        if (!ws || tiles >= (size_t)ws->ncounters || tiles * ks * mt * 4096 > ws->slab_bytes) return false;
         *slabs = ws->ring_slabs;
         *counters = ws->counters;
         return true;
@@ -581,7 +614,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
 }  // namespace
 
 extern int g_tiled_dbg;   // gemm_w4a8_tiled.hip: timing experiments (3100 + bits)
-extern int g_tiled_order; // gemm_w4a8_tiled.hip: tile order A/B (3200 + mode)
+extern int g_wide_order;  // gemm_w4a8_wide.hip: the same switch for the four-wave kernel
 extern int g_ring_flags;  // gemm_w4a8_ring.hip: A/B switches of the decode kernel (5000 + bits), results unchanged
 extern int g_act_off;
 extern "C" void qs_set_gemm_variant(int variant) {
@@ -591,6 +624,7 @@ extern "C" void qs_set_gemm_variant(int variant) {
     }
     if (variant >= 3200 && variant < 3300) {
         g_tiled_order = variant - 3200;
+        g_wide_order = (variant - 3200) % 10;
         return;
     }
     if (variant == 3300 || variant == 3301) {

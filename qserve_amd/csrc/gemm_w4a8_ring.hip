@@ -31,6 +31,7 @@
 //        gate_up at M = 64 17.5 us -> 16.3 / 16.8, both off 15.9 us = 4.2 us of head and tail + 512 KB per CU at 44 GB/s,
 //        the rate scripts/microbench_cufill.hip measures for this L2 + HBM mix with nothing else going on)
 //   16 = (set by the launcher, not by the variant) per-channel epilogue convention qs_set_gemm_epilogue(1): fmaf form
+//   128 = (set by the launcher) the armed one-shot fault of qs_debug_inject_fault: tile 0's K-slice producers do not deliver
 //   256 * d = ring depth d (3..6, if 160 KiB allow): sensitivity to the bytes in flight
 int g_ring_flags = 0;
 
@@ -519,15 +520,24 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
             const size_t tile = (size_t)(unit0 + wn) * mblocks + mblk;
             v4i* const slab = reinterpret_cast<v4i*>(slabs) + tile * ksplit * (size_t)(NP * 64) + lane;
             if (kq != ksplit - 1) {
+                // (flags & 128: the armed one-shot fault of qs_debug_inject_fault - tile 0's producers never deliver)
+                if (!((flags & 128) && tile == 0)) {
 #pragma unroll
-                for (int q = 0; q < PPG; ++q) {
-                    const int pc = q * KG + kg;
-                    if (NP % KG != 0 && pc >= NP) continue;
-                    v4i* const dst = slab + ((size_t)kq * NP + pc) * 64;
-                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(sum[q]) : "memory");
+                    for (int q = 0; q < PPG; ++q) {
+                        const int pc = q * KG + kg;
+                        if (NP % KG != 0 && pc >= NP) continue;
+                        v4i* const dst = slab + ((size_t)kq * NP + pc) * 64;
+                        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(sum[q]) : "memory");
+                    }
                 }
                 return;
             }
+            // BOUNDED (round 5): after `spin_cap` polls the wave stops waiting, reports through the device error word (`counters`
+            // = qs_gemm_error_word()) and finishes with what it has - a wrong tile and a status bit instead of a hung GPU, if the
+            // dispatch-order assumption above ever fails or the slabs were left without their sentinel (include/qserve_amd.h)
+            const int spin_cap = (flags & 128) ? 4096 : QS_SPIN_CAP;
+            int polls = 0;
+            bool gave_up = false;
             constexpr int ZB = PPG <= 4 ? 3 : 1;       // slices requested together (up to 12 x 16 B per lane in flight)
             const v4i sent = {QS_SLAB_SENTINEL, QS_SLAB_SENTINEL, QS_SLAB_SENTINEL, QS_SLAB_SENTINEL};
             // cache-missing loads through the buffer BUILTIN (aux 17 = sc0 | sc1): the compiler counts them and waits before
@@ -567,6 +577,10 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
                     if (g_ring_trace && lane == 0) g_ring_trace[((size_t)blockIdx.x * 8 + wave) * 16 + 13] += 1;
 #endif
                     if (!__builtin_amdgcn_ballot_w64(missing != 0)) break;
+                    if (++polls >= spin_cap) {
+                        gave_up = true;
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(2);
                 }
 #pragma unroll
@@ -584,6 +598,7 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
                     }
                 }
             }
+            if (gave_up && counters && lane == 0) atomicOr(counters, QS_ERR_GEMM_SEAM);
             QS_STAMP(14);
         }
 #pragma unroll
@@ -724,11 +739,16 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
         configured = 160 * 1024;
     }
     dim3 grid((N / (64 * WN)) * mblocks * ksplit);
+    int inject = 0;
+    if (KSPLIT && OUTK != 3 && ksplit > 1) {
+        counters = qs_gemm_error_word();               // the kernel's `counters` is the device error word of the seam's bounded wait
+        if (g_inject_fault & 1) inject = 128, g_inject_fault &= ~1;
+    }
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, A, W, zeros, scales8,
                        reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
                        reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K,
                        mblocks, ns, ksplit, slabs, counters,
-                       (g_ring_flags & ~(3 | 16)) | (g_epi_fma ? 16 : 0) | ((g_ring_flags & 1) || (mblocks > 1 && N <= 8192 && !(g_ring_flags & 2)) ? 1 : 0));
+                       (g_ring_flags & ~(3 | 16 | 128)) | inject | (g_epi_fma ? 16 : 0) | ((g_ring_flags & 1) || (mblocks > 1 && N <= 8192 && !(g_ring_flags & 2)) ? 1 : 0));
     return qs_launch_status("w4a8 gemm (ring)");
 }
 

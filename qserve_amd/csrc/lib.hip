@@ -14,6 +14,43 @@ extern "C" int qs_version(void) { return 1; }
 extern "C" const char* qs_arch(void) { return "gfx950"; }
 extern "C" const char* qs_last_error(void) { return g_err; }
 
+// ---- bounded in-launch waits: status, reset, fault injection (common.h) ---------------------------------------------------------
+int g_inject_fault = 0;
+extern "C" int qs_device_status(int* error_bits) {
+    QS_REQUIRE(error_bits, "qs_device_status: null output");
+    *error_bits = 0;
+    unsigned* words[2] = {qs_gemm_error_word(), qs_attn_error_word()};
+    for (unsigned* w : words) {
+        if (!w) continue;
+        unsigned v = 0;
+        const hipError_t e = hipMemcpy(&v, w, sizeof(v), hipMemcpyDeviceToHost);   // (blocking: orders behind the launches so far)
+        if (e != hipSuccess) {
+            qs_set_error("qs_device_status: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        *error_bits |= (int)v;
+    }
+    if (*error_bits)
+        qs_set_error("a bounded in-launch wait gave up (bits %d: 1 = K-slice seam of a W4A8 GEMM, 2 = attention + quant hand-over): "
+                     "results of that launch are invalid; call qs_device_reset() before reusing the library", *error_bits);
+    return QS_OK;
+}
+extern "C" int qs_device_reset(void) {
+    const hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        qs_set_error("qs_device_reset: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    int rc = qs_gemm_reset_handoff();
+    if (rc == QS_OK) rc = qs_attn_reset_handoff();
+    return rc;
+}
+extern "C" int qs_debug_inject_fault(int what) {
+    QS_REQUIRE(what >= 0 && what <= 3, "qs_debug_inject_fault: what=%d not in 0..3", what);
+    g_inject_fault = what;
+    return QS_OK;
+}
+
 // Device self-test of the wave reductions (common.h): the DPP / permlane butterfly must round exactly like the
 // __shfl_xor loop it replaces.  in: float [n] (n % 64 == 0), out: float [n / 64][4] = {sum, sum via shfl, max, max via shfl}.
 namespace {

@@ -29,6 +29,7 @@ import qserve_backend.qgemm_w4a8_per_group as gemm_grp
 
 from . import fused as fusedmod
 from . import tp as tpmod
+from ._lib import device_status as _device_status
 from .backend._util import check as _check, lib as _lib, stream
 
 
@@ -556,6 +557,11 @@ class DecodeEngine:
         if self.ar is not None and self.ar.error():
             raise RuntimeError("direct all-reduce: a wait for a peer rank timed out (ranks more than a few seconds apart, or "
                                "a peer died); the communicators' epochs no longer match - re-create them")
+        bits = _device_status()                        # K-slice seam of the GEMMs / attention + quant hand-over
+        if bits:
+            raise RuntimeError(f"a bounded in-launch wait of libqserve_amd gave up (error bits {bits}: 1 = K-slice seam of a W4A8 "
+                               "GEMM, 2 = attention + quant hand-over): the tensors of that step are undefined; call "
+                               "qserve_amd._lib.lib.qs_device_reset() before the next step")
 
     def run(self):
         if getattr(self, "pieces", None):

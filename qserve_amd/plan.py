@@ -3,7 +3,7 @@ import ctypes as C
 
 from ._lib import check, lib
 
-FAMILIES = {1: "splitk", 2: "pair", 3: "ring", 4: "tiled"}
+FAMILIES = {1: "splitk", 2: "pair", 3: "ring", 4: "tiled", 5: "wide"}
 
 
 def gemm_plan(M, N, K, per_group=False):
@@ -14,7 +14,7 @@ def gemm_plan(M, N, K, per_group=False):
     fam = FAMILIES.get(buf[0], "none")
     if fam == "ring":
         return dict(family=fam, m_tiles=buf[1], units=buf[2], token_blocks=buf[3], k_slices=buf[4])
-    if fam == "tiled":
+    if fam in ("tiled", "wide"):
         return dict(family=fam, tile_tokens=32 * buf[1])
     if fam == "splitk":
         return dict(family=fam, m_tiles=buf[1], waves=buf[2], slices=buf[3], xcd_map=bool(buf[4]))

@@ -1,0 +1,101 @@
+"""The two in-launch cross-workgroup waits of the library (K-slice seam of the ring GEMM, finisher of the attention + quant
+fusion) are BOUNDED: a producer that never delivers yields a status bit and an invalid result - not a hung GPU - and
+qs_device_reset() brings the library back (include/qserve_amd.h, "Bounded in-launch waits").  The fault is planted with the
+library's one-shot injection hook: through valid inputs it cannot be produced (the seam's sentinel is out of reach of every
+admitted partial sum, the hand-over's tags are read from one word by both sides)."""
+import numpy as np
+import pytest
+import torch
+
+from _helpers import dev
+from oracle import synth, w4a8
+
+pytestmark = pytest.mark.gpu
+
+
+def _status():
+    from qserve_amd._lib import device_status
+    return device_status()
+
+
+@pytest.mark.parametrize("variant,M,N,K", [(4221, 40, 256, 2048), (4422, 64, 128, 4096)])
+def test_k_slice_seam_gives_up_reports_and_recovers(gpu, variant, M, N, K):
+    import qserve_backend.qgemm_w4a8_per_chn as op
+    from qserve_amd import _lib
+    lib = _lib.lib
+    pr = synth.per_channel_problem(M, N, K, seed=variant)
+    _, out_ref = w4a8.gemm_per_chn(pr["A"], pr["qweight"], pr["wscales"], pr["ascales"], pr["w_szs"], pr["a_ssums"])
+    args = [dev(pr[k]) for k in ("A", "qweight", "wscales", "ascales", "w_szs", "a_ssums")]
+
+    def run():
+        out = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+        op.gemm_forward_cuda(*args, out)
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    try:
+        assert lib.qs_device_reset() == 0
+        lib.qs_set_gemm_variant(variant)
+        assert np.array_equal(run().view(np.uint16), out_ref.view(np.uint16)) and _status() == 0
+        assert lib.qs_debug_inject_fault(1) == 0         # the next K-sliced launch: tile 0's producers never deliver
+        bad = run()                                      # returns (bounded wait), tile 0 is wrong
+        assert _status() & 1, "the seam's give-up was not reported"
+        assert b"bounded in-launch wait" in lib.qs_last_error()
+        assert not np.array_equal(bad.view(np.uint16), out_ref.view(np.uint16))
+        assert _status() & 1, "the status word is sticky until the reset"
+        assert lib.qs_device_reset() == 0 and _status() == 0
+        for _ in range(3):                               # clean again, launch after launch
+            assert np.array_equal(run().view(np.uint16), out_ref.view(np.uint16))
+        assert _status() == 0
+    finally:
+        lib.qs_debug_inject_fault(0)
+        lib.qs_set_gemm_variant(-1)
+        lib.qs_device_reset()
+
+
+def test_attention_quant_hand_over_gives_up_reports_and_recovers(gpu):
+    """Through the decode engine (tiny Llama, fused pairs: the attention launch carries the quantiser): an injected missing
+    KV-head row makes DecodeEngine.check() raise; after qs_device_reset() a fresh engine reproduces the healthy run bit for bit."""
+    from qserve_amd import _lib
+    from qserve_amd.decode import TINY, DecodeEngine
+    lib = _lib.lib
+
+    def engine():
+        e = DecodeEngine(TINY, batch=5, prompt_len=70, max_new=6, group_size=-1, device="cuda:0", seed=3, fuse_pairs=True)
+        e.prefill_cache(70)
+        return e
+
+    try:
+        assert lib.qs_device_reset() == 0
+        good = engine()
+        toks = []
+        for _ in range(3):
+            good.step()
+            toks.append(good.tokens.clone())
+        good.check()                                     # healthy: no error
+        hurt = engine()
+        hurt.step()
+        assert lib.qs_debug_inject_fault(2) == 0         # next attention + quant launch: sequence 0's KV head 0 never delivers
+        hurt.step()
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="bounded in-launch wait"):
+            hurt.check()
+        assert lib.qs_device_reset() == 0 and _status() == 0
+        again = engine()
+        for i in range(3):
+            again.step()
+            assert torch.equal(again.tokens, toks[i])
+        again.check()
+        # without the reset the NEXT launch is clean by itself as well (the generation advanced; a late row carries a stale tag)
+        assert lib.qs_debug_inject_fault(2) == 0
+        hurt2 = engine()
+        hurt2.step()
+        torch.cuda.synchronize()
+        assert _status() & 2
+        fresh = engine()
+        for i in range(3):
+            fresh.step()
+            assert torch.equal(fresh.tokens, toks[i])
+    finally:
+        lib.qs_debug_inject_fault(0)
+        lib.qs_device_reset()

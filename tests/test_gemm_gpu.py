@@ -48,7 +48,7 @@ def test_per_group_vs_oracle(gpu, M, N, K, valid):
 TILED = [(256, 256, 256), (300, 512, 384), (513, 256, 1024), (1000, 768, 512)]   # prefill-sized: LDS-tiled kernel
 
 
-@pytest.fixture(params=[3001, 3002], ids=["tile256", "tile128"])
+@pytest.fixture(params=[3001, 3002, 3003], ids=["tile256", "tile128", "wide256"])
 def tiled_variant(request):
     """The dispatcher only picks the tiled kernel for chip-filling shapes; force it for oracle-sized ones."""
     from qserve_amd import _lib
@@ -87,9 +87,10 @@ def test_tiled_per_group_vs_oracle(gpu, tiled_variant, M, N, K, valid):
     assert ulp_diff_f16(out.cpu().numpy(), out_ref).max() == 0
 
 
+@pytest.mark.parametrize("kernel", [3001, 3003], ids=["tile256", "wide256"])
 @pytest.mark.parametrize("mode", ["per_channel", "per_group"])
 @pytest.mark.parametrize("M,N,K", [(1000, 768, 512), (1281, 1024, 256), (700, 2560, 1152)])
-def test_tiled_workgroup_walks_several_tiles(gpu, mode, M, N, K):
+def test_tiled_workgroup_walks_several_tiles(gpu, mode, M, N, K, kernel):
     """Variant 3220: three workgroups walk all the (256-token) tiles - the next tile's pipeline fill is issued before the
     epilogue of the current one (what one workgroup per CU does at prompt sizes).  Same bits as one workgroup per tile
     (3210) and as the oracle."""
@@ -108,7 +109,7 @@ def test_tiled_workgroup_walks_several_tiles(gpu, mode, M, N, K):
         fn = opg.gemm_forward_cuda
     outs = []
     try:
-        _lib.lib.qs_set_gemm_variant(3001)
+        _lib.lib.qs_set_gemm_variant(kernel)          # the eight-wave tile / the four-wave tile (gemm_w4a8_wide.hip)
         for v in (3220, 3210):
             _lib.lib.qs_set_gemm_variant(v)
             out = torch.full((M + 2, N), float("nan"), dtype=torch.float16, device=gpu)
@@ -129,7 +130,7 @@ def test_tiled_workgroup_walks_several_tiles(gpu, mode, M, N, K):
 GATE_UP = [(4111, 16, 128, 1024), (4121, 23, 256, 1024), (4141, 50, 256, 2048), (4122, 32, 256, 512),
            (4142, 64, 512, 1024), (4144, 100, 512, 1024), (4144, 128, 1024, 2048), (4222, 20, 256, 1024),
            (3001, 300, 512, 384), (3002, 513, 1024, 512), (3220, 1000, 1536, 512), (-1, 64, 1792, 1024),
-           (-1, 7, 256, 128)]
+           (-1, 7, 256, 128), (3003, 300, 512, 384), (3003, 513, 1024, 512), (3223, 1000, 1536, 512)]
 
 
 @pytest.mark.parametrize("variant,M,N,K", GATE_UP)
@@ -160,6 +161,9 @@ def test_gate_up_silu_mul_vs_oracle_and_op_pair(gpu, variant, M, N, K, mode):
     try:
         if variant == 3220:
             _lib.lib.qs_set_gemm_variant(3001)
+        if variant == 3223:                            # the four-wave tile with three workgroups walking the tiles
+            _lib.lib.qs_set_gemm_variant(3003)
+            variant = 3220
         _lib.lib.qs_set_gemm_variant(variant)
         for two_launches in (0, 1):
             _lib.lib.qs_set_gemm_variant(3300 + two_launches)
@@ -226,7 +230,7 @@ def test_tiled_kernel_equals_decode_kernel(gpu):
     A, W, Z, S = dev(pr["A"]), dev(pr["qweight"]), dev(pr["s2_zeros"]), dev(pr["s2_scales"])
     outs = []
     try:
-        for v in (3000, 3001, 3002):
+        for v in (3000, 3001, 3002, 3003):
             _lib.lib.qs_set_gemm_variant(v)
             out = torch.full((96, 512), float("nan"), dtype=torch.float16, device=gpu)
             op.gemm_forward_cuda(A, W, Z, S, dev(pr["wscales"]), dev(pr["ascales"]), out)
@@ -235,6 +239,7 @@ def test_tiled_kernel_equals_decode_kernel(gpu):
         _lib.lib.qs_set_gemm_variant(-1)
     assert np.array_equal(outs[0].view(np.uint16), outs[1].view(np.uint16))
     assert np.array_equal(outs[0].view(np.uint16), outs[2].view(np.uint16))
+    assert np.array_equal(outs[0].view(np.uint16), outs[3].view(np.uint16))
 
 
 # decode ring kernel: (variant = 4100 + 100*(ksplit-1) + 10*m_tiles + units, M, N, K); K/64/ksplit divisible by

@@ -25,7 +25,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not ava
 def asm(tmp_path_factory):
     out = {}
     d = tmp_path_factory.mktemp("asm")
-    for name in ("attention_mfma", "attention_mfma8", "gemm_w4a8_ring", "gemm_w4a8_tiled"):
+    for name in ("attention_mfma", "attention_mfma8", "gemm_w4a8_ring", "gemm_w4a8_tiled", "gemm_w4a8_wide"):
         dst = d / (name + ".s")
         r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(dst),
                             os.path.join(CSRC, name + ".hip")], capture_output=True, text=True)
@@ -78,7 +78,7 @@ def test_kv8_attention_page_loop_has_only_the_hand_placed_vmcnt_waits(asm):
         assert waits == ["9", "0", "9", "0"], f"{name}: {waits}"
 
 
-@pytest.mark.parametrize("unit", ["attention_mfma", "attention_mfma8", "gemm_w4a8_ring", "gemm_w4a8_tiled"])
+@pytest.mark.parametrize("unit", ["attention_mfma", "attention_mfma8", "gemm_w4a8_ring", "gemm_w4a8_tiled", "gemm_w4a8_wide"])
 def test_hot_path_kernels_do_not_spill(asm, unit):
     text = asm[unit]
     names = re.findall(r"^\s*\.amdhsa_kernel (\S+)", text, re.M)
@@ -98,3 +98,68 @@ def test_decode_attention_fits_two_workgroups_per_cu(asm):
         alloc = (vg + 7) // 8 * 8
         assert 512 // alloc >= 4, f"{name}: {vg} VGPRs -> fewer than 4 waves per SIMD (two 8-wave workgroups per CU)"
         assert 2 * lds <= 160 * 1024, f"{name}: {lds} B of LDS per workgroup"
+
+
+def _instructions(body):
+    """(mnemonic, operand text, inside_asm) of every instruction of a kernel body, in order."""
+    out, inside = [], False
+    for line in body.splitlines():
+        t = line.strip()
+        if t.startswith(";;#ASMSTART"):
+            inside = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            inside = False
+            continue
+        if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
+            continue
+        t = t.split(";")[0].strip()
+        if not t:
+            continue
+        parts = t.split(None, 1)
+        out.append((parts[0], parts[1] if len(parts) > 1 else "", inside))
+    return out
+
+
+def _vregs(tok):
+    """register numbers of a v[a:b] / vN operand token"""
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def test_wide_gemm_owns_the_accumulator_file(asm):
+    """gemm_w4a8_wide.hip addresses a[0:255] from inline-asm MFMAs with fixed register numbers.  The compiler must (a) allocate
+    the whole accumulator file and leave 256 VGPRs' worth of room for it, (b) never touch an accumulator register itself (a spill
+    into the file or a v_accvgpr_* of its own would be silent corruption), (c) never write an MFMA source operand with a VALU
+    instruction fewer than two instructions ahead of the MFMA (inside an asm statement nothing pads that hazard), and every stage
+    instantiation must contain its 64 MFMAs."""
+    text = asm["gemm_w4a8_wide"]
+    ks = {n: b for n, b in kernels(text).items() if "w4a8_gemm_wide" in n}
+    assert len(ks) == 6
+    for name, body in ks.items():
+        assert meta(text, name, "NumAgprs") == 256, name
+        assert meta(text, name, "NumVgprs") <= 200, name
+        ins = _instructions(body)
+        mf = [i for i, (op, _, _) in enumerate(ins) if op.startswith("v_mfma")]
+        assert len(mf) % 64 == 0 and len(mf) >= 6 * 64, f"{name}: {len(mf)} MFMAs"
+        for i, (op, args, inside) in enumerate(ins):
+            if not inside:
+                assert not op.startswith("v_accvgpr") and not re.search(r"\ba\[?\d", args), \
+                    f"{name}: compiler-generated accumulator access: {op} {args}"
+            else:
+                assert not op.startswith("v_accvgpr_write") and not op.startswith("v_accvgpr_mov"), (name, op, args)
+        for i in mf:
+            op, args, inside = ins[i]
+            assert inside, f"{name}: an MFMA outside inline asm"
+            toks = [t.strip() for t in args.split(",")]
+            assert re.fullmatch(r"a\[\d+:\d+\]", toks[0]) and toks[3] in (toks[0], "0"), (name, args)
+            srcs = _vregs(toks[1]) | _vregs(toks[2])
+            assert len(srcs) == 8, (name, args)
+            for j in (i - 1, i - 2):
+                pop, pargs, _ = ins[j]
+                if pop.startswith("v_") and not pop.startswith("v_mfma") and not pop.startswith("v_cmp"):
+                    dst = _vregs(pargs.split(",")[0].strip())
+                    assert not (dst & srcs), f"{name}: {pop} {pargs} writes a source of the MFMA {args} {i - j} instruction(s) later"
