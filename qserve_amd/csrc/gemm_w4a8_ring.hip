@@ -257,11 +257,15 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
         constexpr int NCH = 64 * WN;                  // channels of the workgroup's tile
 #pragma unroll
         for (int i = 0; i < (NCH + 127) / 128; ++i) { // 128 halfs per instruction
-            int lc = 128 * i + 2 * lane;
-            lc = lc < NCH ? lc : NCH - 2;             // surplus lanes repeat a valid address
-            const int gc = ACT ? (lc < 32 * WN ? 32 * unit0 + lc : N / 2 + 32 * unit0 + (lc - 32 * WN)) : unit0 * 64 + lc;
-            dma4p(reinterpret_cast<const _Float16*>(wscales) + gc, sc_lds + 256 * i);
-            if (MODE == 0) dma4p(reinterpret_cast<const _Float16*>(wszs) + gc, sc_lds + 2 * NCH + 256 * i);
+            const int lc = 128 * i + 2 * lane;
+            // lanes beyond the tile's channels (one-unit workgroups: lanes 32-63) are masked OUT of the DMA: an LDS-DMA lane writes
+            // M0 + 4 * lane whatever its source, and a surplus lane would land in the NEXT region of this staging area (correct
+            // only as long as the later DMA that fills that region also lands later - nothing guarantees write order)
+            if (lc < NCH) {
+                const int gc = ACT ? (lc < 32 * WN ? 32 * unit0 + lc : N / 2 + 32 * unit0 + (lc - 32 * WN)) : unit0 * 64 + lc;
+                dma4p(reinterpret_cast<const _Float16*>(wscales) + gc, sc_lds + 256 * i);
+                if (MODE == 0) dma4p(reinterpret_cast<const _Float16*>(wszs) + gc, sc_lds + 2 * NCH + 256 * i);
+            }
         }
         {   // token vectors: one half per lane in a 4-byte slot (2-byte requests: no alignment assumption on a [M] vector)
             int m = m0 + lane;

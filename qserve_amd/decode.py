@@ -236,12 +236,17 @@ class DecodeEngine:
         # the pair fusions are on, on one GPU, for shapes the library has such a launch for
         if planes is None:
             planes = tuple(x for x in os.environ.get("QS_PLANES", "down").split(",") if x)
+        bad = [x for x in planes if x not in ("o", "down")]
+        if bad:
+            raise ValueError(f"planes / QS_PLANES: {bad} - only the row-parallel projections 'o' and 'down' have a planes form")
         self.planes = {}
         if fuse_pairs and tp_world == 1 and hid <= 4096 and hid % 2048 == 0:
             for name in planes:
-                ks = self.layers[0][name].planes_slices(B)
-                if ks:
-                    self.planes[name] = torch.empty((ks, B, hid), dtype=torch.int32, device=self.dev)
+                # one buffer serves every layer: the form is taken only if EVERY layer's projection has it with the same number
+                # of slices (a layer with a bias, or of another shape, would otherwise run the planes path and lose its bias)
+                ks = {layer[name].planes_slices(B) for layer in self.layers}
+                if len(ks) == 1 and 0 not in ks:
+                    self.planes[name] = torch.empty((ks.pop(), B, hid), dtype=torch.int32, device=self.dev)
         self.lengths = torch.full((B,), prompt_len, dtype=torch.int32, device=self.dev)   # context incl. new token
         self.tokens = torch.randint(0, cfg["vocab"], (B,), device=self.dev, generator=gen)
         # Tensor parallel: the (un-quantised) lm_head is cut over the vocabulary - rank r multiplies rows [v0, v0 + V/N)

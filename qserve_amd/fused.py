@@ -185,6 +185,16 @@ def add_residual_rms_norm_general_planes(out, hidden, planes, wscales, ascales, 
     T = hidden.numel() // hid
     if planes.dim() != 3 or planes.size(1) != T or planes.size(2) != hid:
         raise RuntimeError(f"add_residual_rms_norm_general_planes: planes {tuple(planes.shape)} vs hidden [{T}, {hid}]")
+    # the C entry takes pointers + a plane stride: everything it will read or write must be there (a wrong-sized tensor would be
+    # read or written out of bounds on the device)
+    if not planes[0].is_contiguous() or not hidden.is_contiguous() or not out.is_contiguous():
+        raise RuntimeError("add_residual_rms_norm_general_planes: planes[i], hidden and out must be contiguous [T, hidden] blocks")
+    if out.numel() != T * hid:
+        raise RuntimeError(f"add_residual_rms_norm_general_planes: out has {out.numel()} elements, expected {T * hid}")
+    for n, t, need in (("wscales", wscales, hid), ("w_szs", w_szs, hid), ("weight", weight, hid), ("ascales", ascales, T),
+                       ("a_ssums", a_ssums, T), ("scaling", scaling, T), ("input_sum", input_sum, T)):
+        if t is not None and (t.numel() < need or not t.is_contiguous()):
+            raise RuntimeError(f"add_residual_rms_norm_general_planes: {n} needs {need} contiguous values, has {t.numel()}")
     with guard(out):
         check(lib.qs_add_residual_rms_norm_general_planes(
             ptr(out), ptr(hidden), ptr(planes), planes.size(0), planes.stride(0), ptr(wscales),

@@ -68,22 +68,30 @@ def run_case(gpu, B, H, Hkv, lengths, int4, seed):
     assert np.array_equal(dpool.v.cpu().numpy(), p_k.v), "V pages differ after decode (new token)"
     o = out.cpu().numpy().astype(np.float32)
     assert np.isfinite(o).all()
-    # tolerance: 1e-3 absolute (north_star).  For sequences of 1-2 tokens the output is ~ a V row itself, |out| can
-    # exceed 1 where fp16 spacing is 9.8e-4 .. 1.95e-3: there the oracle modes themselves (reference-order fp16
-    # arithmetic / fp16-rounded cache values / exact de-quantisation) differ by up to a few fp16 ulp.  Every output
-    # must agree with at least one mode (1e-3 or 2 fp16 ulp) and stay inside the envelope the modes span (+1e-3).
+    # The contract (north_star: within 1e-3 of the reference), per element, against the REFERENCE-ORDER restatement (oracle mode
+    # "kernel": the reference's own precisions and order of operations): |HIP - oracle| <= 1e-3 OR <= 2 fp16 ulp of the output
+    # (for sequences of 1-2 tokens the output is ~ a V row itself and |out| can exceed 1, where ONE fp16 ulp is 9.8e-4 .. 1.95e-3).
+    # Every element beyond it must be one of the elements listed BY NAME in tests/golden/attention_parity_exceptions.json (recorded
+    # on the MI355X with QS_PARITY_RECORD=1, every entry with its distance from exact math: the HIP kernel is the more exact side
+    # there); nothing else passes - in particular not "agrees with some other oracle mode".  Hard ceiling for the named ones: 2e-3
+    # on rows of >= 64 tokens (asserted below), the envelope of the three modes + 1e-3 on shorter ones.
     o16 = out.cpu().numpy()
     ek = np.abs(o - ref_k.astype(np.float32))
     ef = np.abs(o - ref_f.astype(np.float32))
     ee = np.abs(o - ref_e.astype(np.float32))
-    ok_k = (ek <= TOL) | (ulp_diff_f16(o16, ref_k) <= 2)
-    ok_f = (ef <= TOL) | (ulp_diff_f16(o16, ref_f) <= 2)
-    ok_e = (ee <= TOL) | (ulp_diff_f16(o16, ref_e) <= 2)
+    case = f"short_B{B}_H{H}_Hkv{Hkv}_{'kv4' if int4 else 'kv8'}_seed{seed}_L{'-'.join(str(int(x)) for x in pr['lengths'])}"
+    ulp_k = ulp_diff_f16(o16, ref_k)
+    beyond_k = (ek > TOL) & (ulp_k > 2)
+    found = sorted((int(b_), int(h_), int(d_)) for b_, h_, d_ in zip(*np.nonzero(beyond_k)))
+    _check_named_exceptions(case, "kernel", found,
+                            lambda b_, h_, d_: dict(context=int(pr["lengths"][b_]), hip=float(o[b_, h_, d_]),
+                                                    oracle=float(ref_k[b_, h_, d_]), abs_err=float(ek[b_, h_, d_]),
+                                                    fp16_ulps=int(ulp_k[b_, h_, d_]), hip_vs_exact=float(ee[b_, h_, d_])))
     refs = np.stack([ref_k.astype(np.float32), ref_f.astype(np.float32), ref_e.astype(np.float32)])
     env = (refs.max(0) - refs.min(0)) + TOL
-    bad = int((~(ok_k | ok_f | ok_e)).sum()) + int((ek > env).sum()) + int((ef > env).sum()) + int((ee > env).sum())
-    assert bad == 0, (f"{bad} outputs out of tolerance; max abs err {ek.max():.2e} (kernel-order oracle) / "
-                      f"{ef.max():.2e} (fp32 oracle)")
+    bad = int((ek > env).sum()) + int((ef > env).sum()) + int((ee > env).sum())
+    assert bad == 0, (f"{bad} outputs outside the envelope of the oracle modes + 1e-3; max abs err {ek.max():.2e} (kernel-order "
+                      f"oracle) / {ef.max():.2e} (fp32 oracle)")
     long_rows = pr["lengths"] >= 64        # realistic contexts: plain 1e-3 against the exact de-quantisation,
     if long_rows.any():
         _record_parity(f"short_B{B}_H{H}_Hkv{Hkv}_{'kv4' if int4 else 'kv8'}_seed{seed}",
@@ -112,9 +120,14 @@ def run_case(gpu, B, H, Hkv, lengths, int4, seed):
                                        hip=float(o[b_, h_, d_]), oracle=float(ref[b_, h_, d_]), abs_err=float(err[b_, h_, d_]),
                                        fp16_ulps=int(ulps[b_, h_, d_]), hip_vs_exact=float(ee[b_, h_, d_]),
                                        half_fp16_ulp_of_output=float(np.spacing(np.float16(abs(o[b_, h_, d_])))) / 2))
+            if mode == "fp32":                           # ("kernel" was checked above over every row)
+                fnd = sorted((int(b_), int(h_), int(d_)) for b_, h_, d_ in zip(*np.nonzero(beyond)))
+                _check_named_exceptions(case, "fp32", fnd,
+                                        lambda b_, h_, d_: dict(context=int(pr["lengths"][b_]), hip=float(o[b_, h_, d_]),
+                                                                oracle=float(ref_f[b_, h_, d_]), abs_err=float(ef[b_, h_, d_]),
+                                                                fp16_ulps=int(ulps[b_, h_, d_]), hip_vs_exact=float(ee[b_, h_, d_])))
         _PARITY_RECORD[f"short_B{B}_H{H}_Hkv{Hkv}_{'kv4' if int4 else 'kv8'}_seed{seed}"]["beyond_1e-3_and_2ulp"] = exceptions
         _flush_parity()
-        assert len(exceptions) <= 1e-3 * int(long_rows.sum()) * H * 128, f"{len(exceptions)} elements beyond 1e-3 and 2 fp16 ulp"
         assert ek[long_rows].max() <= 2 * TOL and ef[long_rows].max() <= 2 * TOL, "hard ceiling 2e-3"
     return ek.max(), ef.max()
 
@@ -377,6 +390,36 @@ def test_attention_quant_fusion_is_bit_identical_to_the_pair(gpu, B, H, Hkv, L, 
 # three oracle modes into gpurun_out/round4_attention_parity.json (copied to profiles/), then asserts the plain 1e-3.
 # ---------------------------------------------------------------------------------------------------------------------
 _PARITY_RECORD = {}
+_NAMED = None
+_NAMED_FOUND = {}
+
+
+def _check_named_exceptions(case, mode, found, describe):
+    """`found` = [(seq, head, dim)] beyond the contract against oracle mode `mode`: each must be listed by name in
+    tests/golden/attention_parity_exceptions.json.  QS_PARITY_RECORD=1 records instead of asserting (-> gpurun_out/)."""
+    import json
+    import os
+    global _NAMED
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if _NAMED is None:
+        fn = os.path.join(root, "tests", "golden", "attention_parity_exceptions.json")
+        _NAMED = json.load(open(fn))["exceptions"] if os.path.exists(fn) else {}
+    if found:
+        _NAMED_FOUND[f"{case}|{mode}"] = [dict(seq=b_, head=h_, dim=d_, **describe(b_, h_, d_)) for b_, h_, d_ in found]
+        try:
+            os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(root, "gpurun_out", "attention_parity_exceptions.json"), "w") as f:
+                json.dump(dict(contract="per element |HIP - oracle| <= 1e-3 OR <= 2 fp16 ulp; every element beyond it, by case | "
+                                        "oracle mode", exceptions=_NAMED_FOUND), f, indent=1, sort_keys=True)
+        except OSError:
+            pass
+    if os.environ.get("QS_PARITY_RECORD") == "1":
+        return
+    allowed = {(e["seq"], e["head"], e["dim"]) for e in _NAMED.get(f"{case}|{mode}", [])}
+    extra = [x for x in found if x not in allowed]
+    assert not extra, f"{case}: {len(extra)} element(s) beyond 1e-3 and 2 fp16 ulp of the {mode}-order oracle that are not named: {extra[:5]}"
+
+
 
 
 def _flush_parity():
@@ -386,7 +429,7 @@ def _flush_parity():
     d = os.path.join(root, "gpurun_out")
     try:
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "round4_attention_parity.json"), "w") as f:
+        with open(os.path.join(d, "round5_attention_parity.json"), "w") as f:
             json.dump(dict(tolerance=TOL, contract="per element: |HIP - reference-order oracle| <= 1e-3 OR <= 2 fp16 ulp; elements "
                                                    "beyond it are listed by name under beyond_1e-3_and_2ulp (short contexts only)",
                            note="max |HIP fp16 output - oracle| over the sampled sequences x all heads x 128 "

@@ -580,6 +580,93 @@ def test_epilogue_fma_envelope(gpu, N, K):
         pass
 
 
+# qs_set_gemm_epilogue(1): the fmaf form of the per-channel epilogue, in EVERY kernel family: (forced variant, M, N, K)
+EPI_FMA = [(-1, 64, 28672, 4096), (-1, 64, 4096, 14336), (-1, 64, 6144, 4096), (-1, 64, 4096, 4096),     # config-2 shapes (ring)
+           (4221, 40, 256, 2048),                     # ring, K-sliced seam
+           (2000, 50, 192, 512), (2001, 300, 384, 512),   # split-K / LDS-pair kernels
+           (3001, 300, 512, 384), (3002, 513, 1024, 512), (3003, 300, 512, 384)]   # tiled 256 / 128, four-wave tile
+
+
+@pytest.mark.parametrize("variant,M,N,K", EPI_FMA)
+def test_epilogue_fma_convention_selectable(gpu, variant, M, N, K):
+    """The likely CUDA convention of gemm_cuda.cu:586 - fmaf(acc * wscale, ascale, -(w_sz * a_ssum)) - is selectable at run
+    time (qs_set_gemm_epilogue) and then equals oracle.w4a8.epilogue_per_chn(fma=True) BIT FOR BIT, kernel family by kernel
+    family; the default stays the un-contracted evaluation.  gate_up + silu * mul follows the GEMM's convention as well."""
+    import qserve_backend.activation_ops as act
+    import qserve_backend.qgemm_w4a8_per_chn as op
+    from qserve_amd import _lib, fused as fz
+    lib = _lib.lib
+    g = torch.Generator(device=gpu).manual_seed(N + K + M)
+    W = torch.randint(-128, 128, (N, K // 2), dtype=torch.int8, device=gpu, generator=g)
+    A = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=gpu, generator=g)
+    acc = int_matmul_torch(A, unpack_qweight_torch(W)).cpu().numpy().astype(np.int32)
+    r = np.random.default_rng(N + K + M)
+    ws = r.uniform(0.002, 0.02, N).astype(np.float16)
+    wz = (r.integers(0, 16, N).astype(np.float16) * ws).astype(np.float16)
+    sa = r.uniform(0.005, 0.05, M).astype(np.float16)
+    ss = (sa.astype(np.float32) * A.cpu().numpy().astype(np.int64).sum(1).astype(np.float32)).astype(np.float16)
+    want = {0: w4a8.epilogue_per_chn(acc, ws, sa, wz, ss), 1: w4a8.epilogue_per_chn(acc, ws, sa, wz, ss, fma=True)}
+    try:
+        lib.qs_set_gemm_variant(variant)
+        for conv in (1, 0, 1):
+            assert lib.qs_set_gemm_epilogue(conv) == 0 and lib.qs_get_gemm_epilogue() == conv
+            out = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+            op.gemm_forward_cuda(A, W, dev(ws), dev(sa), dev(wz), dev(ss), out)
+            assert np.array_equal(out.cpu().numpy().view(np.uint16), want[conv].view(np.uint16)), (variant, conv)
+            if N % 128 == 0 and variant in (-1, 3001, 3002, 3003):     # the activation epilogue: silu_and_mul of THAT fp16 result
+                pair = torch.empty((M, N // 2), dtype=torch.float16, device=gpu)
+                act.silu_and_mul(pair, out)
+                one = torch.full((M, N // 2), float("nan"), dtype=torch.float16, device=gpu)
+                tmp = torch.empty((M, N), dtype=torch.float16, device=gpu)
+                fz.gemm_silu_and_mul_per_chn(A, W, dev(ws), dev(sa), dev(wz), dev(ss), one, tmp)
+                assert torch.equal(one.view(torch.int16), pair.view(torch.int16)), (variant, conv)
+        assert lib.qs_set_gemm_epilogue(2) == -1
+    finally:
+        lib.qs_set_gemm_epilogue(0)
+        lib.qs_set_gemm_variant(-1)
+    if variant == -1 and (want[0].view(np.uint16) != want[1].view(np.uint16)).sum() == 0:
+        pytest.skip("the two conventions agree on every output of this problem")
+
+
+def test_epilogue_fma_convention_through_the_planes_row_kernel(gpu):
+    """K-slice planes: the row kernel that finishes the GEMM applies the SAME convention as the GEMM launch would have."""
+    import qserve_backend.qgemm_w4a8_per_chn as op
+    from qserve_amd import _lib, fused as fz
+    lib = _lib.lib
+    M, N, K = 64, 4096, 14336
+    g = torch.Generator(device=gpu).manual_seed(77)
+    W = torch.randint(-128, 128, (N, K // 2), dtype=torch.int8, device=gpu, generator=g)
+    A = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=gpu, generator=g)
+    ws = (torch.rand((N,), device=gpu, generator=g) * 0.018 + 0.002).half()
+    wz = (torch.randint(0, 16, (N,), device=gpu, generator=g).half() * ws).half()
+    sa = (torch.rand((M,), device=gpu, generator=g) * 0.045 + 0.005).half()
+    ss = (sa.float() * A.float().sum(1)).half()
+    gamma = (torch.rand((N,), device=gpu, generator=g) + 0.5).half()
+    hid0 = (torch.randn((M, N), device=gpu, generator=g) * 2).half()
+    ks = fz.gemm_planes_plan(M, N, K, False)
+    assert ks >= 1
+    try:
+        res = {}
+        for conv in (0, 1):
+            lib.qs_set_gemm_epilogue(conv)
+            y = torch.empty((M, N), dtype=torch.float16, device=gpu)
+            op.gemm_forward_cuda(A, W, ws, sa, wz, ss, y)
+            h1, q1 = hid0.clone(), torch.empty((M, N), dtype=torch.int8, device=gpu)
+            s1, m1 = torch.empty((M,), dtype=torch.float16, device=gpu), torch.empty((M,), dtype=torch.float16, device=gpu)
+            fz.add_residual_rms_norm_general(q1, h1, y, gamma, s1, 1e-5, input_sum=m1)
+            planes = torch.empty((ks, M, N), dtype=torch.int32, device=gpu)
+            fz.gemm_planes(A, W, planes)
+            h2, q2 = hid0.clone(), torch.empty((M, N), dtype=torch.int8, device=gpu)
+            s2, m2 = torch.empty((M,), dtype=torch.float16, device=gpu), torch.empty((M,), dtype=torch.float16, device=gpu)
+            fz.add_residual_rms_norm_general_planes(q2, h2, planes, ws, sa, gamma, s2, 1e-5, w_szs=wz, a_ssums=ss, input_sum=m2)
+            assert torch.equal(h1.view(torch.int16), h2.view(torch.int16)) and torch.equal(q1, q2), conv
+            assert torch.equal(s1.view(torch.int16), s2.view(torch.int16)) and torch.equal(m1.view(torch.int16), m2.view(torch.int16))
+            res[conv] = y.clone()
+        assert not torch.equal(res[0].view(torch.int16), res[1].view(torch.int16)), "the conventions should differ somewhere here"
+    finally:
+        lib.qs_set_gemm_epilogue(0)
+
+
 def _float_reference(A, sa, Wdeq):
     """A_deq . W_deq^T in float64: what the quantised GEMM approximates (SURVEY 8d config 1 "plumbing" reference)."""
     return (A.astype(np.float64) * sa.astype(np.float64)[:, None]) @ Wdeq.T
