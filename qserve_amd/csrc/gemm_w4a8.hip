@@ -615,6 +615,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
 
 extern int g_tiled_dbg;   // gemm_w4a8_tiled.hip: timing experiments (3100 + bits)
 extern int g_wide_order;  // gemm_w4a8_wide.hip: the same switch for the four-wave kernel
+extern int g_wide_dbg;    // gemm_w4a8_wide.hip: timing experiments (3400 + bits; QS_TIMING builds only)
 extern int g_ring_flags;  // gemm_w4a8_ring.hip: A/B switches of the decode kernel (5000 + bits), results unchanged
 extern int g_act_off;
 extern "C" void qs_set_gemm_variant(int variant) {
@@ -625,6 +626,10 @@ extern "C" void qs_set_gemm_variant(int variant) {
     if (variant >= 3200 && variant < 3300) {
         g_tiled_order = variant - 3200;
         g_wide_order = (variant - 3200) % 10;
+        return;
+    }
+    if (variant >= 3400 && variant < 3500) {
+        g_wide_dbg = variant - 3400;
         return;
     }
     if (variant == 3300 || variant == 3301) {

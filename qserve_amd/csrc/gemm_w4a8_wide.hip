@@ -24,6 +24,8 @@
 #include <utility>
 
 int g_wide_order = 0;  // tile order A/B (same meaning as g_tiled_order % 10)
+int g_wide_dbg = 0;    // QS_TIMING builds only (qs_set_gemm_variant(3400 + bits), results WRONG by design): 1 no MFMA, 2 no DMA,
+                       // 4 no activation operand reads, 8 no barrier, 16 no weight reads / unpack
 
 namespace {
 
@@ -91,7 +93,7 @@ __device__ __forceinline__ v4i acc_read() {
     return (v4i){x0, x1, x2, x3};
 }
 
-template <int MODE, int OUTK>
+template <int MODE, int OUTK, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void w4a8_gemm_wide(const int8_t* __restrict__ A, const uint8_t* __restrict__ W,
                                                          const int8_t* __restrict__ zeros,
                                                          const int8_t* __restrict__ scales8,
@@ -289,24 +291,28 @@ __global__ __launch_bounds__(256, 1) void w4a8_gemm_wide(const int8_t* __restric
         static_for<MT>([&](auto mt_c) {
             constexpr int mt = decltype(mt_c)::value;
             const v4i b_use = bq[mt % PD];
-            mfma_acc<(4 * mt + 0) * 4, FIRST>(ac[0], b_use);
-            if constexpr (mt + PD < MT) bq[mt % PD] = read_b(ps, PAR, mt + PD);
-            else bq[mt % PD] = read_b(ps_n, PAR ^ 1, mt + PD - MT);
-            mfma_acc<(4 * mt + 1) * 4, FIRST>(ac[1], b_use);
-            if constexpr (mt == 0) qn = read_w(slot_n);
-            if constexpr (PAR == 0 && mt < NA2) {
-                if (st || pref_a) issue_a((u >> 1) + 2, ps_d, mt);
-            } else if constexpr (mt - (PAR == 0 ? NA2 : 0) < NW) {
-                if (st || pref_w) issue_w(u + NS - 1, slot_d, mt - (PAR == 0 ? NA2 : 0));
+            if constexpr (!(DBG & 1)) mfma_acc<(4 * mt + 0) * 4, FIRST>(ac[0], b_use);
+            if constexpr (!(DBG & 4)) {
+                if constexpr (mt + PD < MT) bq[mt % PD] = read_b(ps, PAR, mt + PD);
+                else bq[mt % PD] = read_b(ps_n, PAR ^ 1, mt + PD - MT);
             }
-            mfma_acc<(4 * mt + 2) * 4, FIRST>(ac[2], b_use);
-            if constexpr (mt >= 4 && mt < 8) {
+            if constexpr (!(DBG & 1)) mfma_acc<(4 * mt + 1) * 4, FIRST>(ac[1], b_use);
+            if constexpr (mt == 0 && !(DBG & 16)) qn = read_w(slot_n);
+            if constexpr (!(DBG & 2)) {
+                if constexpr (PAR == 0 && mt < NA2) {
+                    if (st || pref_a) issue_a((u >> 1) + 2, ps_d, mt);
+                } else if constexpr (mt - (PAR == 0 ? NA2 : 0) < NW) {
+                    if (st || pref_w) issue_w(u + NS - 1, slot_d, mt - (PAR == 0 ? NA2 : 0));
+                }
+            }
+            if constexpr (!(DBG & 1)) mfma_acc<(4 * mt + 2) * 4, FIRST>(ac[2], b_use);
+            if constexpr (mt >= 4 && mt < 8 && !(DBG & 16)) {
                 an[mt - 4] = build(qn, mt - 4);
                 // pinned HERE: left alone, the compiler sinks the unpack into the block of its first use (the stages with run-time
                 // prefetch conditions have several) - straight in front of the asm MFMA that reads it, which nothing pads
                 asm volatile("" : "+v"(an[mt - 4]));
             }
-            mfma_acc<(4 * mt + 3) * 4, FIRST>(ac[3], b_use);
+            if constexpr (!(DBG & 1)) mfma_acc<(4 * mt + 3) * 4, FIRST>(ac[3], b_use);
             QS_PIN();
         });
     };
@@ -314,12 +320,18 @@ __global__ __launch_bounds__(256, 1) void w4a8_gemm_wide(const int8_t* __restric
     using c1 = std::integral_constant<int, 1>;
     int tile = blockIdx.x;
     setup(tile);
-    issue_fill();
+    if (!(DBG & 2)) issue_fill();
     bool first = true;
+    auto stage_sync = [&](int n_static, int v) {       // counted wait + barrier in front of stage v (n_static < 0: by formula)
+        if (DBG & 2) wait_vm<0>();
+        else if (n_static >= 0) wait_vm<3 * NW + NA2>();
+        else wait_vm_dyn(allowed(v));
+        if (!(DBG & 8)) raw_barrier();
+    };
     while (true) {
         // first tile: W(0), A(0), W(1) have landed, the rest of the fill stays in flight.  Later tiles: the fill was issued
         // before the previous tile's epilogue - everything (its stores included) is complete
-        if (first) wait_vm_dyn(allowed(0));
+        if (first && !(DBG & 2)) wait_vm_dyn(allowed(0));
         else wait_vm<0>();
         first = false;
         raw_barrier();
@@ -336,28 +348,23 @@ __global__ __launch_bounds__(256, 1) void w4a8_gemm_wide(const int8_t* __restric
         // the tile's first pair: stage 0 writes the accumulators (A x B + 0); prefetch conditions evaluated (nh may be small)
         stage(c0{}, std::true_type{}, std::false_type{}, 4 < nh, NS - 1 < nh, 0, slot, a0, a1);
         slot = 1;
-        wait_vm_dyn(allowed(1));
-        raw_barrier();
+        stage_sync(-1, 1);
         stage(c1{}, std::false_type{}, std::false_type{}, false, NS < nh, 1, slot, a1, a0);
         slot = 2;
         int u = 2;
         for (; u + NS < nh; u += 2) {                  // steady state: both stages of the pair prefetch, no branches
-            wait_vm<3 * NW + NA2>();
-            raw_barrier();
+            stage_sync(0, u);
             stage(c0{}, std::false_type{}, std::true_type{}, true, true, u, slot, a0, a1);
             slot = slot + 1 == NS ? 0 : slot + 1;
-            wait_vm<3 * NW + NA2>();
-            raw_barrier();
+            stage_sync(0, u + 1);
             stage(c1{}, std::false_type{}, std::true_type{}, true, true, u + 1, slot, a1, a0);
             slot = slot + 1 == NS ? 0 : slot + 1;
         }
         for (; u < nh; u += 2) {                       // drain
-            wait_vm_dyn(allowed(u));
-            raw_barrier();
+            stage_sync(-1, u);
             stage(c0{}, std::false_type{}, std::false_type{}, u + 4 < nh, u + NS - 1 < nh, u, slot, a0, a1);
             slot = slot + 1 == NS ? 0 : slot + 1;
-            wait_vm_dyn(allowed(u + 1));
-            raw_barrier();
+            stage_sync(-1, u + 1);
             stage(c1{}, std::false_type{}, std::false_type{}, false, u + NS < nh, u + 1, slot, a1, a0);
             slot = slot + 1 == NS ? 0 : slot + 1;
         }
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void w4a8_gemm_wide(const int8_t* __restric
         raw_barrier();                                 // the rings are dead: every wave left the k loop
         if (next < ntiles) {                           // next tile's fill: pair slots 0, 1 and weight slots 0..4
             setup(next);
-            issue_fill();
+            if (!(DBG & 2)) issue_fill();
         }
         // The fp16 tile of this wave goes through LDS, 16 tokens x 64 channels at a time (whole 128-byte rows per store
         // instruction).  The staging rows live in activation pair slot 2, which the fill does not touch; written and read by
@@ -475,11 +482,11 @@ __global__ __launch_bounds__(256, 1) void w4a8_gemm_wide(const int8_t* __restric
     }
 }
 
-template <int MODE, int OUTK>
+template <int MODE, int OUTK, int DBG = 0>
 int launch_wide(const int8_t* A, const uint8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales,
                 const void* ascales, const void* wszs, const void* assums, void* out, int M, int N, int K, int persist_mode,
                 hipStream_t stream) {
-    auto kern = w4a8_gemm_wide<MODE, OUTK>;
+    auto kern = w4a8_gemm_wide<MODE, OUTK, DBG>;
     const size_t smem = (size_t)NS * (BM * 64 + WSTAGE + 512);   // (the epilogue's staging rows alias activation pair slot 2)
     static bool configured_dev[QS_MAX_DEVICES] = {};   // the attribute belongs to the (kernel, device) pair
     bool& configured = configured_dev[qs_device_slot()];
@@ -520,6 +527,16 @@ int qs_launch_gemm_wide(int mode, int outk, const int8_t* A, const uint8_t* W, c
     }
 #define QS_T(MODEV, OUTV) \
     return launch_wide<MODEV, OUTV>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, persist_mode, stream)
+#ifdef QS_TIMING   // timing experiments (results are wrong by design): not in the shipped library
+    if (mode == 0 && outk == 0 && g_wide_dbg) {
+#define QS_D(D) case D: return launch_wide<0, 0, D>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, persist_mode, stream)
+        switch (g_wide_dbg) {
+            QS_D(1); QS_D(2); QS_D(4); QS_D(8); QS_D(16); QS_D(20); QS_D(6); QS_D(22); QS_D(30);
+        default: break;
+        }
+#undef QS_D
+    }
+#endif
     if (mode == 0 && outk == 2) QS_T(0, 2);
     if (mode == 1 && outk == 2) QS_T(1, 2);
     if (mode == 0 && outk == 0) QS_T(0, 0);
