@@ -188,6 +188,16 @@ __global__ __launch_bounds__(256, 1) void w4a8_gemm_wide(const int8_t* __restric
     };
     const u32 lds0 = (u32)(size_t)(lptr_t)smem;
 
+    // ---- DMA issue -----------------------------------------------------------------------------------------------------
+    // LDS destinations = a per-wave scalar base + a COMPILE-TIME offset wherever the ring slot is a compile-time constant (the
+    // steady state is unrolled over the six slots): `s_add_u32 m0, base, imm` replaces the address arithmetic + s_mov, and the
+    // wait state M0 needs before the LDS-DMA is an MFMA of the stream instead of an s_nop (mfma_dma: both live in ONE asm
+    // statement - M0 is not preserved between statements).  Round-5 ablation (profiles/round5_wide_ablation.txt): the first
+    // version of this kernel spent 126 non-MFMA instructions per 64 MFMAs, 40 of them on ten DMA issues, and ran at the
+    // eight-wave tile's speed; one wave per SIMD hides about one instruction per MFMA, every further one costs 4-5 cycles.
+    const u32 lds_a = lds0 + wave * 1024;                                          // + pslot*APAIR + i*4096
+    const u32 lds_w = lds0 + (NS / 2) * APAIR + wave * 2048;                       // + slot*WSTAGE + i*1024
+    const u32 lds_m = lds0 + (NS / 2) * APAIR + NS * WSTAGE + (wave & 1) * 256;    // + slot*512
     auto dma16 = [&](u32 voff, const void* sbase, u32 lds_addr) {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
                      : "memory");
@@ -196,12 +206,15 @@ __global__ __launch_bounds__(256, 1) void w4a8_gemm_wide(const int8_t* __restric
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
                      : "memory");
     };
+    auto a_src = [&](int pr) { return static_cast<const void*>(A + (size_t)pr * 128); };
+    auto w_src = [&](int u) { return static_cast<const void*>(w_base + (size_t)u * 1024); };
+    auto m_src = [&](int u) { return static_cast<const void*>(m_base + (size_t)(u >> 1) * N); };
     auto issue_a = [&](int pr, int pslot, int i) {                 // instruction i of activation pair pr (stages 2pr, 2pr+1)
-        dma16(a_off[i], A + (size_t)pr * 128, lds0 + pslot * APAIR + (i * 4 + wave) * 1024);
+        dma16(a_off[i], a_src(pr), lds_a + pslot * APAIR + i * 4096);
     };
     auto issue_w = [&](int u, int slot, int i) {                   // i = 0, 1: weight pieces of stage u, 2: its per-group meta
-        if (i < 2) dma16(w_off[i], w_base + (size_t)u * 1024, lds0 + (NS / 2) * APAIR + slot * WSTAGE + wave * 2048 + i * 1024);
-        else dma4(m_off, m_base + (size_t)(u >> 1) * N, lds0 + (NS / 2) * APAIR + NS * WSTAGE + slot * 512 + (wave & 1) * 256);
+        if (i < 2) dma16(w_off[i], w_src(u), lds_w + slot * WSTAGE + i * 1024);
+        else dma4(m_off, m_src(u), lds_m + slot * 512);
     };
     // issue order of a wave and what a stage needs: gemm_w4a8_tiled.hip (`allowed`), with NW / NA2 of this geometry
     auto allowed = [&](int v) {
@@ -216,8 +229,11 @@ __global__ __launch_bounds__(256, 1) void w4a8_gemm_wide(const int8_t* __restric
     const int m_rd = wave * 64 + (tsel * 8 + c) * 4;
     const int a_rd0 = (li >> 3) * 1024 + (4 * ((li & 7) >> 1) + 2 * ((li >> 1) & 1) + (li & 1)) * 64 +
                       ((g ^ aswz(li >> 2)) * 16);                                                    // half 0; + mt*2048
+    // two base registers (one per k half of a pair); pair slot and m-tile are immediates of the read wherever they are
+    // compile-time constants
+    const uint8_t* const a_rd_p[2] = {a_ring + a_rd0, a_ring + (a_rd0 ^ 128)};
     auto read_b = [&](int pslot, int half, int mt) -> v4i {
-        return *reinterpret_cast<const v4i*>(a_ring + pslot * APAIR + (a_rd0 ^ (half * 128)) + mt * 2048);
+        return *reinterpret_cast<const v4i*>(a_rd_p[half] + pslot * APAIR + mt * 2048);
     };
     struct Raw {
         v2u r[4];
@@ -241,22 +257,24 @@ __global__ __launch_bounds__(256, 1) void w4a8_gemm_wide(const int8_t* __restric
         }
         return q;
     };
-    auto build = [&](const Raw& q, int cl) -> v4i {
+    auto build1 = [&](const Raw& q, int cl, int e) -> int {      // register e (4 k) of row class cl
         u32 s = 0, zb = 0;
         if (MODE == 1) {
             s = (q.sdw >> (8 * cl)) & 0xFFu;
             zb = ((q.zdw >> (8 * cl)) & 0xFFu) * 0x01010101u;
         }
+        const u32 raw = (cl & 1) ? q.r[e].y : q.r[e].x;
+        return (int)((cl & 2) ? unpack_hi<MODE>(raw, s, zb) : unpack_lo<MODE>(raw, s, zb));
+    };
+    auto build = [&](const Raw& q, int cl) -> v4i {
         v4i a;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const u32 raw = (cl & 1) ? q.r[e].y : q.r[e].x;
-            a[e] = (int)((cl & 2) ? unpack_hi<MODE>(raw, s, zb) : unpack_lo<MODE>(raw, s, zb));
-        }
+        for (int e = 0; e < 4; ++e) a[e] = build1(q, cl, e);
         return a;
     };
 
-    v4i a0[4], a1[4], bq[PD];
+    constexpr int NB = 8;                             // activation operand buffers (tile t lives in bq[t % NB]; NB divides MT)
+    v4i a0[4], a1[4], bq[NB];
 
     auto issue_fill = [&]() {
 #pragma unroll
@@ -274,43 +292,96 @@ __global__ __launch_bounds__(256, 1) void w4a8_gemm_wide(const int8_t* __restric
         }
     };
 
-    // One stage = 64 MFMAs of this wave (16 m-tiles x 4 row classes).  `ac`: unpacked weight operands of stage u, `an` receives
-    // those of stage u+1 (raw words read at mt = 0, one row class built per m-tile at mt = 4 .. 7 - late enough for the LDS data
-    // to be there without a wait, a whole half stage before the first use); bq: rolling activation operands, PD m-tiles ahead.
-    // Source order inside an m-tile: MFMA | operand read | MFMA | DMA issue or raw weight reads | MFMA | unpack slice | MFMA.
-    auto stage = [&](auto par_c, auto first_c, auto pref_static, bool pref_a, bool pref_w, int u, int slot, v4i(&ac)[4],
-                     v4i(&an)[4]) {
+    // One stage = 64 MFMAs of this wave (16 m-tiles x 4 row classes) with, in source order (memory operations and asm statements
+    // keep it through the compiler), per m-tile mt:
+    //     MFMA cl 0 | activation operand reads: at EVEN mt the tiles mt + 5, mt + 4 (in that order: the wait for the second covers
+    //     the first, so the compiler waits once per pair) | MFMA cl 1 - with this m-tile's DMA issue wrapped around it (PAR 0:
+    //     activation pieces at mt 0 .. 7, weights / meta of stage u + 5 at mt 8 .. 10; PAR 1: weights at mt 0 .. 2) | raw weight
+    //     words of stage u + 1 (mt 4) or half a row class of its unpack / level-2 dequant (mt 8 .. 15: class (mt - 8) / 2,
+    //     registers 2 (mt & 1), + 1) | MFMA cl 2 | MFMA cl 3.
+    // slot_c: the ring slot as a compile-time constant (the unrolled steady state) or a run-time int (first pair, drain).
+    auto stage = [&](auto par_c, auto first_c, auto pref_static, auto slot_c, bool pref_a, bool pref_w, int u, v4i(&ac)[4],
+                     v4i(&an)[4], Raw& qn) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool FIRST = decltype(first_c)::value;
         constexpr bool st = decltype(pref_static)::value;
+        constexpr bool SLOT_CT = !std::is_same<decltype(slot_c), int>::value;
+        const int slot = slot_c;
         const int slot_n = slot + 1 == NS ? 0 : slot + 1;
         const int slot_d = slot == 0 ? NS - 1 : slot - 1;          // (u + NS - 1) % NS
         const int ps = slot >> 1, ps_n = slot_n >> 1;              // activation pair slots of stage u / u+1
         const int ps_d = ps == 0 ? NS / 2 - 1 : ps - 1;            // (u/2 + 2) % (NS/2)
-        Raw qn;
         static_for<MT>([&](auto mt_c) {
             constexpr int mt = decltype(mt_c)::value;
-            const v4i b_use = bq[mt % PD];
+            const v4i b_use = bq[mt % NB];
             if constexpr (!(DBG & 1)) mfma_acc<(4 * mt + 0) * 4, FIRST>(ac[0], b_use);
-            if constexpr (!(DBG & 4)) {
-                if constexpr (mt + PD < MT) bq[mt % PD] = read_b(ps, PAR, mt + PD);
-                else bq[mt % PD] = read_b(ps_n, PAR ^ 1, mt + PD - MT);
-            }
-            if constexpr (!(DBG & 1)) mfma_acc<(4 * mt + 1) * 4, FIRST>(ac[1], b_use);
-            if constexpr (mt == 0 && !(DBG & 16)) qn = read_w(slot_n);
-            if constexpr (!(DBG & 2)) {
-                if constexpr (PAR == 0 && mt < NA2) {
-                    if (st || pref_a) issue_a((u >> 1) + 2, ps_d, mt);
-                } else if constexpr (mt - (PAR == 0 ? NA2 : 0) < NW) {
-                    if (st || pref_w) issue_w(u + NS - 1, slot_d, mt - (PAR == 0 ? NA2 : 0));
+            if constexpr (!(DBG & 4) && mt % 2 == 0) {
+#pragma unroll
+                for (int t = mt + 5; t >= mt + 4; --t) {
+                    if (t < MT) bq[t % NB] = read_b(ps, PAR, t);
+                    else bq[t % NB] = read_b(ps_n, PAR ^ 1, t - MT);
                 }
             }
+            // this m-tile's DMA, wrapped around MFMA cl 1
+            constexpr int di = mt - (PAR == 0 ? NA2 : 0);          // weight / meta instruction index of this m-tile
+            constexpr bool is_a = PAR == 0 && mt < NA2;
+            constexpr bool is_w = !is_a && di >= 0 && di < NW;
+            bool fused = false;
+            if constexpr (!(DBG & 2) && !(DBG & 1) && (is_a || is_w)) {
+                if (st || (is_a ? pref_a : pref_w)) {
+                    fused = true;
+                    const u32 voff = is_a ? a_off[is_a ? mt : 0] : (di < 2 ? w_off[di < 2 ? (di < 0 ? 0 : di) : 0] : m_off);
+                    const void* const src = is_a ? a_src((u >> 1) + 2) : (di < 2 ? w_src(u + NS - 1) : m_src(u + NS - 1));
+                    const u32 lbase = is_a ? lds_a : (di < 2 ? lds_w : lds_m);
+                    const int loff = is_a ? ps_d * APAIR + mt * 4096 : (di < 2 ? slot_d * WSTAGE + di * 1024 : slot_d * 512);
+                    // m0 = LDS destination (scalar base + compile-time offset where the slot is a compile-time constant) | the MFMA
+                    // (= the wait state M0 needs) | the LDS-DMA
+#define QS_MFMA_DMA(LOADOP, CARG, LB, LO)                                                                                         \
+    asm volatile("s_add_u32 m0, %4, %5\n\tv_mfma_i32_16x16x64_i8 a[%c0:%c1], %2, %3, " CARG "\n\t" LOADOP " %6, %7" ::"n"((4 * mt + 1) * 4), \
+                 "n"((4 * mt + 1) * 4 + 3), "v"(ac[1]), "v"(b_use), "s"(LB), "n"(LO), "v"(voff), "s"(src)                          \
+                 : "memory", "scc")
+#define QS_MFMA_DMA_F(LOADOP, LB, LO)                                          \
+    do {                                                                       \
+        if constexpr (FIRST) QS_MFMA_DMA(LOADOP, "0", LB, LO);                 \
+        else QS_MFMA_DMA(LOADOP, "a[%c0:%c1]", LB, LO);                        \
+    } while (0)
+                    if constexpr (SLOT_CT) {
+                        constexpr int S = decltype(slot_c)::value, SD = S == 0 ? NS - 1 : S - 1, PSD = (S >> 1) == 0 ? NS / 2 - 1 : (S >> 1) - 1;
+                        constexpr int LOFF = is_a ? PSD * APAIR + mt * 4096 : (di < 2 ? SD * WSTAGE + di * 1024 : SD * 512);
+                        if constexpr (is_a || di < 2) QS_MFMA_DMA_F("global_load_lds_dwordx4", lbase, LOFF);
+                        else QS_MFMA_DMA_F("global_load_lds_dword", lbase, LOFF);
+                    } else {
+                        const u32 laddr = lbase + loff;
+                        if constexpr (is_a || di < 2) QS_MFMA_DMA_F("global_load_lds_dwordx4", laddr, 0);
+                        else QS_MFMA_DMA_F("global_load_lds_dword", laddr, 0);
+                    }
+#undef QS_MFMA_DMA_F
+#undef QS_MFMA_DMA
+                }
+            }
+            if constexpr (DBG & 1) {                                   // (timing build without MFMAs: plain DMA issue)
+                if constexpr (!(DBG & 2) && (is_a || is_w)) {
+                    if (st || (is_a ? pref_a : pref_w)) {
+                        if constexpr (is_a) issue_a((u >> 1) + 2, ps_d, mt);
+                        else issue_w(u + NS - 1, slot_d, di < 0 ? 0 : di);
+                    }
+                }
+            } else {
+                if (!fused) mfma_acc<(4 * mt + 1) * 4, FIRST>(ac[1], b_use);
+            }
+            if constexpr (mt == 4 && !(DBG & 16)) qn = read_w(slot_n);
+            if constexpr (mt >= 8 && !(DBG & 16)) {
+                constexpr int cl = (mt - 8) / 2, e0 = 2 * (mt & 1);
+                // pinned HERE (asm with the value as in-out operand): left alone, the compiler sinks the unpack into the block of
+                // its first use - straight in front of the asm MFMA that reads it, where nothing pads the VALU -> MFMA hazard
+                an[cl][e0] = build1(qn, cl, e0);
+                asm volatile("" : "+v"(an[cl][e0]));
+            }
             if constexpr (!(DBG & 1)) mfma_acc<(4 * mt + 2) * 4, FIRST>(ac[2], b_use);
-            if constexpr (mt >= 4 && mt < 8 && !(DBG & 16)) {
-                an[mt - 4] = build(qn, mt - 4);
-                // pinned HERE: left alone, the compiler sinks the unpack into the block of its first use (the stages with run-time
-                // prefetch conditions have several) - straight in front of the asm MFMA that reads it, which nothing pads
-                asm volatile("" : "+v"(an[mt - 4]));
+            if constexpr (mt >= 8 && !(DBG & 16)) {
+                constexpr int cl = (mt - 8) / 2, e1 = 2 * (mt & 1) + 1;
+                an[cl][e1] = build1(qn, cl, e1);
+                asm volatile("" : "+v"(an[cl][e1]));
             }
             if constexpr (!(DBG & 1)) mfma_acc<(4 * mt + 3) * 4, FIRST>(ac[3], b_use);
             QS_PIN();
@@ -328,6 +399,7 @@ __global__ __launch_bounds__(256, 1) void w4a8_gemm_wide(const int8_t* __restric
         else wait_vm_dyn(allowed(v));
         if (!(DBG & 8)) raw_barrier();
     };
+    Raw qraw;                                          // raw weight words of the next stage (read at mt 4, unpacked at mt 8 .. 15)
     while (true) {
         // first tile: W(0), A(0), W(1) have landed, the rest of the fill stays in flight.  Later tiles: the fill was issued
         // before the previous tile's epilogue - everything (its stores included) is complete
@@ -338,34 +410,43 @@ __global__ __launch_bounds__(256, 1) void w4a8_gemm_wide(const int8_t* __restric
         {
             const Raw q0 = read_w(0);
 #pragma unroll
-            for (int t = 0; t < PD; ++t) bq[t] = read_b(0, 0, t);
+            for (int t = 0; t < 4; ++t) bq[t] = read_b(0, 0, t);
 #pragma unroll
             for (int cl = 0; cl < 4; ++cl) a0[cl] = build(q0, cl);
             // a VALU result needs two wait states before an MFMA reads it as a source operand; nothing pads that for an asm MFMA
             asm volatile("s_nop 1" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]));
         }
-        int slot = 0;
         // the tile's first pair: stage 0 writes the accumulators (A x B + 0); prefetch conditions evaluated (nh may be small)
-        stage(c0{}, std::true_type{}, std::false_type{}, 4 < nh, NS - 1 < nh, 0, slot, a0, a1);
-        slot = 1;
+        stage(c0{}, std::true_type{}, std::false_type{}, 0, 4 < nh, NS - 1 < nh, 0, a0, a1, qraw);
         stage_sync(-1, 1);
-        stage(c1{}, std::false_type{}, std::false_type{}, false, NS < nh, 1, slot, a1, a0);
-        slot = 2;
+        stage(c1{}, std::false_type{}, std::false_type{}, 1, false, NS < nh, 1, a1, a0, qraw);
         int u = 2;
-        for (; u + NS < nh; u += 2) {                  // steady state: both stages of the pair prefetch, no branches
+        // steady state, unrolled over the six ring slots (u = 2 (mod 6) here: slots 2, 3, 4, 5, 0, 1): every LDS address of
+        // the stage is an immediate; every stage of the block prefetches (u + 5 + 5 < nh)
+        for (; u + 11 <= nh; u += 6) {
+            static_for<6>([&](auto k_c) {
+                constexpr int k = decltype(k_c)::value;
+                constexpr int S = (2 + k) % NS;
+                stage_sync(0, u + k);
+                if constexpr (k % 2 == 0) stage(c0{}, std::false_type{}, std::true_type{}, std::integral_constant<int, S>{}, true, true, u + k, a0, a1, qraw);
+                else stage(c1{}, std::false_type{}, std::true_type{}, std::integral_constant<int, S>{}, true, true, u + k, a1, a0, qraw);
+            });
+        }
+        int slot = 2;                                  // (u = 2 (mod 6) again)
+        for (; u + NS < nh; u += 2) {                  // the last full-prefetch pairs, run-time slot
             stage_sync(0, u);
-            stage(c0{}, std::false_type{}, std::true_type{}, true, true, u, slot, a0, a1);
+            stage(c0{}, std::false_type{}, std::true_type{}, slot, true, true, u, a0, a1, qraw);
             slot = slot + 1 == NS ? 0 : slot + 1;
             stage_sync(0, u + 1);
-            stage(c1{}, std::false_type{}, std::true_type{}, true, true, u + 1, slot, a1, a0);
+            stage(c1{}, std::false_type{}, std::true_type{}, slot, true, true, u + 1, a1, a0, qraw);
             slot = slot + 1 == NS ? 0 : slot + 1;
         }
         for (; u < nh; u += 2) {                       // drain
             stage_sync(-1, u);
-            stage(c0{}, std::false_type{}, std::false_type{}, u + 4 < nh, u + NS - 1 < nh, u, slot, a0, a1);
+            stage(c0{}, std::false_type{}, std::false_type{}, slot, u + 4 < nh, u + NS - 1 < nh, u, a0, a1, qraw);
             slot = slot + 1 == NS ? 0 : slot + 1;
             stage_sync(-1, u + 1);
-            stage(c1{}, std::false_type{}, std::false_type{}, false, u + NS < nh, u + 1, slot, a1, a0);
+            stage(c1{}, std::false_type{}, std::false_type{}, slot, false, u + NS < nh, u + 1, a1, a0, qraw);
             slot = slot + 1 == NS ? 0 : slot + 1;
         }
 

@@ -135,7 +135,8 @@ def test_wide_gemm_owns_the_accumulator_file(asm):
     the whole accumulator file and leave 256 VGPRs' worth of room for it, (b) never touch an accumulator register itself (a spill
     into the file or a v_accvgpr_* of its own would be silent corruption), (c) never write an MFMA source operand with a VALU
     instruction fewer than two instructions ahead of the MFMA (inside an asm statement nothing pads that hazard), and every stage
-    instantiation must contain its 64 MFMAs."""
+    instantiation must contain its 64 MFMAs.  The hazard rule also covers the MFMA that sits INSIDE a DMA statement behind the
+    s_add_u32 that sets M0 (an SALU instruction: no VGPR hazard)."""
     text = asm["gemm_w4a8_wide"]
     ks = {n: b for n, b in kernels(text).items() if "w4a8_gemm_wide" in n}
     assert len(ks) == 6
@@ -144,7 +145,9 @@ def test_wide_gemm_owns_the_accumulator_file(asm):
         assert meta(text, name, "NumVgprs") <= 200, name
         ins = _instructions(body)
         mf = [i for i, (op, _, _) in enumerate(ins) if op.startswith("v_mfma")]
-        assert len(mf) % 64 == 0 and len(mf) >= 6 * 64, f"{name}: {len(mf)} MFMAs"
+        # 12 stage instantiations (first pair, six unrolled slots, run-time-slot pair, drain pair) of 64 MFMAs; the stages with
+        # run-time prefetch conditions carry the MFMA of a DMA m-tile twice (wrapped into the DMA statement / plain)
+        assert 12 * 64 <= len(mf) <= 12 * 64 + 6 * 11, f"{name}: {len(mf)} MFMAs"
         for i, (op, args, inside) in enumerate(ins):
             if not inside:
                 assert not op.startswith("v_accvgpr") and not re.search(r"\ba\[?\d", args), \
