@@ -443,9 +443,11 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
             if (M >= 192 && ((M + 255) / 256) * nb >= 192) tmt = 8;
             else if (M >= 256 && ((M + 127) / 128) * nb >= (MODE == 0 ? 96 : 192)) tmt = 4;
         }
-        // 256-token tiles: the four-wave kernel (gemm_w4a8_wide.hip; round 5) unless variant 3001 asks for the eight-wave one
-        // (A/B, tests); 3003 forces it for any M
-        if (tmt == 8 && g_variant != 3001)
+        // 256-token tiles, PER-GROUP: the four-wave kernel (gemm_w4a8_wide.hip; round 5) - one level-2 dequant per weight byte for
+        // 256 tokens instead of two: +10 ... 18 % in-run (profiles/round5_wide_ab.txt: 4096^3 70.2 -> 64.0 us, 8192 x 4096 x 14336
+        // 436 -> 369 us).  Per-channel the two tiles measure the same within +-3 % (both ~3.2 POPS marginal): the eight-wave one
+        // stays.  Variant 3003 forces the four-wave tile for any problem, 3001 the eight-wave one (A/B, tests).
+        if (tmt == 8 && (g_variant == 3003 || (MODE == 1 && g_variant != 3001)))
             return qs_launch_gemm_wide(MODE, outk, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,
                                        g_tiled_order / 10, stream);
         if (tmt)

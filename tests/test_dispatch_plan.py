@@ -31,10 +31,12 @@ def test_small_batches_keep_whole_tokens_per_workgroup():
 
 
 def test_compute_bound_shapes_take_the_tiled_kernel():
-    # 256-token tiles: the four-wave kernel of round 5 (gemm_w4a8_wide.hip); variant 3001 keeps the eight-wave one reachable
-    assert gemm_plan(4096, 4096, 4096) == dict(family="wide", tile_tokens=256)        # configs[0]
-    assert gemm_plan(65536, 28672, 4096) == dict(family="wide", tile_tokens=256)      # prefill gate_up
+    assert gemm_plan(4096, 4096, 4096) == dict(family="tiled", tile_tokens=256)       # configs[0]
+    assert gemm_plan(65536, 28672, 4096) == dict(family="tiled", tile_tokens=256)     # prefill gate_up
+    # per-group, 256-token tiles: the four-wave kernel of round 5 (gemm_w4a8_wide.hip: one level-2 dequant per weight byte for 256
+    # tokens); per-channel the two tiles measure the same and the eight-wave one stays
     assert gemm_plan(4096, 4096, 4096, per_group=True) == dict(family="wide", tile_tokens=256)
+    assert gemm_plan(65536, 28672, 4096, per_group=True) == dict(family="wide", tile_tokens=256)
     assert gemm_plan(1024, 4096, 4096) == dict(family="tiled", tile_tokens=128)
     assert gemm_plan(512, 3584, 4096)["family"] == "ring"                              # too few tiles: ring 64 x 128
 
@@ -44,7 +46,7 @@ def test_tiled_kernel_needs_real_tokens():
     for N in (49152, 57344, 65536):                          # one round of four-unit workgroups instead of 1.5-2 of two-unit ones
         assert gemm_plan(64, N, 8192) == ring(4, 4, 1)          # (measured 48.9 vs 58.4 us at N = 49152, 55.1 vs 66.1 at 57344)
     assert gemm_plan(191, 57344, 8192)["family"] == "ring"
-    assert gemm_plan(192, 57344, 8192) == dict(family="wide", tile_tokens=256)
+    assert gemm_plan(192, 57344, 8192) == dict(family="tiled", tile_tokens=256)
 
 
 def test_k_slices_only_for_under_filled_grids():
