@@ -249,6 +249,8 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
     // 14 % of the launch).  Layout: [w scale: 64 WN halfs | w scale*zero: 64 WN halfs | token scale: 64 x 4-byte slots | token
     // sum: 64 slots]; local channel = 64 wn + 32 t + ... (ACT: the 32 WN gate channels, then the 32 WN up channels).
     uint8_t* const s_sc = smem + SC_OFF;
+    constexpr int TSL = MT > 4 ? 512 : 256;           // bytes of one staged token vector (4-byte slots)
+    static_assert(4 * 64 * WN + 2 * TSL <= SC_BYTES, "epilogue operand staging area");
     if ((OUTK == 0 || OUTK == 2) && wave == 0) {
         const u32 sc_lds = (u32)(size_t)(lptr_t)s_sc;
         auto dma4p = [&](const void* src, u32 dst) {
@@ -267,14 +269,19 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
                 if (MODE == 0) dma4p(reinterpret_cast<const _Float16*>(wszs) + gc, sc_lds + 2 * NCH + 256 * i);
             }
         }
-        {   // token vectors: one half per lane in a 4-byte slot (2-byte requests: no alignment assumption on a [M] vector)
-            int m = m0 + lane;
+        // token vectors: one half per lane in a 4-byte slot (2-byte requests: no alignment assumption on a [M] vector); 64 tokens
+        // per instruction, TSL bytes per vector
+#pragma unroll
+        for (int i = 0; i < (16 * MT + 63) / 64; ++i) {
+            int m = m0 + 64 * i + lane;
             m = m < M ? m : M - 1;
             const _Float16* sa_p = reinterpret_cast<const _Float16*>(ascales) + m;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off" ::"v"(sa_p), "s"(sc_lds + 4 * NCH) : "memory");
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off" ::"v"(sa_p), "s"(sc_lds + 4 * NCH + 256 * i)
+                         : "memory");
             if (MODE == 0) {
                 const _Float16* ss_p = reinterpret_cast<const _Float16*>(assums) + m;
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off" ::"v"(ss_p), "s"(sc_lds + 4 * NCH + 256)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off" ::"v"(ss_p),
+                             "s"(sc_lds + 4 * NCH + TSL + 256 * i)
                              : "memory");
             }
         }
@@ -467,42 +474,51 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
     // well: all eight waves carry the seam's traffic (below).
     {
         constexpr int PPG = (NP + KG - 1) / KG;        // pieces per owning group
-        __syncthreads();                               // rings are dead (every wave drained its DMA queue)
-        QS_STAMP(4);
-        // partial of piece pc from group kg -> slot [owner][wn][source index among the other groups][pc / KG][lane]
-        v4i* const red4 = reinterpret_cast<v4i*>(smem);
-#pragma unroll
-        for (int pc = 0; pc < NP; ++pc) {
-            const int own = pc % KG;
-            if (own != kg) {
-                const int src = kg < own ? kg : kg - 1;
-                red4[((((own * WN + wn) * (KG - 1) + src) * PPG + pc / KG) << 6) + lane] = acc[pc >> 2][pc & 3];
-            }
-        }
-        QS_STAMP(7);
-        __syncthreads();
-        QS_STAMP(10);
+        // 128-token workgroups (MT = 8): the partial tiles of all groups are 192 KB (128 KB for four-unit workgroups) - they go
+        // through LDS in NPASS passes of PPP pieces per owner
+        constexpr int NPASS = MT > 4 ? 2 : 1;
+        constexpr int PPP = PPG / NPASS;
+        static_assert(PPG % NPASS == 0, "pieces per owner must split evenly over the passes");
         constexpr int RS = ACT ? 64 * WN + 16 : 144;   // staged fp16 row: 128 B + 16 (keeps 16-byte alignment); ACT: the
                                                        // workgroup's 32 WN result channels in one row
-        uint8_t* const st = smem + (size_t)KG * WN * (KG - 1) * PPG * 1024 + (ACT ? wn * 64 : wn * (16 * MT * RS));
+        uint8_t* const st = smem + (size_t)KG * WN * (KG - 1) * PPP * 1024 + (ACT ? wn * 64 : wn * (16 * MT * RS));
         // The pieces this wave finishes are pc = q KG + kg, q < PPG.  Their accumulators are picked by wave-uniform SELECTS, not by
         // branches (round 4: with one basic block per (q, kk) the four pieces of a gate_up wave ran one after the other, each
         // a chain LDS read -> sum -> scale -> exp / rcp -> LDS write with nothing to overlap it: 4 400 cycles between the two
         // barriers in the timeline trace; as straight-line code the reads of all pieces are in flight together).
         v4i sum[PPG];
+        v4i* const red4 = reinterpret_cast<v4i*>(smem);
 #pragma unroll
-        for (int q = 0; q < PPG; ++q) {
-            v4i own = acc[(q * KG) >> 2][(q * KG) & 3];
+        for (int pass = 0; pass < NPASS; ++pass) {
+            __syncthreads();                           // rings are dead (every wave drained its DMA queue) / previous pass consumed
+            if (pass == 0) QS_STAMP(4);
+            // partial of piece pc from group kg -> slot [owner][wn][source index among the other groups][pc / KG - pass PPP][lane]
 #pragma unroll
-            for (int kk = 1; kk < KG; ++kk)
-                if (q * KG + kk < NP) own = kg == kk ? acc[(q * KG + kk) >> 2][(q * KG + kk) & 3] : own;
-            sum[q] = own;
+            for (int pc = 0; pc < NP; ++pc) {
+                const int own = pc % KG, qq = pc / KG;
+                if (qq < pass * PPP || qq >= (pass + 1) * PPP) continue;
+                if (own != kg) {
+                    const int src = kg < own ? kg : kg - 1;
+                    red4[((((own * WN + wn) * (KG - 1) + src) * PPP + (qq - pass * PPP)) << 6) + lane] = acc[pc >> 2][pc & 3];
+                }
+            }
+            if (pass == 0) QS_STAMP(7);
+            __syncthreads();
+            if (pass == 0) QS_STAMP(10);
+#pragma unroll
+            for (int q = pass * PPP; q < (pass + 1) * PPP; ++q) {
+                v4i own = acc[(q * KG) >> 2][(q * KG) & 3];
+#pragma unroll
+                for (int kk = 1; kk < KG; ++kk)
+                    if (q * KG + kk < NP) own = kg == kk ? acc[(q * KG + kk) >> 2][(q * KG + kk) & 3] : own;
+                sum[q] = own;
+            }
+#pragma unroll
+            for (int q = pass * PPP; q < (pass + 1) * PPP; ++q)
+#pragma unroll
+                for (int sidx = 0; sidx < KG - 1; ++sidx)
+                    sum[q] += red4[((((kg * WN + wn) * (KG - 1) + sidx) * PPP + (q - pass * PPP)) << 6) + lane];
         }
-#pragma unroll
-        for (int q = 0; q < PPG; ++q)
-#pragma unroll
-            for (int sidx = 0; sidx < KG - 1; ++sidx)
-                sum[q] += red4[((((kg * WN + wn) * (KG - 1) + sidx) * PPG + q) << 6) + lane];
 #ifdef QS_RING_TRACE
 #pragma unroll
         for (int q = 0; q < PPG; ++q) asm volatile("" : "+v"(sum[q]));
@@ -625,7 +641,7 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
                 h4 o;
                 if (MODE == 0) {
                     const h4 wz4 = *reinterpret_cast<const h4*>(s_sc + 2 * (64 * WN) + 2 * lcol);
-                    const float ss = (float)*reinterpret_cast<const _Float16*>(s_sc + 4 * (64 * WN) + 256 + 4 * (16 * mt + li));
+                    const float ss = (float)*reinterpret_cast<const _Float16*>(s_sc + 4 * (64 * WN) + TSL + 4 * (16 * mt + li));
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(sum[q][r], (float)ws4[r], sa, (float)wz4[r], ss, flags & 16);
                 } else {
@@ -656,7 +672,7 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
         QS_STAMP(5);
         if (ACT) {                                     // rows of 64 WN bytes, shared by all eight waves
             constexpr int LPR = 4 * WN, RPI = 64 / LPR;                // lanes per row, rows per instruction
-            const uint8_t* const sa0 = smem + (size_t)KG * WN * (KG - 1) * PPG * 1024;
+            const uint8_t* const sa0 = smem + (size_t)KG * WN * (KG - 1) * PPP * 1024;
             _Float16* const arow = reinterpret_cast<_Float16*>(out) + unit0 * 32 + (lane % LPR) * 8;
 #pragma unroll
             for (int i = 0; i < 16 * MT / RPI; ++i) {
@@ -681,7 +697,9 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
     }
 }
 
-// MT m-tiles (16 tokens each) per wave = tokens per workgroup / 16; WN units per workgroup; KG = 8 / WN K-groups.
+// MT m-tiles (16 tokens each) per wave = tokens per workgroup / 16 (1, 2, 4; 8 = 128-token workgroups, round 5: one level-2
+// dequant of a weight byte serves 128 tokens, ring depth 3-4, reduction through LDS in two passes); WN units per workgroup;
+// KG = 8 / WN K-groups.
 // KSPLIT = false folds every K-slice path away (the un-split launches keep exactly their earlier code).
 template <int MT, int WN, int MODE, int OUTK, bool KSPLIT>
 __global__ __launch_bounds__(512, 1) void w4a8_gemm_ring(const int8_t* __restrict__ A, const uint8_t* __restrict__ W,
@@ -719,11 +737,11 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
     }
     if (ns < 3) ns = 3;                                // the slot read ahead and the slot refilled must differ
     size_t smem = (size_t)KG * ns * GSTAGE;
-    size_t tail = (size_t)(KG - 1) * WN * MT * 4 * 4 * 64 * 4 + (size_t)WN * 16 * MT * 144;   // reduction + staging
-    {   // distributed form: [owner KG][WN][KG-1 sources][pieces per group] x 1 KiB + the same staging area
-        const size_t ppg = (MT * 4 + KG - 1) / KG;
-        const size_t t2 = (size_t)KG * WN * (KG - 1) * ppg * 1024 + (size_t)WN * 16 * MT * 144;
-        if (tail < t2) tail = t2;
+    size_t tail;
+    {   // reduction area [owner KG][WN][KG-1 sources][pieces per group and pass] x 1 KiB (two passes for 128-token workgroups) +
+        // the staged fp16 tile (activation epilogue: rows of 64 WN + 16 bytes)
+        const size_t ppp = (MT * 4 + KG - 1) / KG / (MT > 4 ? 2 : 1);
+        tail = (size_t)KG * WN * (KG - 1) * ppp * 1024 + (OUTK == 2 ? (size_t)16 * MT * (64 * WN + 16) : (size_t)WN * 16 * MT * 144);
     }
     if (smem < tail) smem = tail;
     if (smem > (size_t)SC_OFF) {
@@ -814,8 +832,10 @@ int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, con
 #define QS_RM(MODEV, OUTV)                              \
     do {                                                \
         if (wn == 4) {                                  \
+            if (mt == 8) QS_R(8, 4, MODEV, OUTV);       \
             if (mt == 4) QS_R(4, 4, MODEV, OUTV);       \
         } else if (wn == 2) {                           \
+            if (mt == 8) QS_R(8, 2, MODEV, OUTV);       \
             if (mt == 4) QS_R(4, 2, MODEV, OUTV);       \
             if (mt == 2) QS_R(2, 2, MODEV, OUTV);       \
         } else {                                        \
