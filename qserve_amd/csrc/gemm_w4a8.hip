@@ -473,8 +473,8 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         const int v = g_variant - 4100, ks = v / 100 + 1, mt = (v % 100) / 10, wn = v % 10;
         const int mb = ((M + 15) / 16 + mt - 1) / mt;
         if (act && ks > 1) return QS_UNFUSED;
-        QS_REQUIRE((mt == 1 || mt == 2 || mt == 4 || mt == 8) && (wn == 1 || wn == 2 || (wn == 4 && mt >= 4)) &&
-                       !(mt == 1 && wn == 2) && !(mt == 8 && wn == 1) &&
+        QS_REQUIRE((mt == 1 || mt == 2 || mt == 4 || mt == 8) && (wn == 1 || wn == 2 || (wn == 4 && mt == 4)) &&
+                       !(mt == 1 && wn == 2) && !(mt == 8 && wn != 2) &&
                        N % (64 * wn) == 0 && (K / 64) % ks == 0 && (K / 64 / ks) % (8 / wn) == 0 && (ks == 1 || K / ks <= 32768),
                    "w4a8 gemm: forced ring geometry mt=%d wn=%d ksplit=%d does not fit M=%d N=%d K=%d", mt, wn, ks, M, N,
                    K);
@@ -492,8 +492,13 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
     if (M <= 1024 && !(K < 1024 && M <= 64) && g_variant != 4000 && (g_variant < 1000 || g_variant >= 4000) &&
         (size_t)M * K < (1ull << 32) && (size_t)N * K / 2 < (1ull << 32)) {
         const int mt_all = (M + 15) / 16;
-        // (8 m-tiles = 128-token workgroups, round 5: considered from 65 tokens on; variant 4004 keeps them out - A/B)
-        static const int geo[8][2] = {{4, 2}, {2, 2}, {4, 1}, {2, 1}, {1, 1}, {4, 4}, {8, 2}, {8, 4}};   // 4 units (2 K-groups): fewer bytes per CU where two-unit
+        // <8,2> = 128-token workgroups (round 5): PER-GROUP only, un-split, from 65 tokens on - one level-2 dequant of a weight byte
+        // serves 128 tokens instead of being repeated per 64-token block.  Measured (scripts/gpu_mt8_ab.sh, weights from HBM, g128):
+        // gate_up 28 672 x 4096 at M = 128: 30.6 us against 35.6 for <4,4> x 2 token blocks (M = 96: 29.6 / 35.2); per-channel
+        // the same geometry LOSES (28.5 vs 25.4 us: ring depth 3 instead of 5, nothing to share), K-sliced or four-unit forms of it
+        // lose everywhere (<8,4>: 60 us), and for N <= 6144 the 64-token geometries fill the chip better (qkv 28.7 vs 15.9 us).
+        // Variant 4004 keeps it out (A/B).
+        static const int geo[7][2] = {{4, 2}, {2, 2}, {4, 1}, {2, 1}, {1, 1}, {4, 4}, {8, 2}};   // 4 units (2 K-groups): fewer bytes per CU where two-unit
         // workgroups need a second round - M = 128 x N = 28 672: 26.8 vs 32.4 us (per-group 41.0 vs 47.0), M = 64 x 49 152: 48.9 vs 58.4
         // K slices (ksplit 2 / 4, int32 partial tiles meeting in a workspace, the last-dispatched slice finishes): fewer bytes per
         // CU when neither tokens nor channels can be cut further, against the seam's cost; variant 4001
@@ -507,9 +512,9 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         long best = -1;
         int bmt = 0, bwn = 0, bks = 1;
         for (int ks = 1; ks <= (g_variant == 4001 || act ? 1 : 4); ks *= 2)
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 7; ++i) {
                 const int mt = geo[i][0], wn = geo[i][1];
-                if (mt == 8 && (mt_all <= 4 || g_variant == 4004)) continue;
+                if (mt == 8 && (MODE != 1 || ks > 1 || mt_all <= 4 || mt_all > 8 || g_variant == 4004)) continue;   // (65 .. 128 tokens)
                 if (N % (64 * wn) != 0 || (K / 64) % ks != 0 || (K / 64 / ks) % (8 / wn) != 0) continue;
                 if (ks > 1 && K / ks > 32768) continue;        // the seam's sentinel must stay out of reach of a partial sum
                 const int mb = (mt_all + mt - 1) / mt;
@@ -738,13 +743,13 @@ bool planes_geometry(int mode, int M, int N, int K, PlanesGeo& g) {
         (size_t)N * K / 2 >= (1ull << 32))
         return false;
     const int mt_all = (M + 15) / 16;
-    static const int geo[8][2] = {{4, 2}, {2, 2}, {4, 1}, {2, 1}, {1, 1}, {4, 4}, {8, 2}, {8, 4}};
+    static const int geo[7][2] = {{4, 2}, {2, 2}, {4, 1}, {2, 1}, {1, 1}, {4, 4}, {8, 2}};   // <8,2>: forced only (tests)
     const int force = g_variant >= 4600 && g_variant < 5000 ? g_variant - 4600 : -1;   // tests / A-B: 4600 + 100*(ks-1) + 10*mt + wn
     long best = -1;
     for (int ks = 1; ks <= 4; ks *= 2)
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 7; ++i) {
             const int mt = geo[i][0], wn = geo[i][1];
-            if (mt == 8 && (mt_all <= 4 || g_variant == 4004)) continue;
+            if (mt == 8 && force < 0) continue;         // (measured: the 128-token geometry never wins as planes)
             if (N % (64 * wn) != 0 || (K / 64) % ks != 0 || (K / 64 / ks) % (8 / wn) != 0) continue;
             if (force >= 0 && force != 100 * (ks - 1) + 10 * mt + wn) continue;
             const int mb = (mt_all + mt - 1) / mt;

@@ -832,7 +832,6 @@ int qs_launch_gemm_ring(int mode, int outk, int mt, int wn, const int8_t* A, con
 #define QS_RM(MODEV, OUTV)                              \
     do {                                                \
         if (wn == 4) {                                  \
-            if (mt == 8) QS_R(8, 4, MODEV, OUTV);       \
             if (mt == 4) QS_R(4, 4, MODEV, OUTV);       \
         } else if (wn == 2) {                           \
             if (mt == 8) QS_R(8, 2, MODEV, OUTV);       \

@@ -73,7 +73,12 @@ def test_tensor_parallel_shards_use_the_ring_kernel(tp):
 def test_per_group_follows_the_same_model():
     assert gemm_plan(64, 4096, 14336, per_group=True) == ring(2, 1, 2, 2)     # (19.6-19.9 vs 20.6-20.9 us)
     assert gemm_plan(32, 4096, 14336) == ring(2, 1, 1, 4)                       # M = 32 keeps four slices (11.35 vs 11.87 us)
-    assert gemm_plan(128, 28672, 4096, per_group=True) == ring(4, 4, 2)     # 224 workgroups, one round (41.0 vs 47.0 us)
+    # g128 at 65 .. 128 tokens, many channels: ONE 128-token block per workgroup (round 5: the level-2 dequant of a weight byte
+    # serves all 128 tokens; 30.6 us against 35.6 for two 64-token blocks of four units); per-channel has nothing to share
+    assert gemm_plan(128, 28672, 4096, per_group=True) == ring(8, 2, 1)
+    assert gemm_plan(96, 28672, 4096, per_group=True) == ring(8, 2, 1)
+    assert gemm_plan(128, 28672, 4096) == ring(4, 4, 2)                     # 224 workgroups, one round
+    assert gemm_plan(129, 28672, 4096, per_group=True)["m_tiles"] == 4
     assert gemm_plan(2048, 4096, 4096, per_group=True)["family"] in ("tiled", "ring", "pair")
     # the level-2 dequant is VALU work per streamed weight byte: at equal bytes per CU the geometry with fewer channels per
     # workgroup wins per-group (g128 qkv at M = 128: 16.2 vs 18.3 us), while per-channel keeps (2,2) (12.1 vs 13.9 us)
