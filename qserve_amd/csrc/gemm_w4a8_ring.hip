@@ -132,10 +132,12 @@ constexpr int QS_HEAD_CAP = 1 << 18;               // polls (each: a memory roun
 template <int MODE, int HEADK>
 __device__ __forceinline__ void ring_head_rows(const RingHead& hd, int M, unsigned* errw, uint8_t* smem) {
     const int tid = threadIdx.x, half = tid >> 8, t = tid & 255;
+    // the epoch is requested first and USED last (the row's own loads go out behind it at once; its value is needed for the flag)
     const unsigned e = __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc(hd.sync, 0, 512, 0x00020000), 0, 0, 17);
-    // the census increment may not overtake the epoch read: wait for the value first (the asm consumes it)
-    asm volatile("s_waitcnt vmcnt(0)" ::"v"(e) : "memory");
-    if (tid == 0) __hip_atomic_fetch_add(hd.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef QS_RING_TRACE
+    const int lane = tid & 63, wave = tid >> 6;
+#endif
+    QS_STAMP(0);
     int row = 2 * (int)blockIdx.x + half;
     const bool real = row < M;
     float* const sm = reinterpret_cast<float*>(smem) + half * 32;
@@ -165,8 +167,12 @@ __device__ __forceinline__ void ring_head_rows(const RingHead& hd, int M, unsign
         __syncthreads();
         __syncthreads();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores of the row are acknowledged
+    QS_STAMP(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(e) : "memory");   // the write-through stores of the row are acknowledged (and e is here)
+    // the census increment may not overtake the epoch read: it is issued behind the wait above
+    if (tid == 0) __hip_atomic_fetch_add(hd.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    QS_STAMP(2);
     if (t == 0 && real && !(hd.inject && row == 0)) {
         unsigned* const f = hd.sync + 64 + row;
         const unsigned v = e + 1u;
@@ -318,7 +324,11 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
                 else dma16(p_off[j], sb, dst + p_lds[j]);
             } else {
                 if (what == 1) continue;
+#ifdef QS_TIMING   // (timing probe, 5000 + 512: the head launch's activation requests through the caches - results may be STALE)
+                if (HEADK && !(flags & 512)) dma16_sc(p_off[j], sb, dst + p_lds[j]);
+#else
                 if (HEADK) dma16_sc(p_off[j], sb, dst + p_lds[j]);
+#endif
                 else dma16(p_off[j], sb, dst + p_lds[j]);
             }
         }
@@ -393,38 +403,53 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
         // workgroups produce the activations; then the activation pieces of the prefetched stages and the token vectors
         const RingHead& hd = *hdp;
         const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(hd.sync, 0, 512, 0x00020000);
-        const unsigned e = __builtin_amdgcn_raw_buffer_load_b32(srs, 0, 0, 17);
-        asm volatile("s_waitcnt vmcnt(0)" ::"v"(e) : "memory");    // the census increment may not overtake the epoch read
-        if (tid == 0) __hip_atomic_fetch_add(hd.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int* const s_seen = reinterpret_cast<int*>(s_sc + SC_BYTES - 8);
         const int npre = ns - 1 < nloc ? ns - 1 : nloc;
-        int pre = 0, polls = 0;
-        bool ok = false;
-        while (!ok) {
-            if (pre < npre) {
-                issue(pre, pre, 1);
-                ++pre;
-                wait_vm<0>();
-            } else {
-                __builtin_amdgcn_s_sleep(4);
+        int pre = 0;
+        // Wave 0 is the POLLER: it requests nothing but the epoch and the flags (a poll behind a weight fill would come back
+        // only when the fill has landed - 2.5 us under load; timeline trace of the first version: rows done at 4.4 us, flags
+        // seen at 10); waves 1-7 prefetch their weight pieces one fill at a time and look at an LDS word between fills.  Wave 0's
+        // own pieces of the prefetched stages follow behind the flags.
+        volatile int* const v_seen = s_seen;
+        if (tid == 0) *s_seen = 0;
+        __syncthreads();
+        if (wave == 0) {
+            const unsigned e = __builtin_amdgcn_raw_buffer_load_b32(srs, 0, 0, 17);
+            int polls = 0;
+            bool counted = false;
+            for (;;) {
+                unsigned f = 0;
+                if (lane < M) f = __builtin_amdgcn_raw_buffer_load_b32(srs, 256 + 4 * lane, 0, 17);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(f) : "v"(e) : "memory");
+                if (!counted) {                        // the census increment may not overtake the epoch read: behind the wait
+                    if (lane == 0) __hip_atomic_fetch_add(hd.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    counted = true;
+                }
+                if (__builtin_amdgcn_ballot_w64(lane < M && f != e + 1u) == 0) break;
+                if (++polls >= QS_HEAD_CAP) {
+                    if (lane == 0 && counters) atomicOr(counters, QS_ERR_GEMM_HEAD);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
             }
-            if (wave == 0) {                           // one poller per workgroup: the 64 flags = two lines, one request
-                const unsigned f = lane < M ? __builtin_amdgcn_raw_buffer_load_b32(srs, 256 + 4 * lane, 0, 17) : e + 1u;
-                const bool all = __builtin_amdgcn_ballot_w64(f != e + 1u) == 0;
-                if (lane == 0) *s_seen = all ? 1 : 0;
-            }
-            __syncthreads();
-            ok = *s_seen != 0;
-            __syncthreads();
-            if (!ok && ++polls >= QS_HEAD_CAP) {
-                if (tid == 0 && counters) atomicOr(counters, QS_ERR_GEMM_HEAD);
-                break;
+            if (lane == 0) *v_seen = 1;
+        } else {
+            while (!__builtin_amdgcn_readfirstlane(*v_seen)) {      // (wave-uniform: `pre` and the ring slot stay scalar)
+                if (pre < npre) {
+                    issue(pre, pre, 1);
+                    ++pre;
+                    wait_vm<0>();                      // thinned: the next fill only when this one has landed
+                } else {
+                    __builtin_amdgcn_s_sleep(4);
+                }
             }
         }
+        QS_STAMP(13);
         for (; pre < npre; ++pre) issue(pre, pre, 1);
         if ((OUTK == 0 || OUTK == 2) && wave == 0) issue_token_vectors();
         for (int j = 0; j < npre; ++j) issue(j, j, 2);
         wait_vm<0>();                                  // (everything of the prologue: the loop's counted waits start from empty)
+        QS_STAMP(14);
     } else {
         for (int j = 0; j < ns - 1; ++j)
             if (j < nloc) issue(j, j);
@@ -960,7 +985,9 @@ int launch_ring_head(const uint8_t* W, const int8_t* zeros, const int8_t* scales
     hipLaunchKernelGGL(kern, grid, dim3(512), 160 * 1024, stream, hd.q_out, W, zeros, scales8, reinterpret_cast<const __half*>(wscales),
                        reinterpret_cast<const __half*>(hd.scale_out), reinterpret_cast<const __half*>(wszs),
                        reinterpret_cast<const __half*>(hd.sum_out), out, M, N, K, mblocks, ns, qs_gemm_error_word(),
-                       (g_epi_fma ? 16 : 0) | ((g_ring_flags & 1) || (mblocks > 1 && N <= 8192 && !(g_ring_flags & 2)) ? 1 : 0), hd);
+                       (g_ring_flags & 512) | (g_epi_fma ? 16 : 0) |
+                           ((g_ring_flags & 1) || (mblocks > 1 && N <= 8192 && !(g_ring_flags & 2)) ? 1 : 0),
+                       hd);
     return qs_launch_status("w4a8 gemm (ring, row-op head)");
 }
 
