@@ -121,7 +121,7 @@ int qs_w8a8_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscal
  *   9xx / 1000 + 100*mtile + 10*S + NW ... split-K decode kernel geometries;  2000 / 2001 ... LDS-pair kernel off / forced;
  *   3000 ... tiled (prefill) kernel off, 3001 / 3002 ... forced with the 256- / 128-token tile;
  *   4000 ... ring (decode) kernel off, 4001 ... ring kernel without K slices, 4002 ... cost model without the per-group term,
- *   4004 ... without the 128-token ring geometry <8,2>, 4005 ... qs_add_norm_quant_w4a8_gemm always as two launches,
+ *   4004 ... without the 128-token ring geometry <8,2> (round 5),
  *   4600 + 100*(k_slices-1) + 10*m_tiles + units ... forced geometry of the K-slice planes launches,
  *   3003 ... the four-wave compute-bound tile forced (3001: the eight-wave one), 3400 + bits ... [QS_TIMING builds] its ablations,
  *   4100 + 100*(k_slices-1) + 10*m_tiles + units ... forced ring geometry;
@@ -263,27 +263,6 @@ int qs_add_residual_rms_norm_general_planes(int8_t* out, void* hidden_io, const 
                                             float epsilon, int num_tokens, int hidden, qs_stream_t stream);
 int qs_silu_and_mul_quant(int8_t* out, const void* input, void* input_sum, void* scale, int num_tokens, int d,
                           qs_stream_t stream);
-/* ROW-OP HEAD (engine-side fusion, round 5; no reference op of its own: llama_w4a8_unpad.py:337,351 issue the layer norm and the
- * projection as separate ops).  BIT-IDENTICAL to
- *     qs_add_residual_rms_norm_general(q_out, hidden_io, delta, gamma, input_sum, scaling, eps, T, hidden)           [delta != NULL]
- *  or qs_add_residual_rms_norm_general_planes(q_out, hidden_io, planes, k_slices, plane_stride, p_wscales, p_w_szs,
- *                                             p_ascales, p_a_ssums, gamma, input_sum, scaling, eps, T, hidden)       [planes != NULL]
- * followed by the W4A8 GEMM the row feeds, with K = hidden:
- *     qs_w4a8_per_chn_gemm[_silu_mul](q_out, kernel, wscales, scaling, w_szs, input_sum, out[, tmp], T, N, hidden)   [w_szs != NULL]
- *  or qs_w4a8_per_group_gemm[_silu_mul](q_out, kernel, zeros, scales_i8, wscales, scaling, out[, tmp], T, N, hidden) [zeros != NULL]
- * (silu_mul != 0: out is [T, N/2], tmp the [T, N] scratch of the _silu_mul entries or NULL).  Exactly one of delta / planes.
- * ONE launch where the GEMM's geometry has a head instantiation - T <= 64, hidden = 4096, qkv- / gate_up-shaped N (the decode step
- * of the Llama-3-8B class) - and the per-device GEMM workspace exists: the row work runs as the first workgroups of the GEMM launch
- * while the others prefetch weights one fill at a time (gemm_w4a8_ring.hip, RingHead; scripts/microbench_rowhead.hip).  Otherwise
- * the two launches are issued here.  Uses the per-device workspace (same single-stream rule as the K-sliced GEMMs); its waits are
- * bounded (qs_device_status bit 4).  qs_set_gemm_variant(4005) keeps the two launches (A/B). */
-long qs_debug_head_launch_count(void);   /* tests: calls of the entry below that took the one-launch form so far */
-int qs_add_norm_quant_w4a8_gemm(int8_t* q_out, void* hidden_io, const void* delta, const int32_t* planes, int k_slices,
-                                int64_t plane_stride, const void* p_wscales, const void* p_w_szs, const void* p_ascales,
-                                const void* p_a_ssums, const void* gamma, void* input_sum, void* scaling, float epsilon,
-                                int num_tokens, int hidden, const int8_t* kernel, const int8_t* zeros, const int8_t* scales_i8,
-                                const void* wscales, const void* w_szs, void* out, void* tmp, int N, int silu_mul,
-                                qs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Prefill attention: provider for the call the reference makes into the un-vendored flash-attn wheel,
@@ -331,8 +310,7 @@ int qs_comm_destroy(void* comm);
  * rely on in-order workgroup dispatch and on single-stream use of the per-device scratch (see the header comment).  Every such
  * wait is BOUNDED: after ~1e6 polls (seconds) the waiting wave gives up, sets a bit in a per-device error word and finishes
  * the launch with what it has - results of that launch are invalid, the GPU is not hung.
- *   qs_device_status   error_bits = OR of 1 (K-slice seam gave up), 2 (attention + quant hand-over gave up), 4 (row-op head of a
- *                      GEMM launch: a token row or the start census never arrived) on the CURRENT
+ *   qs_device_status   error_bits = OR of 1 (K-slice seam gave up), 2 (attention + quant hand-over gave up) on the CURRENT
  *                      device since the last reset; blocking (a device-to-host copy behind the work launched so far) - call it
  *                      at checkpoints, not per launch.  Returns QS_OK when the word could be read; a non-zero word also sets
  *                      qs_last_error().
@@ -341,8 +319,7 @@ int qs_comm_destroy(void* comm);
  *                      status and after an aborted launch before the library is used again; replayed hipGraphs stay valid
  *                      (no address changes).
  *   qs_debug_inject_fault  tests only: arms a ONE-SHOT fault - bit 0: the next K-sliced ring GEMM launch, bit 1: the next
- *                      fused attention + quant launch, bit 2: the next row-op-head GEMM launch (qs_add_norm_quant_w4a8_gemm)
- *                      runs with one producer that never delivers (and, bits 0 / 1, a short poll bound), so
+ *                      fused attention + quant launch runs with one producer that never delivers (and a short poll bound), so
  *                      that the give-up path, the status word and the recovery can be exercised.  The results of THAT launch
  *                      are wrong by design; 0 disarms. */
 int qs_device_status(int* error_bits);

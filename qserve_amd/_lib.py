@@ -49,9 +49,6 @@ SIGNATURES = {
     "qs_add_residual_rms_norm_general": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "qs_add_residual_rms_norm_general_planes": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "qs_silu_and_mul_quant": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
-    "qs_debug_head_launch_count": (C.c_long, []),
-    "qs_add_norm_quant_w4a8_gemm": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp,
-                                        _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "qs_debug_wave_reduce_selftest": (_i, [_vp, _vp, _i, _vp]),
     "qs_device_status": (_i, [C.POINTER(C.c_int)]),
     "qs_device_reset": (_i, []),

@@ -198,30 +198,11 @@ constexpr int QS_SLAB_SENTINEL = (int)0x80808080u;
 constexpr int QS_SPIN_CAP = 1 << 20;
 constexpr unsigned QS_ERR_GEMM_SEAM = 1u;     // K-slice seam: a partial tile never arrived
 constexpr unsigned QS_ERR_ATTN_HANDOVER = 2u; // attention + quant: a KV head's result row never arrived
-constexpr unsigned QS_ERR_GEMM_HEAD = 4u;     // row-op head of a ring GEMM: a token row (or the start census) never arrived
-extern int g_inject_fault;                    // lib.hip: bit 0 next K-sliced ring GEMM launch, bit 1 next attention + quant launch,
-                                              // bit 2 next row-op-head GEMM launch
+extern int g_inject_fault;                    // lib.hip: bit 0 next K-sliced ring GEMM launch, bit 1 next attention + quant launch
 unsigned* qs_gemm_error_word();               // gemm_w4a8.hip: nullptr until the split-K workspace exists
 unsigned* qs_attn_error_word();               // attention_mfma.hip: nullptr until the hand-over workspace exists
 int qs_gemm_reset_handoff();                  // gemm_w4a8.hip: sentinel-fill the K-slice slabs, clear the error word
 int qs_attn_reset_handoff();                  // attention_mfma.hip: zero generation words / exchange rows, clear the error word
-
-// arguments of the row-op head of a ring GEMM launch (gemm_w4a8_ring.hip: protocol and arithmetic; filled by
-// qs_add_norm_quant_w4a8_gemm in gemm_w4a8.hip)
-struct RingHead {
-    int8_t* q_out;              // [M, hidden] int8 = the GEMM's A
-    _Float16* hidden_io;        // [M, hidden] residual stream, updated in place
-    const _Float16* delta;      // HEADK 1: fp16 [M, hidden] (the residual branch)
-    const int* planes;          // HEADK 2 / 3: int32 [KS][M][hidden] K-slice planes of the PREVIOUS GEMM ...
-    size_t pstride;
-    const _Float16 *p_ws, *p_wz;        // ... and its epilogue operands
-    const __half *p_ascale, *p_asum;    // (may alias scale_out / sum_out: a row reads its own values first)
-    const _Float16* gamma;
-    __half *sum_out, *scale_out;        // sum_out may be null (per-group)
-    float eps;
-    int hidden, epi_fma, nrow_wgs, inject;
-    unsigned* sync;             // {epoch, started, error word index ...}: [0] epoch, [1] started, [64 .. 127] flags
-};
 
 struct QsGemmPlan {
     int active;   // 1 while qs_w4a8_gemm_plan runs the dispatcher
@@ -269,8 +250,6 @@ __device__ __forceinline__ unsigned rni_sat_u8(float x) {
 }
 // 8 values x mul -> 8 int8 (cvt.rni.sat.s8.f32), one 8-byte store: the quantising store of the per-token row kernels
 // (fused_kernels.cu:78-82), shared by fused_small.hip and the attention + quant fusion
-// WT: write-through store (sc0 sc1) - the row is read by OTHER workgroups of the same launch (row-op heads of the ring GEMM)
-template <bool WT = false>
 __device__ __forceinline__ void qs_store_q8(int8_t* p, const float (&v)[8], float mul) {
     unsigned lo = 0, hi = 0;
 #pragma unroll
@@ -278,20 +257,5 @@ __device__ __forceinline__ void qs_store_q8(int8_t* p, const float (&v)[8], floa
         lo |= ((unsigned)rni_sat_s8(v[j] * mul) & 0xFFu) << (8 * j);
         hi |= ((unsigned)rni_sat_s8(v[4 + j] * mul) & 0xFFu) << (8 * j);
     }
-    if constexpr (WT) {
-        const uint2 q = make_uint2(lo, hi);
-        asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(q) : "memory");
-    } else {
-        *reinterpret_cast<uint2*>(p) = make_uint2(lo, hi);
-    }
-}
-template <bool WT = false>
-__device__ __forceinline__ void qs_store_half(__half* p, float v) {
-    const __half h = __float2half_rn(v);
-    if constexpr (WT) {
-        const unsigned bits = __half_as_ushort(h);
-        asm volatile("global_store_short %0, %1, off sc0 sc1" ::"v"(p), "v"(bits) : "memory");
-    } else {
-        *p = h;
-    }
+    *reinterpret_cast<uint2*>(p) = make_uint2(lo, hi);
 }

@@ -368,7 +368,7 @@ int launch_splitk(const int8_t* A, const uint8_t* W, const int8_t* zeros, const 
         Workspace* ws = get_workspace(stream);
         const size_t tiles = (size_t)grid.x * grid.y;
         const size_t need = tiles * S * (size_t)(MT * 4 * 64) * 16;
-        if (ws && need <= ws->slab_bytes && tiles < (size_t)ws->ncounters - 256) {     // (the last 256 counters: row-op head sync words, error word)
+        if (ws && need <= ws->slab_bytes && tiles < (size_t)ws->ncounters) {     // (the last counter is the error word)
             slabs = ws->slabs;
             counters = ws->counters;
             grid.z = S;
@@ -464,7 +464,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         if (g_qs_plan.active) return true;      // plan-only: assume the workspace exists
         Workspace* ws = get_workspace(stream);
         const size_t tiles = (size_t)units * mb;
-        if (!ws || tiles >= (size_t)ws->ncounters - 256 || tiles * ks * mt * 4096 > ws->slab_bytes) return false;
+        if (!ws || tiles >= (size_t)ws->ncounters || tiles * ks * mt * 4096 > ws->slab_bytes) return false;
         *slabs = ws->ring_slabs;
         *counters = ws->counters;
         return true;
@@ -789,91 +789,6 @@ extern "C" int qs_w4a8_per_chn_gemm_planes(const int8_t* in_feats, const int8_t*
 extern "C" int qs_w4a8_per_group_gemm_planes(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros,
                                              const int8_t* scales_i8, int32_t* planes, int M, int N, int K, qs_stream_t stream) {
     return gemm_planes<1>(in_feats, kernel, zeros, scales_i8, planes, M, N, K, stream);
-}
-
-// ---- row-op head (round 5): residual add + norm + quant and the GEMM it feeds in ONE launch -----------------------------------
-// == qs_add_residual_rms_norm_general[_planes](q_out, hidden_io, ...) ; qs_w4a8_per_{chn,group}_gemm[_silu_mul](q_out, kernel, ...,
-// scaling, input_sum, out) - bit-identical.  One launch (gemm_w4a8_ring.hip, RingHead) where the GEMM's geometry has a head
-// instantiation (the decode step's qkv- and gate_up-shaped GEMMs at <= 64 tokens of a 4096-wide model) and the per-device
-// workspace exists; the two launches otherwise.  qs_set_gemm_variant(4005) keeps the two launches (A/B).
-int qs_launch_gemm_ring_head(int mode, int outk, int mt, int wn, int headk, const uint8_t* W, const int8_t* zeros, const int8_t* scales8,
-                             const void* wscales, const void* wszs, void* out, int M, int N, int K, int mblocks, const RingHead& hd,
-                             hipStream_t stream);
-static long g_head_launches = 0;
-extern "C" long qs_debug_head_launch_count(void) { return g_head_launches; }   // tests: how many calls took the one-launch form
-extern "C" int qs_add_norm_quant_w4a8_gemm(int8_t* q_out, void* hidden_io, const void* delta, const int32_t* planes, int k_slices,
-                                           int64_t plane_stride, const void* p_wscales, const void* p_w_szs, const void* p_ascales,
-                                           const void* p_a_ssums, const void* gamma, void* input_sum, void* scaling, float epsilon,
-                                           int num_tokens, int hidden, const int8_t* kernel, const int8_t* zeros,
-                                           const int8_t* scales_i8, const void* wscales, const void* w_szs, void* out, void* tmp,
-                                           int N, int silu_mul, qs_stream_t stream) {
-    QS_REQUIRE((delta != nullptr) != (planes != nullptr), "add_norm_quant_w4a8_gemm: exactly one of delta / planes");
-    QS_REQUIRE((zeros == nullptr) == (scales_i8 == nullptr) && (zeros == nullptr) == (w_szs != nullptr),
-               "add_norm_quant_w4a8_gemm: per-channel (w_szs) or per-group (zeros, scales_i8) operands");
-    const bool per_group = zeros != nullptr;
-    QS_REQUIRE(per_group || input_sum, "add_norm_quant_w4a8_gemm: the per-channel GEMM needs input_sum");
-    const int M = num_tokens, K = hidden;
-    int headk = 0;
-    if (M >= 1 && M <= 64 && hidden == 4096 && N > 0 && N % 64 == 0 && g_variant != 4005 && !g_qs_plan.active && q_out && hidden_io &&
-        gamma && scaling && kernel && wscales && out) {
-        if (delta) headk = 1;
-        else if ((k_slices == 4 || k_slices == 2) && plane_stride >= (int64_t)M * hidden && p_wscales && p_ascales &&
-                 (p_w_szs == nullptr) == per_group && (p_a_ssums == nullptr) == per_group &&
-                 !((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(p_wscales) | reinterpret_cast<uintptr_t>(p_w_szs)) & 15))
-            headk = k_slices == 4 ? 2 : 3;
-    }
-    Workspace* ws = headk ? get_workspace(reinterpret_cast<hipStream_t>(stream)) : nullptr;
-    if (headk && ws) {
-        // the geometry the dispatcher takes for this GEMM (plan-only pass)
-        const int8_t* d8 = reinterpret_cast<const int8_t*>(uintptr_t(256));
-        void* dv = reinterpret_cast<void*>(uintptr_t(256));
-        g_qs_plan = {1, 0, {0, 0, 0, 0}};
-        const int prc = per_group ? dispatch<1, 0>(d8, d8, d8, d8, dv, dv, nullptr, nullptr, dv, M, N, K, nullptr, silu_mul != 0)
-                                  : dispatch<0, 0>(d8, d8, nullptr, nullptr, dv, dv, dv, dv, dv, M, N, K, nullptr, silu_mul != 0);
-        const QsGemmPlan plan = g_qs_plan;
-        g_qs_plan.active = 0;
-        if (prc == QS_OK && plan.family == 3 && plan.p[3] == 1 &&
-            ((plan.p[0] == 2 && plan.p[1] == 1 && !silu_mul) || (plan.p[0] == 4 && plan.p[1] == 2 && silu_mul)) &&
-            (size_t)M * K < (1ull << 32) && (size_t)N * K / 2 < (1ull << 32) &&
-            !((reinterpret_cast<uintptr_t>(wscales) | (per_group ? 0 : reinterpret_cast<uintptr_t>(w_szs))) & 3)) {
-            RingHead hd;
-            hd.q_out = q_out;
-            hd.hidden_io = reinterpret_cast<_Float16*>(hidden_io);
-            hd.delta = reinterpret_cast<const _Float16*>(delta);
-            hd.planes = planes;
-            hd.pstride = (size_t)plane_stride;
-            hd.p_ws = reinterpret_cast<const _Float16*>(p_wscales);
-            hd.p_wz = reinterpret_cast<const _Float16*>(p_w_szs);
-            hd.p_ascale = reinterpret_cast<const __half*>(p_ascales);
-            hd.p_asum = reinterpret_cast<const __half*>(p_a_ssums);
-            hd.gamma = reinterpret_cast<const _Float16*>(gamma);
-            hd.sum_out = reinterpret_cast<__half*>(input_sum);
-            hd.scale_out = reinterpret_cast<__half*>(scaling);
-            hd.eps = epsilon;
-            hd.hidden = hidden;
-            hd.epi_fma = g_epi_fma;
-            hd.nrow_wgs = (M + 1) / 2;
-            hd.inject = 0;
-            hd.sync = ws->counters + (ws->ncounters - 256);
-            const int rc = qs_launch_gemm_ring_head(per_group ? 1 : 0, silu_mul ? 2 : 0, plan.p[0], plan.p[1], headk,
-                                                    reinterpret_cast<const uint8_t*>(kernel), zeros, scales_i8, wscales, w_szs, out, M, N,
-                                                    K, plan.p[2], hd, reinterpret_cast<hipStream_t>(stream));
-            if (rc != QS_ENOSUP) {
-                if (rc == QS_OK) ++g_head_launches;
-                return rc;
-            }
-        }
-    }
-    // the two launches
-    int rc = delta ? qs_add_residual_rms_norm_general(q_out, hidden_io, delta, gamma, input_sum, scaling, epsilon, M, hidden, stream)
-                   : qs_add_residual_rms_norm_general_planes(q_out, hidden_io, planes, k_slices, plane_stride, p_wscales, p_w_szs,
-                                                             p_ascales, p_a_ssums, gamma, input_sum, scaling, epsilon, M, hidden, stream);
-    if (rc != QS_OK) return rc;
-    if (silu_mul)
-        return per_group ? qs_w4a8_per_group_gemm_silu_mul(q_out, kernel, zeros, scales_i8, wscales, scaling, out, tmp, M, N, K, stream)
-                         : qs_w4a8_per_chn_gemm_silu_mul(q_out, kernel, wscales, scaling, w_szs, input_sum, out, tmp, M, N, K, stream);
-    return per_group ? qs_w4a8_per_group_gemm(q_out, kernel, zeros, scales_i8, wscales, scaling, out, M, N, K, stream)
-                     : qs_w4a8_per_chn_gemm(q_out, kernel, wscales, scaling, w_szs, input_sum, out, M, N, K, stream);
 }
 
 extern "C" int qs_w4a8_per_chn_gemm_acc(const int8_t* in_feats, const int8_t* kernel, int32_t* acc_out, int M, int N,

@@ -21,7 +21,6 @@
 //   * the KG partial int32 tiles are summed exactly through LDS, the fp32 epilogue is fused, its scale operands are
 //     requested before the reduction, and the fp16 tile leaves through LDS as whole 128-byte rows.
 #include "common.h"
-#include "row_ops.h"
 #include <type_traits>
 
 // A/B switches (qs_set_gemm_variant(5000 + bits); every setting computes the same results):
@@ -113,95 +112,15 @@ __device__ __forceinline__ RingCoords ring_coords(int b, int N, int wn, int mblo
     return c;
 }
 
-// ---- row-op HEAD (round 5) -------------------------------------------------------------------------------------------------
-// The row kernel that produces the GEMM's int8 activations (residual add + norm + quant, llama_w4a8_unpad.py:337 / :351) runs as
-// the FIRST workgroups of the GEMM launch, two token rows per workgroup (the stand-alone kernel's 256-thread layout and arithmetic:
-// qs_row::norm_quant_row, bit-identical), with write-through stores; the GEMM workgroups meanwhile prefetch their first weight
-// stages THINNED - one 16 KiB fill outstanding at a time - poll the rows' flags, then fetch their activations cache-bypassing and
-// run the ordinary k loop.  Round 3 built this with the whole ring fill requested at once and lost (17.3 vs 12.9 us): the rows'
-// requests queue behind everybody's weight burst.  scripts/microbench_rowhead.hip (profiles/round5_rowhead.txt): burst 15.1 us,
-// no prefetch 17.0, two launches 15.6, THINNED 13.3 us per (row phase + 48 MB stream).
-// Protocol (placement- and timing-independent; every wait bounded): three words + 64 flags of the per-device GEMM workspace.
-//   every workgroup: e = epoch (cache-bypassing load), THEN started += 1 (fire and forget);
-//   row workgroup: rows -> write-through stores -> drain -> flag[row] = e + 1 (write-through);
-//   row workgroup 0, afterwards: waits until started == gridDim.x (everybody has READ the epoch), then started = 0, epoch = e + 1;
-//   GEMM workgroup: polls until flag[r] == e + 1 for every row r (one wave, one 256-byte request per poll).
-// Flags are never reset: a stale value never equals the running launch's e + 1.
-constexpr int QS_HEAD_CAP = 1 << 18;               // polls (each: a memory round trip + sleep): ~ a second
-
-template <int MODE, int HEADK>
-__device__ __forceinline__ void ring_head_rows(const RingHead& hd, int M, unsigned* errw, uint8_t* smem) {
-    const int tid = threadIdx.x, half = tid >> 8, t = tid & 255;
-    // the epoch is requested first and USED last (the row's own loads go out behind it at once; its value is needed for the flag)
-    const unsigned e = __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc(hd.sync, 0, 512, 0x00020000), 0, 0, 17);
-#ifdef QS_RING_TRACE
-    const int lane = tid & 63, wave = tid >> 6;
-#endif
-    QS_STAMP(0);
-    int row = 2 * (int)blockIdx.x + half;
-    const bool real = row < M;
-    float* const sm = reinterpret_cast<float*>(smem) + half * 32;
-    const int hid = hd.hidden;
-    if (real) {
-        const size_t base = (size_t)row * hid;
-        if constexpr (HEADK == 1) {
-            qs_row::norm_quant_row<2, 4, 4, true, false, qs_row::NoHook, qs_row::FromRow, true, true>(
-                hd.q_out + base, hd.hidden_io + base, hd.delta + base, hd.gamma, hd.sum_out ? hd.sum_out + row : nullptr,
-                hd.scale_out + row, hd.eps, hid, sm, t);
-        } else {
-            constexpr int KS = HEADK == 2 ? 4 : 2;
-            qs_row::FromPlanes<KS, MODE> dfn;
-            dfn.row0 = hd.planes + base;
-            dfn.pstride = hd.pstride;
-            dfn.ws = hd.p_ws;
-            dfn.wz = hd.p_wz;
-            dfn.sa = __half2float(hd.p_ascale[row]);
-            dfn.ss = MODE == 0 ? __half2float(hd.p_asum[row]) : 0.f;
-            dfn.fma = hd.epi_fma;
-            qs_row::norm_quant_row<2, 4, 4, true, false, qs_row::NoHook, qs_row::FromPlanes<KS, MODE>, true, true>(
-                hd.q_out + base, hd.hidden_io + base, nullptr, hd.gamma, hd.sum_out ? hd.sum_out + row : nullptr,
-                hd.scale_out + row, hd.eps, hid, sm, t, qs_row::NoHook(), dfn);
-        }
-    } else {                                           // (odd row count: the idle half keeps the barrier count of the row function)
-        __syncthreads();
-        __syncthreads();
-        __syncthreads();
-    }
-    QS_STAMP(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::"v"(e) : "memory");   // the write-through stores of the row are acknowledged (and e is here)
-    // the census increment may not overtake the epoch read: it is issued behind the wait above
-    if (tid == 0) __hip_atomic_fetch_add(hd.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    QS_STAMP(2);
-    if (t == 0 && real && !(hd.inject && row == 0)) {
-        unsigned* const f = hd.sync + 64 + row;
-        const unsigned v = e + 1u;
-        asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(f), "v"(v) : "memory");
-    }
-    if (blockIdx.x == 0 && tid == 0) {
-        // everybody has read the epoch once `started` shows the whole grid: only then may it move on
-        int polls = 0;
-        while (__hip_atomic_load(hd.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x) {
-            if (++polls >= QS_HEAD_CAP) {
-                if (errw) atomicOr(errw, QS_ERR_GEMM_HEAD);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(8);
-        }
-        __hip_atomic_store(hd.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(hd.sync, e + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 // The GEMM proper.
-template <int MT, int WN, int MODE, int OUTK, bool KSPLIT, int HEADK = 0>
+template <int MT, int WN, int MODE, int OUTK, bool KSPLIT>
 __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const uint8_t* __restrict__ W,
                                          const int8_t* __restrict__ zeros, const int8_t* __restrict__ scales8,
                                          const __half* __restrict__ wscales, const __half* __restrict__ ascales,
                                          const __half* __restrict__ wszs, const __half* __restrict__ assums,
                                          void* __restrict__ out, int M, int N, int K, int mblocks, int ns, int ksplit_arg,
                                          int* __restrict__ slabs, unsigned* __restrict__ counters, int flags,
-                                         uint8_t* smem, const RingHead* hdp = nullptr) {
+                                         uint8_t* smem) {
     const int ksplit = KSPLIT ? ksplit_arg : 1;
     constexpr int KG = 8 / WN;
     constexpr int ASTAGE = 16 * MT * 64;              // activation bytes per stage (64 k)
@@ -223,7 +142,7 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
     // weights are fetched from HBM once and re-served by that XCD's L2
     // K split (ksplit > 1): the K range is cut into ksplit slices handled by different workgroups (same XCD as well);
     // the int32 partial tiles meet in a workspace, the last-dispatched slice finishes (see the seam below).
-    const RingCoords rc = ring_coords(HEADK ? (int)blockIdx.x - hdp->nrow_wgs : (int)blockIdx.x, N, WN, mblocks, ksplit);
+    const RingCoords rc = ring_coords(blockIdx.x, N, WN, mblocks, ksplit);
     const int nblk = rc.nblk, mblk = rc.mblk, kq = rc.kq;
     const int unit0 = nblk * WN;                      // first 64-channel unit of the workgroup
     // OUTK == 2 (gate_up + silu * mul): N stacks [gate | up] (N/2 channels each); "unit" j then means gate channels
@@ -304,13 +223,7 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(lds_addr)
                      : "memory");
     };
-    // row-op head: the activations were written by other workgroups of THIS launch - cache-bypassing requests
-    auto dma16_sc = [&](u32 voff, const void* sbase, u32 lds_addr) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc0 sc1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
-                     : "memory");
-    };
-    // what: 0 = the whole stage, 1 = its weight pieces (+ per-group meta) only, 2 = its activation pieces only (row-op head)
-    auto issue = [&](int i, int slot, int what = 0) { // group-local stage i -> global stage u = i*KG + kg
+    auto issue = [&](int i, int slot) {               // group-local stage i -> global stage u = i*KG + kg
         const int u = u0 + i * KG + kg;
         const u32 dst = ring_lds + slot * GSTAGE;
 #pragma unroll
@@ -318,21 +231,10 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
             const void* sb = p_isw[j] ? static_cast<const void*>(W + (size_t)u * 1024)
                                       : static_cast<const void*>(A + (size_t)(u - hf) * 64);   // the pair's line
             static_assert(MT % WN == 0, "piece kind must be a compile-time function of j");
-            if (j >= MT / WN) {                        // (p = wn + j*WN >= MT: a weight piece)
-                if (what == 2) continue;
-                if (!(flags & 1)) dma16_nt(p_off[j], sb, dst + p_lds[j]);
-                else dma16(p_off[j], sb, dst + p_lds[j]);
-            } else {
-                if (what == 1) continue;
-#ifdef QS_TIMING   // (timing probe, 5000 + 512: the head launch's activation requests through the caches - results may be STALE)
-                if (HEADK && !(flags & 512)) dma16_sc(p_off[j], sb, dst + p_lds[j]);
-#else
-                if (HEADK) dma16_sc(p_off[j], sb, dst + p_lds[j]);
-#endif
-                else dma16(p_off[j], sb, dst + p_lds[j]);
-            }
+            if (j >= MT / WN && !(flags & 1)) dma16_nt(p_off[j], sb, dst + p_lds[j]);   // (p = wn + j*WN >= MT: a weight piece)
+            else dma16(p_off[j], sb, dst + p_lds[j]);
         }
-        if (MODE == 1 && what != 2) {
+        if (MODE == 1) {
             const int8_t* src = m_base + (size_t)(u >> 1) * N;
             const u32 ml = dst + ASTAGE + WSTAGE + (WN > 2 ? (wn & 1) * MZ : 0);
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(ml) : "memory");
@@ -349,38 +251,12 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
     uint8_t* const s_sc = smem + SC_OFF;
     constexpr int TSL = MT > 4 ? 512 : 256;           // bytes of one staged token vector (4-byte slots)
     static_assert(4 * 64 * WN + 2 * TSL <= SC_BYTES, "epilogue operand staging area");
-    constexpr int NCH = 64 * WN;                      // channels of the workgroup's tile
-    // token vectors: one half per lane in a 4-byte slot (2-byte requests: no alignment assumption on a [M] vector); 64 tokens per
-    // instruction, TSL bytes per vector.  Row-op head: they are written by this launch's row workgroups - requested behind the
-    // flags, cache-bypassing
-    auto issue_token_vectors = [&]() {
-        const u32 sc_lds = (u32)(size_t)(lptr_t)s_sc;
-#pragma unroll
-        for (int i = 0; i < (16 * MT + 63) / 64; ++i) {
-            int m = m0 + 64 * i + lane;
-            m = m < M ? m : M - 1;
-            const _Float16* sa_p = reinterpret_cast<const _Float16*>(ascales) + m;
-            const _Float16* ss_p = reinterpret_cast<const _Float16*>(assums) + m;
-            if (HEADK) {
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off sc0 sc1" ::"v"(sa_p),
-                             "s"(sc_lds + 4 * NCH + 256 * i) : "memory");
-                if (MODE == 0)
-                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off sc0 sc1" ::"v"(ss_p),
-                                 "s"(sc_lds + 4 * NCH + TSL + 256 * i) : "memory");
-            } else {
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off" ::"v"(sa_p), "s"(sc_lds + 4 * NCH + 256 * i)
-                             : "memory");
-                if (MODE == 0)
-                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off" ::"v"(ss_p),
-                                 "s"(sc_lds + 4 * NCH + TSL + 256 * i) : "memory");
-            }
-        }
-    };
     if ((OUTK == 0 || OUTK == 2) && wave == 0) {
         const u32 sc_lds = (u32)(size_t)(lptr_t)s_sc;
         auto dma4p = [&](const void* src, u32 dst) {
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(dst) : "memory");
         };
+        constexpr int NCH = 64 * WN;                  // channels of the workgroup's tile
 #pragma unroll
         for (int i = 0; i < (NCH + 127) / 128; ++i) { // 128 halfs per instruction
             const int lc = 128 * i + 2 * lane;
@@ -393,67 +269,28 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
                 if (MODE == 0) dma4p(reinterpret_cast<const _Float16*>(wszs) + gc, sc_lds + 2 * NCH + 256 * i);
             }
         }
-        if (!HEADK) issue_token_vectors();
+        // token vectors: one half per lane in a 4-byte slot (2-byte requests: no alignment assumption on a [M] vector); 64 tokens
+        // per instruction, TSL bytes per vector
+#pragma unroll
+        for (int i = 0; i < (16 * MT + 63) / 64; ++i) {
+            int m = m0 + 64 * i + lane;
+            m = m < M ? m : M - 1;
+            const _Float16* sa_p = reinterpret_cast<const _Float16*>(ascales) + m;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off" ::"v"(sa_p), "s"(sc_lds + 4 * NCH + 256 * i)
+                         : "memory");
+            if (MODE == 0) {
+                const _Float16* ss_p = reinterpret_cast<const _Float16*>(assums) + m;
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off" ::"v"(ss_p),
+                             "s"(sc_lds + 4 * NCH + TSL + 256 * i)
+                             : "memory");
+            }
+        }
     }
 
     // ---- prologue: stages 0..ns-2 in flight, operands of stage 0 in registers ---------------------------------------
     QS_STAMP(15);
-    if constexpr (HEADK) {
-        // ---- row-op head: THINNED weight prefetch (one stage's weight pieces outstanding at a time) while this launch's row
-        // workgroups produce the activations; then the activation pieces of the prefetched stages and the token vectors
-        const RingHead& hd = *hdp;
-        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(hd.sync, 0, 512, 0x00020000);
-        int* const s_seen = reinterpret_cast<int*>(s_sc + SC_BYTES - 8);
-        const int npre = ns - 1 < nloc ? ns - 1 : nloc;
-        int pre = 0;
-        // Wave 0 is the POLLER: it requests nothing but the epoch and the flags (a poll behind a weight fill would come back
-        // only when the fill has landed - 2.5 us under load; timeline trace of the first version: rows done at 4.4 us, flags
-        // seen at 10); waves 1-7 prefetch their weight pieces one fill at a time and look at an LDS word between fills.  Wave 0's
-        // own pieces of the prefetched stages follow behind the flags.
-        volatile int* const v_seen = s_seen;
-        if (tid == 0) *s_seen = 0;
-        __syncthreads();
-        if (wave == 0) {
-            const unsigned e = __builtin_amdgcn_raw_buffer_load_b32(srs, 0, 0, 17);
-            int polls = 0;
-            bool counted = false;
-            for (;;) {
-                unsigned f = 0;
-                if (lane < M) f = __builtin_amdgcn_raw_buffer_load_b32(srs, 256 + 4 * lane, 0, 17);
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(f) : "v"(e) : "memory");
-                if (!counted) {                        // the census increment may not overtake the epoch read: behind the wait
-                    if (lane == 0) __hip_atomic_fetch_add(hd.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    counted = true;
-                }
-                if (__builtin_amdgcn_ballot_w64(lane < M && f != e + 1u) == 0) break;
-                if (++polls >= QS_HEAD_CAP) {
-                    if (lane == 0 && counters) atomicOr(counters, QS_ERR_GEMM_HEAD);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if (lane == 0) *v_seen = 1;
-        } else {
-            while (!__builtin_amdgcn_readfirstlane(*v_seen)) {      // (wave-uniform: `pre` and the ring slot stay scalar)
-                if (pre < npre) {
-                    issue(pre, pre, 1);
-                    ++pre;
-                    wait_vm<0>();                      // thinned: the next fill only when this one has landed
-                } else {
-                    __builtin_amdgcn_s_sleep(4);
-                }
-            }
-        }
-        QS_STAMP(13);
-        for (; pre < npre; ++pre) issue(pre, pre, 1);
-        if ((OUTK == 0 || OUTK == 2) && wave == 0) issue_token_vectors();
-        for (int j = 0; j < npre; ++j) issue(j, j, 2);
-        wait_vm<0>();                                  // (everything of the prologue: the loop's counted waits start from empty)
-        QS_STAMP(14);
-    } else {
-        for (int j = 0; j < ns - 1; ++j)
-            if (j < nloc) issue(j, j);
-    }
+    for (int j = 0; j < ns - 1; ++j)
+        if (j < nloc) issue(j, j);
     QS_STAMP(1);
     // Everything the k loop needs but the first requests do not - operand reader addresses, accumulators - is computed BEHIND
     // the prologue (round 4, timeline trace: the first request left 1 200-1 400 cycles after kernel entry; with two waves per
@@ -937,88 +774,7 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
     return qs_launch_status("w4a8 gemm (ring)");
 }
 
-// ---- the same kernel with a row-op head (see RingHead): un-split geometries only ----------------------------------------------
-template <int MT, int WN, int MODE, int OUTK, int HEADK>
-__global__ __launch_bounds__(512, 1) void w4a8_gemm_ring_head(const int8_t* __restrict__ A, const uint8_t* __restrict__ W,
-                                                              const int8_t* __restrict__ zeros,
-                                                              const int8_t* __restrict__ scales8,
-                                                              const __half* __restrict__ wscales,
-                                                              const __half* __restrict__ ascales,
-                                                              const __half* __restrict__ wszs,
-                                                              const __half* __restrict__ assums, void* __restrict__ out,
-                                                              int M, int N, int K, int mblocks, int ns, unsigned* __restrict__ errw,
-                                                              int flags, RingHead hd) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    if ((int)blockIdx.x < hd.nrow_wgs) {
-        ring_head_rows<MODE, HEADK>(hd, M, errw, smem);
-        return;
-    }
-    ring_body<MT, WN, MODE, OUTK, false, HEADK>(A, W, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K, mblocks, ns, 1,
-                                                nullptr, errw, flags, smem, &hd);
-}
-
-template <int MT, int WN, int MODE, int OUTK, int HEADK>
-int launch_ring_head(const uint8_t* W, const int8_t* zeros, const int8_t* scales8, const void* wscales, const void* wszs, void* out,
-                     int M, int N, int K, int mblocks, RingHead hd, hipStream_t stream) {
-    auto kern = w4a8_gemm_ring_head<MT, WN, MODE, OUTK, HEADK>;
-    constexpr int KG = 8 / WN;
-    constexpr int GSTAGE = ring_gstage<MT, WN, MODE>();
-    int ns = (144 * 1024) / (KG * GSTAGE);
-    if (ns > 5) ns = 5;
-    const int nloc = (K / 64) / KG;
-    if (ns > nloc + 1) ns = nloc + 1;
-    if (ns < 3) ns = 3;
-    static size_t configured_dev[QS_MAX_DEVICES] = {};
-    size_t& configured = configured_dev[qs_device_slot()];
-    if (configured < 160 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(160 * 1024));
-        if (e != hipSuccess) {
-            qs_set_error("w4a8 gemm (ring, row-op head): cannot reserve LDS: %s", hipGetErrorString(e));
-            return (int)e;
-        }
-        configured = 160 * 1024;
-    }
-    hd.inject = 0;
-    if (g_inject_fault & 4) hd.inject = 1, g_inject_fault &= ~4;
-    dim3 grid((N / (64 * WN)) * mblocks + hd.nrow_wgs);
-    hipLaunchKernelGGL(kern, grid, dim3(512), 160 * 1024, stream, hd.q_out, W, zeros, scales8, reinterpret_cast<const __half*>(wscales),
-                       reinterpret_cast<const __half*>(hd.scale_out), reinterpret_cast<const __half*>(wszs),
-                       reinterpret_cast<const __half*>(hd.sum_out), out, M, N, K, mblocks, ns, qs_gemm_error_word(),
-                       (g_ring_flags & 512) | (g_epi_fma ? 16 : 0) |
-                           ((g_ring_flags & 1) || (mblocks > 1 && N <= 8192 && !(g_ring_flags & 2)) ? 1 : 0),
-                       hd);
-    return qs_launch_status("w4a8 gemm (ring, row-op head)");
-}
-
 }  // namespace
-
-// Row-op head launches (qs_add_norm_quant_w4a8_gemm in gemm_w4a8.hip): the geometries the decode step of a 4096-wide model takes
-// - qkv-like <2,1> (plain epilogue) and gate_up-like <4,2> (silu * mul epilogue) - with the head reading an fp16 residual branch
-// (headk 1) or K-slice planes of 4 / 2 slices (headk 2 / 3).  QS_ENOSUP for anything else: the caller issues the two launches.
-int qs_launch_gemm_ring_head(int mode, int outk, int mt, int wn, int headk, const uint8_t* W, const int8_t* zeros, const int8_t* scales8,
-                             const void* wscales, const void* wszs, void* out, int M, int N, int K, int mblocks, const RingHead& hd,
-                             hipStream_t stream) {
-#define QS_H(MTV, WNV, MODEV, OUTV, HK) \
-    return launch_ring_head<MTV, WNV, MODEV, OUTV, HK>(W, zeros, scales8, wscales, wszs, out, M, N, K, mblocks, hd, stream)
-#define QS_HK(MTV, WNV, MODEV, OUTV)                 \
-    do {                                             \
-        if (headk == 1) QS_H(MTV, WNV, MODEV, OUTV, 1); \
-        if (headk == 2) QS_H(MTV, WNV, MODEV, OUTV, 2); \
-        if (headk == 3) QS_H(MTV, WNV, MODEV, OUTV, 3); \
-    } while (0)
-    if (mt == 2 && wn == 1 && outk == 0) {
-        if (mode == 0) QS_HK(2, 1, 0, 0);
-        else QS_HK(2, 1, 1, 0);
-    }
-    if (mt == 4 && wn == 2 && outk == 2) {
-        if (mode == 0) QS_HK(4, 2, 0, 2);
-        else QS_HK(4, 2, 1, 2);
-    }
-#undef QS_HK
-#undef QS_H
-    return QS_ENOSUP;
-}
 
 #ifdef QS_RING_TRACE
 extern "C" int qs_debug_ring_trace(void* buf) {

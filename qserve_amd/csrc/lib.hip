@@ -31,8 +31,7 @@ extern "C" int qs_device_status(int* error_bits) {
         *error_bits |= (int)v;
     }
     if (*error_bits)
-        qs_set_error("a bounded in-launch wait gave up (bits %d: 1 = K-slice seam of a W4A8 GEMM, 2 = attention + quant hand-over, "
-                     "4 = row-op head of a W4A8 GEMM): "
+        qs_set_error("a bounded in-launch wait gave up (bits %d: 1 = K-slice seam of a W4A8 GEMM, 2 = attention + quant hand-over): "
                      "results of that launch are invalid; call qs_device_reset() before reusing the library", *error_bits);
     return QS_OK;
 }
@@ -47,7 +46,7 @@ extern "C" int qs_device_reset(void) {
     return rc;
 }
 extern "C" int qs_debug_inject_fault(int what) {
-    QS_REQUIRE(what >= 0 && what <= 7, "qs_debug_inject_fault: what=%d not in 0..7", what);
+    QS_REQUIRE(what >= 0 && what <= 3, "qs_debug_inject_fault: what=%d not in 0..3", what);
     g_inject_fault = what;
     return QS_OK;
 }

@@ -159,7 +159,7 @@ __device__ __forceinline__ void reduce_max_sum(float (&mx)[NVW / PW], float (&su
 // out int8 [hidden], in fp16 [hidden]; sum_out may be null.  sm: 2 * NVW floats of LDS.  SC: `in` was published by other
 // workgroups of this launch (cache-bypassing loads).  `ready` runs before the first load of `in` (the GEMM tail waits there
 // for the row to be complete).  Every thread of the workgroup must call (barriers); `active` = tid < 64 * PW.
-template <int NC, int NVW, int PW, bool SC, class Hook = NoHook, bool WT = false>
+template <int NC, int NVW, int PW, bool SC, class Hook = NoHook>
 __device__ __forceinline__ void quant_row(int8_t* __restrict__ out, const _Float16* __restrict__ in,
                                           __half* __restrict__ sum_out, __half* __restrict__ scale_out, int hidden,
                                           float* sm, int tid, Hook ready = Hook()) {
@@ -210,8 +210,8 @@ __device__ __forceinline__ void quant_row(int8_t* __restrict__ out, const _Float
     float mx, s;
     reduce_max_sum<NVW, PW>(amax, sum, sm, sm + NVW, sum_out != nullptr, wave, lane, active, mx, s);
     if (tid == 0) {
-        qs_store_half<WT>(scale_out, mx / 127.0f);                      // fused_kernels.cu:72
-        if (sum_out) qs_store_half<WT>(sum_out, s);                     // :121
+        *scale_out = __float2half_rn(mx / 127.0f);                      // fused_kernels.cu:72
+        if (sum_out) *sum_out = __float2half_rn(s);                     // :121
     }
     const float mul = 127.0f / mx;                                      // :78 (unrounded fp32 amax)
     if (active) {
@@ -225,7 +225,7 @@ __device__ __forceinline__ void quant_row(int8_t* __restrict__ out, const _Float
                     float f[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
-                    qs_store_q8<WT>(out + i, f, mul);
+                    qs_store_q8(out + i, f, mul);
                 }
             }
     }
@@ -235,10 +235,7 @@ __device__ __forceinline__ void quant_row(int8_t* __restrict__ out, const _Float
 // ADD = false: no residual (plain general_norm_quant; `delta` unused, hidden_io read only).  sm: 4 * NVW floats of LDS.
 // SC: `delta` was published by other workgroups of this launch.  `ready` runs after the loads of hidden / gamma were
 // requested and before the first load of `delta`.
-// WT: the quantised outputs (int8 row, scale, sum) leave by write-through stores - they are read by other workgroups of the
-// SAME launch (row-op heads of the ring GEMM); the residual stream keeps its plain stores (a later launch reads it).
-template <int NC, int NVW, int PW, bool ADD, bool SC, class Hook = NoHook, class DeltaFn = FromRow, bool FULL = false,
-          bool WT = false>
+template <int NC, int NVW, int PW, bool ADD, bool SC, class Hook = NoHook, class DeltaFn = FromRow, bool FULL = false>
 __device__ __forceinline__ void norm_quant_row(int8_t* __restrict__ out, _Float16* __restrict__ hidden_io,
                                                const _Float16* __restrict__ delta, const _Float16* __restrict__ gamma,
                                                __half* __restrict__ sum_out, __half* __restrict__ scale_out, float eps,
@@ -387,14 +384,14 @@ __device__ __forceinline__ void norm_quant_row(int8_t* __restrict__ out, _Float1
                     float f[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = ln_val((float)v[j][c][e], mean, rstd_e, (float)g[j][c][e]);   // fp32, :315
-                    qs_store_q8<WT>(out + i, f, mul);
+                    qs_store_q8(out + i, f, mul);
                     if (ADD) *reinterpret_cast<h8*>(hidden_io + i) = v[j][c];
                 }
             }
     }
     if (tid == 0) {
-        qs_store_half<WT>(scale_out, mx / 127.f);                        // :322
-        if (sum_out) qs_store_half<WT>(sum_out, sm_row);                 // :323
+        *scale_out = __float2half_rn(mx / 127.f);                        // :322
+        if (sum_out) *sum_out = __float2half_rn(sm_row);                 // :323
     }
 }
 

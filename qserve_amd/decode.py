@@ -127,21 +127,6 @@ class W4A8Linear:
             fusedmod.add_residual_rms_norm_general_planes(out, hidden, planes, self.s1_scales, input_scales, weight, scaling, eps,
                                                           input_sum=out_sum)
 
-    def head_gemm(self, q_out, hidden, gamma, scaling, input_sum, eps, out, *, delta=None, prev=None, planes=None, p_ascales=None,
-                  p_a_ssums=None, silu_mul=False, tmp=None):
-        """(residual add + norm + quant) -> this projection (-> silu * mul) as one call (fused.add_norm_quant_gemm).  delta: the fp16
-        residual branch; or planes of the previous projection `prev` with the scale / sum its input was quantised with."""
-        assert self.bias is None
-        kw = dict(delta=delta, input_sum=input_sum, silu_mul=silu_mul, tmp=tmp)
-        if planes is not None:
-            kw.update(planes=planes, p_wscales=prev.s1_scales, p_ascales=p_ascales,
-                      p_w_szs=prev.s1_szeros if prev.group_size == -1 else None, p_a_ssums=p_a_ssums if prev.group_size == -1 else None)
-        if self.group_size == -1:
-            kw.update(w_szs=self.s1_szeros)
-        else:
-            kw.update(zeros=self.s2_zeros, scales_i8=self.s2_scales)
-        fusedmod.add_norm_quant_gemm(q_out, hidden, gamma, scaling, eps, self.qweight, self.s1_scales, out, **kw)
-
     def silu_mul(self, x, input_scales, input_sum, out_act, tmp):
         """gate_up projection + silu_and_mul as one op (qserve_amd.fused.gemm_silu_and_mul_*): out_act [T, n/2].  Only for
         a stacked gate_up weight without bias (the bias would have to be added between the two ops)."""
@@ -157,17 +142,13 @@ class W4A8Linear:
 class DecodeEngine:
     def __init__(self, cfg, batch, prompt_len, max_new, group_size=-1, int4_kv=True, device="cuda:0", seed=0,
                  tp_rank=0, tp_world=1, with_lm_head=True, fuse_pairs=True, weights=None, vocab_parallel=True, planes=None,
-                 direct_allreduce=None, heads=None):
+                 direct_allreduce=None):
         """weights: None = synthetic random-quantised tensors of the right shapes; otherwise this rank's tensors as
         qserve_amd.loader.load_llama_w4a8 returns them (checkpoint path)."""
         self.cfg, self.B, self.dev = cfg, batch, torch.device(device)
         # fuse_pairs: issue (residual add + layer norm) and (silu_and_mul + quant) as one launch each
         # (qserve_amd/fused.py: bit-identical to the op pairs; False = the reference's exact op-by-op sequence)
         self.fuse_pairs = fuse_pairs
-        # heads (round 5): the add + norm + quant launch in front of the qkv / gate_up GEMM runs as the ROW-OP HEAD of that GEMM launch
-        # (qserve_amd.fused.add_norm_quant_gemm: bit-identical; one launch where the library has the instantiation).  Default: on
-        # with the pair fusions on one GPU; QS_HEADS=0 turns it off (A/B)
-        self.heads = bool(fuse_pairs and tp_world == 1 and (heads if heads is not None else os.environ.get("QS_HEADS", "1") != "0"))
         self.tp_rank, self.tp_world = tp_rank, tp_world
         self.group_size, self.int4 = group_size, int4_kv
         H, Hkv = cfg["heads"], cfg["kv_heads"]
@@ -425,35 +406,22 @@ class DecodeEngine:
                 residual_add_(x, delta)
                 norm_quant(x, w)
 
-        # row-op heads (self.heads): the add + norm + quant launch that ENDS a sub-block is deferred and issued as the head of the
-        # GEMM launch it feeds (qkv of the next layer / gate_up of this one): `pending` = ("planes", projection, planes) or
-        # ("delta", tensor); a projection with a bias (or a tensor-parallel step) takes the ordinary two launches
-        def head_or_pair(lin, pending, w, out, silu_mul=False, tmp=None):
-            kind, a, b = pending
-            if self.heads and lin.bias is None:
-                if kind == "planes":
-                    lin.head_gemm(qa, h, w, self.q_scale, sums, cfg["eps"], out, prev=a, planes=b, p_ascales=self.q_scale,
-                                  p_a_ssums=self.q_sum, silu_mul=silu_mul, tmp=tmp)
-                else:
-                    lin.head_gemm(qa, h, w, self.q_scale, sums, cfg["eps"], out, delta=a, silu_mul=silu_mul, tmp=tmp)
-                return
-            if kind == "planes":
-                a.add_norm_quant_planes(qa, h, b, self.q_scale, self.q_sum, w, self.q_scale, cfg["eps"], sums)
-            else:
-                add_norm_quant(h, a, w)
-            if silu_mul:
-                lin.silu_mul(qa, self.q_scale, self.q_sum, out, tmp)
-            else:
-                lin(qa, self.q_scale, self.q_sum, out)
+        # (row-parallel GEMM, add + norm + quant) as K-slice planes: the GEMM leaves int32 partial sums per K slice, the row
+        # kernel that follows sums them and applies the GEMM's epilogue (bit-identical pair fusion; single GPU only - under
+        # tensor parallelism the all-reduce sits between the two)
+        def proj_add_norm_quant(lin, name, xq, x, w):
+            pl = self.planes.get(name) if fuse and self.tp_world == 1 else None
+            if pl is not None:
+                lin.planes(xq, pl)
+                lin.add_norm_quant_planes(qa, x, pl, self.q_scale, self.q_sum, w, self.q_scale, cfg["eps"], sums)
+                return True
+            return False
 
         nl = len(self.layers)
-        pending = None
         for li, L in enumerate(self.layers):
             if li == 0:
                 norm_quant(h, L["ln1"])
-                L["qkv"](qa, self.q_scale, self.q_sum, self.qkv_buf)
-            else:
-                head_or_pair(L["qkv"], pending, L["ln1"], self.qkv_buf)
+            L["qkv"](qa, self.q_scale, self.q_sum, self.qkv_buf)
             q, k, v = self.qkv_buf.split([self.H * 128, self.Hkv * 128, self.Hkv * 128], dim=-1)
             if fuse:         # attention + invoke_quant(_fuse_sum) of its output in one call (bit-identical pair fusion)
                 fusedmod.single_query_attention_quant(
@@ -470,11 +438,7 @@ class DecodeEngine:
                     fused_kernels.invoke_quant_fuse_sum(qo, attn, self.q_sum, self.q_scale)
                 else:
                     fused_kernels.invoke_quant(qo, attn, self.q_scale)
-            pl = self.planes.get("o") if fuse and self.tp_world == 1 else None
-            if pl is not None:
-                L["o"].planes(qo, pl)
-                pend2 = ("planes", L["o"], pl)
-            else:
+            if not proj_add_norm_quant(L["o"], "o", qo, h, L["ln2"]):
                 L["o"](qo, self.q_scale, self.q_sum, self.proj_out)
                 res = self.proj_out
                 if self.tp_world > 1:
@@ -482,14 +446,10 @@ class DecodeEngine:
                     res = self.proj_res
                     if L["o"].defer_bias and L["o"].bias is not None:
                         res += L["o"].bias                    # once, after the reduce
-                pend2 = ("delta", res, None)
-            if fuse and L["gate_up"].bias is None:     # (add + norm + quant ->) gate_up GEMM with the silu * mul epilogue
-                head_or_pair(L["gate_up"], pend2, L["ln2"], self.mlp_act, silu_mul=True, tmp=self.gate_up_buf)
+                add_norm_quant(h, res, L["ln2"])
+            if fuse and L["gate_up"].bias is None:     # gate_up GEMM with the silu * mul epilogue, then the quantiser
+                L["gate_up"].silu_mul(qa, self.q_scale, self.q_sum, self.mlp_act, self.gate_up_buf)
             else:
-                if pend2[0] == "planes":
-                    L["o"].add_norm_quant_planes(qa, h, pl, self.q_scale, self.q_sum, L["ln2"], self.q_scale, cfg["eps"], sums)
-                else:
-                    add_norm_quant(h, pend2[1], L["ln2"])
                 L["gate_up"](qa, self.q_scale, self.q_sum, self.gate_up_buf)
             if fuse and L["gate_up"].bias is not None:
                 fusedmod.silu_and_mul_quant(self.q_mlp, self.gate_up_buf, self.q_scale, sums)
@@ -500,11 +460,8 @@ class DecodeEngine:
                     fused_kernels.invoke_quant_fuse_sum(self.q_mlp, self.mlp_act, self.q_sum, self.q_scale)
                 else:
                     fused_kernels.invoke_quant(self.q_mlp, self.mlp_act, self.q_scale)
-            pl = self.planes.get("down") if fuse and self.tp_world == 1 and li + 1 < nl else None
-            if pl is not None:                                       # next layer's input norm finishes the GEMM from its planes
-                L["down"].planes(self.q_mlp, pl)
-                pending = ("planes", L["down"], pl)
-                continue
+            if li + 1 < nl and proj_add_norm_quant(L["down"], "down", self.q_mlp, h, self.layers[li + 1]["ln1"]):
+                continue                                             # (next layer's input norm done from the planes)
             L["down"](self.q_mlp, self.q_scale, self.q_sum, self.proj_out)
             res = self.proj_out
             if self.tp_world > 1:
@@ -513,7 +470,7 @@ class DecodeEngine:
                 if L["down"].defer_bias and L["down"].bias is not None:
                     res += L["down"].bias
             if li + 1 < nl:
-                pending = ("delta", res, None)                       # next layer's input norm (head of its qkv launch, or a launch of its own)
+                add_norm_quant(h, res, self.layers[li + 1]["ln1"])   # next layer's input norm
             else:
                 residual_add_(h, res)
         layernorm_ops.rms_norm(self.final, h, self.norm_w, cfg["eps"])

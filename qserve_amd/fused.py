@@ -7,8 +7,6 @@ they exist because at decode batch sizes each row kernel is a fixed ~5 us latenc
     silu_and_mul_quant(_fuse_sum)             ==  activation_ops.silu_and_mul ; fused_kernels.invoke_quant(_fuse_sum)
     single_query_attention_quant(_fuse_sum)   ==  fused_attention.single_query_attention ; fused_kernels.invoke_quant(_fuse_sum)
     gemm_silu_and_mul_per_chn / _per_group    ==  qgemm_w4a8_per_*.gemm_forward_cuda(gate_up) ; activation_ops.silu_and_mul
-    add_norm_quant_gemm                       ==  add_residual_rms_norm_general[_planes] ; the W4A8 GEMM (+ silu_and_mul) it feeds
-                                                  (row-op HEAD of the GEMM launch, include/qserve_amd.h)
 
 """
 import torch
@@ -203,63 +201,3 @@ def add_residual_rms_norm_general_planes(out, hidden, planes, wscales, ascales, 
             ptr(w_szs) if w_szs is not None else 0, ptr(ascales), ptr(a_ssums) if a_ssums is not None else 0, ptr(weight),
             ptr(input_sum) if input_sum is not None else 0, ptr(scaling), float(epsilon), T, hid, stream()),
             "fused.add_residual_rms_norm_general_planes")
-
-
-def add_norm_quant_gemm(q_out, hidden, gamma, scaling, epsilon, kernel, wscales, out, *, delta=None, planes=None, p_wscales=None,
-                        p_w_szs=None, p_ascales=None, p_a_ssums=None, input_sum=None, w_szs=None, zeros=None, scales_i8=None,
-                        silu_mul=False, tmp=None):
-    """One call == add_residual_rms_norm_general (delta) / add_residual_rms_norm_general_planes (planes + the previous GEMM's epilogue
-    operands p_*) writing (q_out, scaling, input_sum) and updating hidden, followed by the W4A8 GEMM q_out @ kernel^T -> out
-    (per-channel: w_szs + input_sum; per-group: zeros + scales_i8; silu_mul: out is [T, N/2]).  Bit-identical to the two calls; one
-    launch where the library has a row-op-head instantiation for the shape (qs_add_norm_quant_w4a8_gemm)."""
-    expect(q_out, torch.int8, "q_out")
-    expect(hidden, torch.float16, "hidden")
-    expect(kernel, torch.int8, "kernel")
-    expect(out, torch.float16, "out")
-    for n, t in (("gamma", gamma), ("scaling", scaling), ("wscales", wscales), ("delta", delta), ("p_wscales", p_wscales),
-                 ("p_w_szs", p_w_szs), ("p_ascales", p_ascales), ("p_a_ssums", p_a_ssums), ("input_sum", input_sum),
-                 ("w_szs", w_szs), ("tmp", tmp)):
-        if t is not None:
-            expect(t, torch.float16, n)
-    for n, t in (("zeros", zeros), ("scales_i8", scales_i8)):
-        if t is not None:
-            expect(t, torch.int8, n)
-    if (delta is None) == (planes is None):
-        raise RuntimeError("add_norm_quant_gemm: exactly one of delta / planes")
-    if (zeros is None) != (scales_i8 is None) or (zeros is None) == (w_szs is None):
-        raise RuntimeError("add_norm_quant_gemm: per-channel (w_szs) or per-group (zeros, scales_i8) operands")
-    if zeros is None and input_sum is None:
-        raise RuntimeError("add_norm_quant_gemm: the per-channel GEMM needs input_sum")
-    hid = hidden.size(-1)
-    T = hidden.numel() // hid
-    N = kernel.size(0)
-    if kernel.size(1) * 2 != hid or q_out.numel() != T * hid or not (hidden.is_contiguous() and q_out.is_contiguous()):
-        raise RuntimeError(f"add_norm_quant_gemm: kernel {tuple(kernel.shape)} / q_out {tuple(q_out.shape)} vs hidden [{T}, {hid}]")
-    if out.numel() != T * (N // 2 if silu_mul else N) or not out.is_contiguous():
-        raise RuntimeError(f"add_norm_quant_gemm: out has {out.numel()} elements, expected {T} x {N // 2 if silu_mul else N}")
-    if tmp is not None and tmp.numel() < T * N:
-        raise RuntimeError(f"add_norm_quant_gemm: tmp has {tmp.numel()} elements, needs {T} x {N}")
-    for n, t, need in (("gamma", gamma, hid), ("scaling", scaling, T), ("input_sum", input_sum, T), ("wscales", wscales, N),
-                       ("w_szs", w_szs, N), ("p_wscales", p_wscales, hid), ("p_w_szs", p_w_szs, hid), ("p_ascales", p_ascales, T),
-                       ("p_a_ssums", p_a_ssums, T)):
-        if t is not None and (t.numel() < need or not t.is_contiguous()):
-            raise RuntimeError(f"add_norm_quant_gemm: {n} needs {need} contiguous values, has {t.numel()}")
-    ks, pstride = 0, 0
-    if planes is not None:
-        expect(planes, torch.int32, "planes")
-        if planes.dim() != 3 or planes.size(1) != T or planes.size(2) != hid or not planes[0].is_contiguous() or p_wscales is None \
-                or p_ascales is None or (p_w_szs is None) != (p_a_ssums is None):
-            raise RuntimeError(f"add_norm_quant_gemm: planes {tuple(planes.shape)} / their epilogue operands vs hidden [{T}, {hid}]")
-        ks, pstride = planes.size(0), planes.stride(0)
-    elif delta.shape != hidden.shape or not delta.is_contiguous():
-        raise RuntimeError(f"add_norm_quant_gemm: delta {tuple(delta.shape)} vs hidden {tuple(hidden.shape)}")
-    if zeros is not None and (tuple(zeros.shape) != (hid // 128, N) or tuple(scales_i8.shape) != (hid // 128, N)):
-        raise RuntimeError("add_norm_quant_gemm: zeros / scales_i8 must be [K/128, N]")
-
-    def p(t):
-        return ptr(t) if t is not None else 0
-    with guard(out):
-        check(lib.qs_add_norm_quant_w4a8_gemm(
-            ptr(q_out), ptr(hidden), p(delta), p(planes), ks, pstride, p(p_wscales), p(p_w_szs), p(p_ascales), p(p_a_ssums), ptr(gamma),
-            p(input_sum), ptr(scaling), float(epsilon), T, hid, ptr(kernel), p(zeros), p(scales_i8), ptr(wscales), p(w_szs), ptr(out),
-            p(tmp), N, 1 if silu_mul else 0, stream()), "fused.add_norm_quant_gemm")

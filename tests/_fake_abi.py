@@ -209,27 +209,6 @@ def qs_add_residual_rms_norm_general_planes(out, hidden_io, planes, k_slices, pl
     return qs_add_residual_rms_norm_general(out, hidden_io, delta.ctypes.data, weight, input_sum, scaling, eps, T, hidden, stream)
 
 
-def qs_add_norm_quant_w4a8_gemm(q_out, hidden_io, delta, planes, k_slices, plane_stride, p_wscales, p_w_szs, p_ascales, p_a_ssums,
-                                gamma, input_sum, scaling, eps, T, hidden, kernel, zeros, scales_i8, wscales, w_szs, out, tmp, N,
-                                silu_mul, stream):
-    """The row-op head entry as the two calls it is defined to equal."""
-    CALLS.append(("qs_add_norm_quant_w4a8_gemm", "planes" if planes else "delta", T, hidden, N, silu_mul))
-    if delta:
-        rc = qs_add_residual_rms_norm_general(q_out, hidden_io, delta, gamma, input_sum, scaling, eps, T, hidden, stream)
-    else:
-        rc = qs_add_residual_rms_norm_general_planes(q_out, hidden_io, planes, k_slices, plane_stride, p_wscales, p_w_szs, p_ascales,
-                                                     p_a_ssums, gamma, input_sum, scaling, eps, T, hidden, stream)
-    if rc:
-        return rc
-    if zeros:
-        fn = qs_w4a8_per_group_gemm_silu_mul if silu_mul else qs_w4a8_per_group_gemm
-        args = (q_out, kernel, zeros, scales_i8, wscales, scaling, out) + ((tmp,) if silu_mul else ())
-    else:
-        fn = qs_w4a8_per_chn_gemm_silu_mul if silu_mul else qs_w4a8_per_chn_gemm
-        args = (q_out, kernel, wscales, scaling, w_szs, input_sum, out) + ((tmp,) if silu_mul else ())
-    return fn(*args, T, N, hidden, stream)
-
-
 def qs_silu_and_mul_quant(out, inp, input_sum, scale, T, d, stream):
     tmp = np.empty((T, d), np.float16)
     tmp[:] = ofused.silu_and_mul(_arr(inp, (T, 2 * d), np.float16))
@@ -313,7 +292,7 @@ SYMBOLS = {f.__name__: f for f in (
     qs_residual_add, qs_argmax_rows, qs_add_residual_rms_norm_general, qs_silu_and_mul_quant, qs_compute_padding_offsets,
     qs_w4a8_gemm_planes_plan, qs_w4a8_per_chn_gemm_planes, qs_w4a8_per_group_gemm_planes, qs_add_residual_rms_norm_general_planes,
     qs_apply_bias_rope_update_kv_cache, qs_single_query_attention, qs_single_query_attention_quant,
-    qs_flash_attn_varlen_fwd, qs_add_norm_quant_w4a8_gemm)}
+    qs_flash_attn_varlen_fwd)}
 
 
 class _NoGuard:
