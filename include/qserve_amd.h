@@ -127,8 +127,9 @@ int qs_w8a8_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscal
  *   4100 + 100*(k_slices-1) + 10*m_tiles + units ... forced ring geometry;
  *   5000 + bits ... A/B switches of the ring kernel (1: weight DMA without the non-temporal hint; 256 * d: ring depth d;
  *                   [QS_TIMING builds: 32 / 64 no MFMA / no operand reads]); sticky until reset with 5000;
- *   3200 + 10*p + o ... tiled kernel A/B, sticky until reset with 3200: tile order o (0 super-tiles, 1 / 2 token- /
- *                   channel-fastest bands); p = 1 one workgroup per tile instead of one per CU walking the tiles,
+ *   3200 + 10*p + o ... tiled kernel A/B, sticky until reset with 3200: tile order o (0 super-tiles with the XCD-aware 4 x 8
+ *                   placement inside a super-tile, 3 super-tiles without it, 1 / 2 token- / channel-fastest bands); p = 1 one
+ *                   workgroup per tile instead of one per CU walking the tiles,
  *                   p = 2 three workgroups walk all tiles (tests of the tile-to-tile hand-over);
  *   3301 / 3300 ... qs_w4a8_*_gemm_silu_mul always as two launches / default (sticky);
  *   3100 + bits ... [QS_TIMING builds only] kernel parts of the tiled kernel switched off. */

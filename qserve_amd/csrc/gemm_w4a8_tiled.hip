@@ -116,6 +116,15 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
             }
             bm = srow * sm + in_st % hgt;
             bn = scol * sn + in_st / hgt;
+            if (order != 3 && hgt == sm && scol < full_n) {
+                // XCD-aware placement inside a full 16 x 16 super-tile (round 5; order 3 = without it, A/B): workgroup b runs on
+                // XCD b % 8 (observed; speed only), so the 32 tiles of one XCD form a 4 x 8 block - 4 activation + 8 weight tiles
+                // through that L2 (8 MB at K = 4096) instead of 2 + 16 (10 MB).  In-run: per-channel +0.6 ... +1.6 % on the prompt
+                // shapes, 4096^3 56.4 -> 54.2 us; per-group unchanged (profiles/round5_tile_order.txt)
+                const int x = in_st & 7, j = in_st >> 3;
+                bm = srow * sm + 4 * (x & 3) + (j & 3);
+                bn = scol * sn + 8 * (x >> 2) + (j >> 2);
+            }
             (void)wid;
         }
     };
