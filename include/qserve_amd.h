@@ -169,7 +169,10 @@ int qs_w4a8_gemm_plan(int per_group, int M, int N, int K, int* plan5);
  * Page layout (kvCacheUtils.h:47-126): [Hkv][tokens_per_block][Dh'] data, then half scale[Hkv][tpb], then
  * half zero[Hkv][tpb]; Dh' = size_per_token / Hkv bytes.
  * Side effect: quantises the new token's rotated K and V into the page of position length-1.
- * Supported (what the reference instantiates): Dh = 128, tokens_per_block = 64, neox style, kv_cache_with_zeros.
+ * Supported (what the reference instantiates): Dh = 128, tokens_per_block = 64, kv_cache_with_zeros.
+ * neox_rotary_style is accepted and has no effect: the reference never forwards it (fused_attention.cpp:109 is commented out;
+ * update_kv_cache.cu:57 hard-codes kROPE_GPT_NEOX) - RoPE is always the NeoX pairing (d, d + 64).  Likewise the op-level
+ * `alibi_slopes` argument is checked and dropped by the reference (fused_attention.cpp:91,193-199) and by both mirrors here.
  * ---------------------------------------------------------------------------------------------------------- */
 int qs_single_query_attention(const void* q, const void* k, const void* v, const int64_t* kv_pointers,
                               const int32_t* length_per_sample, void* out, int batch, int num_heads,

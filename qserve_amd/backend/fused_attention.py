@@ -8,7 +8,8 @@ def single_query_attention(q, k, v, kv_pointers, length_per_sample, alibi_slopes
                            tokens_per_block, size_per_token, timestep, rotary_embedding_dim, rotary_base,
                            neox_rotary_style, int4_kv_cache, kv_cache_with_zeros):
     """fused_attention.h:13-28.  q [B,H,Dh] / k,v [B,Hkv,Dh] fp16 views of the qkv buffer; kv_pointers int64
-    [B,2,max_blocks] of page addresses; returns a fresh contiguous fp16 [B,H,Dh] (torch::empty_like(q))."""
+    [B,2,max_blocks] of page addresses; returns a fresh contiguous fp16 [B,H,Dh] (torch::empty_like(q)).
+    `alibi_slopes` and `neox_rotary_style` are accepted and have no effect - as in the reference (see below)."""
     for n, t in (("q", q), ("k", k), ("v", v)):
         expect(t, torch.float16, n, contiguous=False)
     expect(kv_pointers, torch.int64, "kv_pointers")
@@ -24,7 +25,12 @@ def single_query_attention(q, k, v, kv_pointers, length_per_sample, alibi_slopes
         if tuple(length_per_sample.shape) != (batch,):
             raise RuntimeError("length_per_sample must have shape (batch_size)")
     if alibi_slopes is not None:
-        raise RuntimeError("alibi_slopes is not supported (the W4A8KV4 models never pass it)")
+        # validated and then IGNORED, exactly as the reference does: fused_attention.cpp:193-199 checks device / shape /
+        # dtype, set_params never stores the pointer (`// params.linear_bias_slopes = alibi_slopes_ptr;`, :91) and the
+        # kernel's linear-bias lines are commented out (decoderMaskedMultiheadAttentionTemplate.hpp:1604-1615)
+        expect(alibi_slopes, torch.float32, "alibi_slopes")
+        if tuple(alibi_slopes.shape) != (nheads,):
+            raise RuntimeError("alibi_slopes must have shape (nheads)")
     out = torch.empty((q.size(0), nheads, headdim), dtype=q.dtype, device=q.device)
     with guard(q):
         check(lib.qs_single_query_attention(ptr(q), ptr(k), ptr(v), ptr(kv_pointers), ptr(length_per_sample), ptr(out),

@@ -644,9 +644,12 @@ extern "C" int qs_single_query_attention(const void* q, const void* k, const voi
     QS_REQUIRE(q && k && v && kv_pointers && out, "single_query_attention: null pointer");
     QS_REQUIRE(batch >= 0 && num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
                "single_query_attention: bad head counts H=%d Hkv=%d", num_heads, num_kv_heads);
-    if (head_dim != 128 || rotary_embedding_dim != 128 || tokens_per_block != 64 || !neox_rotary_style ||
-        !kv_cache_with_zeros) {
-        qs_set_error("single_query_attention: only head_dim=128, rotary_dim=128, tokens_per_block=64, NeoX RoPE and "
+    // neox_rotary_style is accepted and has NO effect, as in the reference: set_params leaves the field unset
+    // (fused_attention.cpp:109, commented out) and the kernel's only rotary branch is the NeoX one
+    // (decoderMaskedMultiheadAttentionTemplate.hpp:1136-1215: the GPT-J case is commented out).
+    (void)neox_rotary_style;
+    if (head_dim != 128 || rotary_embedding_dim != 128 || tokens_per_block != 64 || !kv_cache_with_zeros) {
+        qs_set_error("single_query_attention: only head_dim=128, rotary_dim=128, tokens_per_block=64 and "
                      "zero-point KV caches are supported (the variants the reference instantiates)");
         return QS_ENOSUP;
     }
@@ -732,8 +735,11 @@ extern "C" int qs_apply_bias_rope_update_kv_cache(void* qkv, const int32_t* seq_
     QS_REQUIRE(qkv && seq_lens, "apply_bias_rope_update_kv_cache: null pointer");
     QS_REQUIRE(head_num > 0 && kv_head_num > 0 && seq_len > 0 && batch >= 0,
                "apply_bias_rope_update_kv_cache: bad sizes");
-    if (rotary_embedding_dim != 128 || tokens_per_block != 64 || !neox_rotary_style || !kv_cache_with_zeros) {
-        qs_set_error("apply_bias_rope_update_kv_cache: only head_dim=128, tokens_per_block=64, NeoX RoPE and "
+    // neox_rotary_style: accepted, no effect - the reference hard-codes PositionEmbeddingType::kROPE_GPT_NEOX whatever the
+    // flag says (update_kv_cache.cu:57)
+    (void)neox_rotary_style;
+    if (rotary_embedding_dim != 128 || tokens_per_block != 64 || !kv_cache_with_zeros) {
+        qs_set_error("apply_bias_rope_update_kv_cache: only head_dim=128, tokens_per_block=64 and "
                      "zero-point KV caches are supported");
         return QS_ENOSUP;
     }

@@ -112,7 +112,13 @@ torch::Tensor single_query_attention(const torch::Tensor q, const torch::Tensor 
         TORCH_CHECK(l.dim() == 1 && l.size(0) == batch, "length_per_sample must have shape (batch_size)");
         lens = l.data_ptr<int32_t>();
     }
-    TORCH_CHECK(!alibi_slopes_.has_value(), "alibi_slopes is not supported (the W4A8KV4 models never pass it)");
+    if (alibi_slopes_.has_value()) {
+        // checked, then ignored - the reference's behaviour (fused_attention.cpp:193-199 checks, :91 never stores the pointer,
+        // decoderMaskedMultiheadAttentionTemplate.hpp:1604-1615 is commented out)
+        const auto& a = alibi_slopes_.value();
+        need(a, at::kFloat, "alibi_slopes");
+        TORCH_CHECK(a.dim() == 1 && a.size(0) == nheads, "alibi_slopes must have shape (nheads)");
+    }
     const DeviceGuard guard(q.device());       // fused_attention.cpp:203
     torch::Tensor out = torch::empty({q.size(0), nheads, headdim}, q.options());
     QS_CALL(qs_single_query_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), kv_pointers.data_ptr<int64_t>(), lens,

@@ -19,6 +19,9 @@ case $w in
 mb5)
   echo "=== microbench_mfma5"
   hipcc -O3 --offload-arch=gfx950 scripts/microbench_mfma5.hip -o /tmp/mb_mfma5 2>/dev/null && timeout 120 /tmp/mb_mfma5 | tee gpurun_out/${TAG}_mb_mfma5.txt ;;
+mbvalu)
+  echo "=== microbench_valu"
+  hipcc -O3 --offload-arch=gfx950 -Wno-unused-value scripts/microbench_valu.hip -o /tmp/mb_valu 2>/dev/null && timeout 120 /tmp/mb_valu | tee gpurun_out/${TAG}_mb_valu.txt ;;
 tests|tests_record)
   echo "=== pytest -m gpu ($w)"
   if [ $w = tests_record ]; then export QS_PARITY_RECORD=1; fi

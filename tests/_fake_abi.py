@@ -227,7 +227,7 @@ def qs_apply_bias_rope_update_kv_cache(qkv, seq_lens, padding_offset, kv_pointer
                                        seq_len, tokens_per_block, size_per_token, rot_dim, base, max_pos, neox, int4,
                                        with_zeros, stream):
     CALLS.append(("qs_apply_bias_rope_update_kv_cache", num_tokens, batch, H, Hkv, seq_len, int4))
-    assert tokens_per_block == 64 and rot_dim == 128 and neox and with_zeros
+    assert tokens_per_block == 64 and rot_dim == 128 and with_zeros      # neox: no effect (update_kv_cache.cu:57)
     x = _arr(qkv, (num_tokens, (H + 2 * Hkv) * 128), np.float16)
     sl = _arr(seq_lens, (batch,), np.int32)
     pad = _arr(padding_offset, (num_tokens,), np.int32)
@@ -246,7 +246,7 @@ def qs_single_query_attention(q, k, v, kv_pointers, length_per_sample, out, batc
                               max_blocks, memory_max_seqlen, tokens_per_block, size_per_token, timestep, rot_dim, base,
                               neox, int4, with_zeros, stream):
     CALLS.append(("qs_single_query_attention", batch, H, Hkv, max_blocks, timestep, int4))
-    assert head_dim == 128 and tokens_per_block == 64 and rot_dim == 128 and neox and with_zeros
+    assert head_dim == 128 and tokens_per_block == 64 and rot_dim == 128 and with_zeros   # neox: no effect
     assert size_per_token == Hkv * (64 if int4 else 128)
     qa = _strided_rows(q, batch, q_stride0, H * 128, np.float16).reshape(batch, H, 128)
     ka = _strided_rows(k, batch, kv_stride0, Hkv * 128, np.float16).reshape(batch, Hkv, 128)

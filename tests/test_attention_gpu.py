@@ -295,6 +295,52 @@ def test_rejects_what_reference_rejects(gpu):
                                   512, 1, 128, ROPE, True, True, True)
 
 
+@pytest.mark.parametrize("form", ["ctypes", "ext"])
+@pytest.mark.parametrize("int4", [True, False], ids=["kv4", "kv8"])
+def test_alibi_slopes_and_rotary_style_are_accepted_and_inert_like_the_reference(gpu, int4, form):
+    """The reference accepts `alibi_slopes` (checked: device, shape (nheads), fp32 - fused_attention.cpp:193-199) and
+    `neox_rotary_style = False` and uses NEITHER: set_params never stores them (fused_attention.cpp:91,109 are commented out), the
+    kernel's linear-bias lines and its GPT-J rotary case are commented out (Template.hpp:1136-1158,1604-1615) and the prefill
+    writer hard-codes kROPE_GPT_NEOX (update_kv_cache.cu:57).  Same inputs, same results: both boundary forms take the arguments
+    and produce bit-identical pages and outputs; a wrongly shaped / typed alibi tensor is rejected as the reference rejects it."""
+    if form == "ext":
+        import qserve_backend_ext
+        qserve_backend_ext.load()
+        fa = qserve_backend_ext.fused_attention
+    else:
+        import qserve_backend.fused_attention as fa
+    B, H, Hkv = 3, 8, 2
+    pr = synth.attention_problem(B, H, Hkv, [70, 131, 200], seed=11)
+    size_per_token = Hkv * (64 if int4 else 128)
+    seq = (pr["lengths"] - 1).astype(np.int32)
+    hist = np.concatenate(pr["hist"])
+    cu = np.concatenate([[0], np.cumsum(seq)]).astype(np.int32)
+    results = []
+    for neox, slopes in ((True, None), (False, torch.linspace(0.1, 0.9, H, dtype=torch.float32, device=gpu))):
+        dpool = DevPools(pr["nblocks"], Hkv, int4, gpu)
+        ptrs = dpool.pointers(pr["tables"])
+        pad = fa.compute_padding_offsets(dev(cu), int(seq.max()), hist.shape[0])
+        qkv = dev(hist)
+        fa.apply_bias_rope_update_kv_cache(qkv, dev(seq), pad, ptrs, H, Hkv, int(seq.max()), 64, size_per_token, 128, ROPE,
+                                           8192, neox, int4, True)
+        buf = dev(np.concatenate([pr["q"].reshape(B, -1), pr["k"].reshape(B, -1), pr["v"].reshape(B, -1)], axis=1))
+        q, k, v = buf.split([H * 128, Hkv * 128, Hkv * 128], dim=-1)
+        out = fa.single_query_attention(q.reshape(B, H, 128), k.reshape(B, Hkv, 128), v.reshape(B, Hkv, 128), ptrs,
+                                        dev(pr["lengths"]), slopes, 8192, 64, size_per_token, int(pr["lengths"].max()), 128,
+                                        ROPE, neox, int4, True)
+        torch.cuda.synchronize()
+        results.append((qkv.clone(), dpool.k.clone(), dpool.v.clone(), out.clone()))
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+    q0 = torch.zeros((B, H, 128), dtype=torch.float16, device=gpu)
+    k0 = torch.zeros((B, Hkv, 128), dtype=torch.float16, device=gpu)
+    ptrs = DevPools(pr["nblocks"], Hkv, int4, gpu).pointers(pr["tables"])
+    for bad in (torch.zeros(H + 1, dtype=torch.float32, device=gpu), torch.zeros(H, dtype=torch.float16, device=gpu)):
+        with pytest.raises(RuntimeError):
+            fa.single_query_attention(q0, k0, k0, ptrs, dev(pr["lengths"]), bad, 8192, 64, size_per_token,
+                                      int(pr["lengths"].max()), 128, ROPE, True, int4, True)
+
+
 @pytest.mark.parametrize("int4", [True, False])
 @pytest.mark.parametrize("nsplit", [1, 2, 3, 7])
 def test_decode_split_kv_forced(gpu, nsplit, int4):

@@ -248,3 +248,45 @@ def test_unchanged_reference_model_runs_on_the_mirror(ref, monkeypatch, group_si
         assert names.count("qs_single_query_attention") == nl and names.count("qs_flash_attn_varlen_fwd") == 0
         sqa = [c for c in calls if c[0] == "qs_single_query_attention"][0]
         assert sqa[1:] == (B, CFG["heads"], Hkv, mb, max(lens), int(int4))
+
+
+def test_mirror_takes_alibi_slopes_and_rotary_style_and_ignores_them_like_the_reference(monkeypatch):
+    """fused_attention.cpp:91,109: the reference's set_params leaves `linear_bias_slopes` and `neox_rotary_style` unset (both
+    lines are commented out), update_kv_cache.cu:57 hard-codes the NeoX pairing: the arguments are legal and inert.  The mirror
+    forwards the same calls to the C ABI with and without them (host simulator), and rejects an ill-shaped alibi tensor as
+    fused_attention.cpp:193-199 does."""
+    from oracle import synth
+    _fake_abi.install(monkeypatch)
+    import qserve_backend.fused_attention as fa
+    B, H, Hkv = 2, 4, 2
+    pr = synth.attention_problem(B, H, Hkv, [9, 70], seed=4)
+    pb = kvattn.page_bytes(Hkv, 128, True)
+    seq = (pr["lengths"] - 1).astype(np.int32)
+    hist = np.concatenate(pr["hist"])
+    cu = np.concatenate([[0], np.cumsum(seq)]).astype(np.int32)
+    outs = []
+    for neox, slopes in ((True, None), (False, torch.linspace(0.5, 2.0, H, dtype=torch.float32))):
+        kp = torch.zeros((pr["nblocks"], pb), dtype=torch.uint8)
+        vp = torch.zeros((pr["nblocks"], pb), dtype=torch.uint8)
+        t = torch.from_numpy(pr["tables"].astype(np.int64))
+        ptrs = torch.empty_like(t)
+        ptrs[:, 0] = kp.data_ptr() + t[:, 0] * pb
+        ptrs[:, 1] = vp.data_ptr() + t[:, 1] * pb
+        qkv = torch.from_numpy(hist.copy())
+        pad = fa.compute_padding_offsets(torch.from_numpy(cu), int(seq.max()), hist.shape[0])
+        fa.apply_bias_rope_update_kv_cache(qkv, torch.from_numpy(seq), pad, ptrs, H, Hkv, int(seq.max()), 64, Hkv * 64, 128,
+                                           5e5, 8192, neox, True, True)
+        buf = torch.from_numpy(np.concatenate([pr["q"].reshape(B, -1), pr["k"].reshape(B, -1), pr["v"].reshape(B, -1)], 1))
+        q, k, v = buf.split([H * 128, Hkv * 128, Hkv * 128], dim=-1)
+        o = fa.single_query_attention(q.reshape(B, H, 128), k.reshape(B, Hkv, 128), v.reshape(B, Hkv, 128), ptrs,
+                                      torch.from_numpy(pr["lengths"]), slopes, 8192, 64, Hkv * 64, int(pr["lengths"].max()),
+                                      128, 5e5, neox, True, True)
+        outs.append((qkv, kp, vp, o))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    q0 = torch.zeros((B, H, 128), dtype=torch.float16)
+    k0 = torch.zeros((B, Hkv, 128), dtype=torch.float16)
+    for bad in (torch.zeros(H + 1, dtype=torch.float32), torch.zeros(H, dtype=torch.float64)):
+        with pytest.raises(RuntimeError):
+            fa.single_query_attention(q0, k0, k0, ptrs, torch.from_numpy(pr["lengths"]), bad, 8192, 64, Hkv * 64, 70, 128, 5e5,
+                                      True, True, True)
