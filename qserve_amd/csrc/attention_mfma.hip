@@ -1024,6 +1024,30 @@ float* qs_split_workspace(size_t bytes, hipStream_t st) {
     return w.p;
 }
 size_t qs_split_workspace_capacity() { return SPLIT_WS_BYTES; }
+
+// Split-KV factor of the matrix-core decode kernels (KV4: this file, KV8: attention_mfma8.hip): the number of workgroups a
+// (sequence, KV head) pair's page range is cut into.  Cost model fitted to a sweep on the MI355X (profiles/round5_split_sweep*.txt:
+// 1 .. 48 sequences x 8 KV heads, 1 030 .. 7 700 tokens, 1 .. 32 splits; mean regret 0.7 %, worst 10 %, against the forced best;
+// the round-2 rule "aim at >= 512 workgroups" it replaces: 8 % / 39 %):
+//   time(n) = rounds * F + max(rounds * pages / n * t_cu,  blocks * pages * t_hbm) + merge(n)
+// rounds = ceil(blocks * n / 256): workgroups land on the 256 CUs round-robin and a CU streams at its own request budget whatever
+// the number of resident workgroups, so 320 workgroups take as long as 512; F = a workgroup's head + tail; t_cu = one CU's time
+// per page (64 tokens of K and V), t_hbm = the chip's; merge = the second launch (boundary + n partials per head).
+// ns / ps units, integer arithmetic (the plan is part of the ABI: tests/test_dispatch_plan.py pins it).
+int qs_attn_choose_splits(int blocks, int pages, int kv8) {
+    if (blocks >= 512 || pages < 4) return 1;
+    const long F = kv8 ? 5000 : 4000, t_cu = kv8 ? 450 : 340, t_hbm_ps = kv8 ? 2540 : 1330;
+    long best = -1;
+    int best_n = 1;
+    for (int n = 1; n <= 8; ++n) {
+        if (n > 1 && pages / n < 2) break;
+        const long rounds = ((long)blocks * n + 255) / 256;
+        const long per_cu = rounds * pages * t_cu / n, chip = (long)blocks * pages * t_hbm_ps / 1000;
+        const long cost = rounds * F + (per_cu > chip ? per_cu : chip) + (n > 1 ? 2500 + 300 * n : 0);
+        if (best < 0 || cost < best) best = cost, best_n = n;
+    }
+    return best_n;
+}
 // timing tool (scripts/trace_attn.py): copy the first `bytes` of the split workspace (the EXP & 32 timeline stamps) to dst
 extern "C" int qs_debug_copy_split_workspace(void* dst, size_t bytes) {
     int dev = 0;
@@ -1091,17 +1115,10 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
     }
     int tab_len = 0;
     const float2* tab = g_qs_attn_plan.active ? nullptr : qs_rope_table(base, max_pos, st, &tab_len);
-    // split-KV when (sequences x kv heads) cannot fill 256 CUs twice: aim at >= 512 workgroups, keep >= NW pages each
+    // split-KV (qs_attn_choose_splits above)
     const int blocks = (int)(grid.x * grid.y);
     const int pages_max = (timestep + PAGE_TOK - 1) / PAGE_TOK;
-    int nsplit = 1;
-    if (force_split > 0) nsplit = force_split;
-    else if (blocks < 384) {
-        nsplit = (512 + blocks - 1) / blocks;
-        const int cap = pages_max / (2 * NW) > 1 ? pages_max / (2 * NW) : 1;   // >= 2 pages per wave and split
-        if (nsplit > cap) nsplit = cap;
-        if (nsplit > 32) nsplit = 32;
-    }
+    int nsplit = force_split > 0 ? force_split : qs_attn_choose_splits(blocks, pages_max, 0);
     if (g_qs_attn_plan.active) {
         g_qs_attn_plan.family = 1, g_qs_attn_plan.nsplit = nsplit, g_qs_attn_plan.waves = NW;
         return QS_OK;

@@ -102,11 +102,20 @@ def test_attention_headline_config_is_one_workgroup_per_sequence_and_kv_head():
 
 
 def test_attention_small_batches_split_the_context():
+    # round 5: the split factor comes from a cost model fitted to a sweep on the MI355X (profiles/round5_split_sweep*.txt):
+    # workgroups land on the 256 CUs round-robin and a CU streams at its own request budget, so the model fills the chip ONCE
+    # (64 pairs -> 3-4 splits) instead of twice (the round-2 rule: 8 splits, 3-15 % slower at these sizes)
     p = attention_plan(8, 32, 8, 129, 8192, int4_kv_cache=False)        # BASELINE configs[4]: 64 workgroups -> split
-    assert p["family"] == "mfma_kv8" and p["waves"] == 4 and p["kv_splits"] == 8
+    assert p["family"] == "mfma_kv8" and p["waves"] == 4 and p["kv_splits"] == 3
+    assert attention_plan(8, 32, 8, 121, 7700)["kv_splits"] == 4       # its KV4 twin: measured 19.7 us (8 splits: 22.7)
     p = attention_plan(1, 32, 8, 129, 8192)
-    assert p["family"] == "mfma_kv4" and 2 <= p["kv_splits"] <= 32
-    assert attention_plan(1, 32, 8, 4, 200)["kv_splits"] == 1          # too short to give every wave two pages
+    assert p["family"] == "mfma_kv4" and p["kv_splits"] == 8            # 8 pairs: the merge's cost caps the factor
+    assert attention_plan(1, 32, 8, 4, 200)["kv_splits"] == 1          # too short
+    assert attention_plan(16, 32, 8, 65, 4096)["kv_splits"] == 2       # 128 pairs x 2 = 256 workgroups
+    assert attention_plan(32, 32, 8, 65, 4096)["kv_splits"] == 1       # 256 pairs: one round, no merge (was 2: +11 %)
+    assert attention_plan(24, 32, 8, 121, 7700)["kv_splits"] == 1      # 192 pairs: a second workgroup on some CUs doubles their time
+    assert attention_plan(48, 32, 8, 121, 7700)["kv_splits"] == 2      # 384 pairs = 1.5 rounds -> 768 = 3 full rounds (-9 %)
+    assert attention_plan(48, 32, 8, 17, 1030)["kv_splits"] == 1
 
 
 def test_attention_wide_page_tables_take_the_valu_kernel():
