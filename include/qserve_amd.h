@@ -21,9 +21,11 @@
  *     is a fixed-size allocation made lazily on a first EAGER call (never while the stream is being captured into a
  *     graph: such a call runs the variant that needs no scratch) and is NEVER freed, moved or grown afterwards, so a
  *     hipGraph that captured its address stays valid for the life of the process.  Requests beyond the fixed capacity
- *     fall back to the un-split variants.  The scratch areas are per device (the CURRENT device of the calling thread):
- *     launches that use them (split-KV attention, K-sliced GEMMs, the split argmax, the fused attention quantiser's
- *     hand-over) must not run concurrently on different streams of one device (the reference's engine is single-stream).
+ *     fall back to the un-split variants.  The scratch areas exist once per device (the CURRENT device of the calling thread),
+ *     shared by every stream: launches that use them (split-KV attention, K-sliced GEMMs, the split argmax, the fused attention
+ *     quantiser's hand-over) must not run concurrently on different streams of one device (the reference's engine is
+ *     single-stream) - UNLESS the extra streams were given scratch of their own with qs_stream_scratch_bind() (below: up to 7
+ *     streams per device; launches issued on, or captured on, a bound stream use that stream's areas).
  *     A launch that is ABORTED mid-way (device reset) may leave the K-slice slabs without their sentinel or an exchange row
  *     half-tagged: call qs_device_reset() before the library is used again.  The in-launch waits on these areas are BOUNDED
  *     (round 5): a violated assumption yields a status bit (qs_device_status) and an invalid result, never a hung GPU.
@@ -311,8 +313,8 @@ int qs_comm_destroy(void* comm);
 /* ------------------------------------------------------------------------------------------------------------
  * Bounded in-launch waits (no reference counterpart).  Two launches of this library contain a cross-workgroup hand-off that
  * polls inside the launch: the K-slice seam of the decode W4A8 GEMMs and the finisher of qs_single_query_attention_quant.  They
- * rely on in-order workgroup dispatch and on single-stream use of the per-device scratch (see the header comment).  Every such
- * wait is BOUNDED: after ~1e6 polls (seconds) the waiting wave gives up, sets a bit in a per-device error word and finishes
+ * rely on in-order workgroup dispatch and on one-stream-at-a-time use of a scratch set (see the header comment).  Every such
+ * wait is BOUNDED: after ~1e6 polls (seconds) the waiting wave gives up, sets a bit in the error word of its scratch set and finishes
  * the launch with what it has - results of that launch are invalid, the GPU is not hung.
  *   qs_device_status   error_bits = OR of 1 (K-slice seam gave up), 2 (attention + quant hand-over gave up) on the CURRENT
  *                      device since the last reset; blocking (a device-to-host copy behind the work launched so far) - call it
@@ -329,6 +331,20 @@ int qs_comm_destroy(void* comm);
 int qs_device_status(int* error_bits);
 int qs_device_reset(void);
 int qs_debug_inject_fault(int what);
+
+/* Per-stream scratch (no reference counterpart; the reference's engine is single-stream).  By default every stream of a device
+ * shares ONE set of the library's scratch areas, so scratch-using launches must not overlap across streams.  A caller that runs
+ * the library on several streams of one device concurrently binds the extra streams first:
+ *   qs_stream_scratch_bind    gives `stream` (on the calling thread's current device) its own split-K / K-slice slabs, split-KV
+ *                             partials, hand-over rows and argmax keys (~130 MiB, allocated HERE - call it outside stream capture,
+ *                             before the stream's first launch or capture; idempotent).  Launches issued or captured on the stream
+ *                             use these areas from then on; qs_device_status / qs_device_reset cover every bound stream.
+ *                             QS_ENOSUP when the device's 7 slots are taken, QS_EINVAL while the stream is capturing.
+ *   qs_stream_scratch_unbind  forgets the binding (the stream falls back to the shared areas); the slot's memory is kept and
+ *                             handed to the next bind on this device, so graphs captured on the stream stay valid - but they
+ *                             then share the areas with that next stream. */
+int qs_stream_scratch_bind(qs_stream_t stream);
+int qs_stream_scratch_unbind(qs_stream_t stream);
 
 /* Device self-test (tests/test_fused_gpu.py): the DPP / permlane wave reductions every row kernel uses round exactly like
  * the shuffle butterfly they replace.  in: float [n] (n % 64 == 0); out: float [n/64][4] = {sum, sum by shuffles, max, max

@@ -53,6 +53,8 @@ SIGNATURES = {
     "qs_device_status": (_i, [C.POINTER(C.c_int)]),
     "qs_device_reset": (_i, []),
     "qs_debug_inject_fault": (_i, [_i]),
+    "qs_stream_scratch_bind": (_i, [_vp]),
+    "qs_stream_scratch_unbind": (_i, [_vp]),
     "qs_comm_create": (_i, [_i, _i, _i64, C.POINTER(C.c_void_p), _vp]),
     "qs_comm_connect": (_i, [_vp, _vp]),
     "qs_comm_connect_local": (_i, [_vp, C.POINTER(C.c_void_p)]),

@@ -998,7 +998,7 @@ constexpr size_t SPLIT_WS_BYTES = (size_t)32 << 20;   // heuristic needs < 1024 
 struct SplitWs {
     float* p = nullptr;
 };
-SplitWs g_ws[16];
+SplitWs g_ws[16][QS_MAX_STREAM_SLOTS];   // [device][scratch slot] (common.h)
 }  // namespace
 // second phase of split-KV, shared with the KV8 kernel (attention_mfma8.hip)
 void qs_launch_attention_merge(const float* ws, _Float16* out, int H, int Hkv, int G, int nsplit, int batch,
@@ -1008,7 +1008,7 @@ void qs_launch_attention_merge(const float* ws, _Float16* out, int H, int Hkv, i
 float* qs_split_workspace(size_t bytes, hipStream_t st) {
     int dev = 0;
     if (bytes > SPLIT_WS_BYTES || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    SplitWs& w = g_ws[dev];
+    SplitWs& w = g_ws[dev][qs_scratch_slot(st)];
     if (w.p) return w.p;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
@@ -1051,8 +1051,8 @@ int qs_attn_choose_splits(int blocks, int pages, int kv8) {
 // timing tool (scripts/trace_attn.py): copy the first `bytes` of the split workspace (the EXP & 32 timeline stamps) to dst
 extern "C" int qs_debug_copy_split_workspace(void* dst, size_t bytes) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !g_ws[dev].p || bytes > SPLIT_WS_BYTES) return QS_EINVAL;
-    return (int)hipMemcpy(dst, g_ws[dev].p, bytes, hipMemcpyDeviceToDevice);
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !g_ws[dev][0].p || bytes > SPLIT_WS_BYTES) return QS_EINVAL;
+    return (int)hipMemcpy(dst, g_ws[dev][0].p, bytes, hipMemcpyDeviceToDevice);      // (the shared slot: the trace tools bind nothing)
 }
 
 // workspace of the attention + quant fusion: one fixed allocation per device - QS_ATTNQ_CAP generation words followed by
@@ -1060,12 +1060,13 @@ extern "C" int qs_debug_copy_split_workspace(void* dst, size_t bytes) {
 // (generation 0, every tag stale), never freed; nullptr for larger batches or while it cannot be allocated (first use inside
 // a stream capture): the caller then runs the un-fused pair
 namespace {
-unsigned* g_qcounters[16];
+unsigned* g_qcounters[16][QS_MAX_STREAM_SLOTS];
 }
 unsigned* qs_attn_quant_counters(hipStream_t st, int batch) {
     int dev = 0;
     if (batch > QS_ATTNQ_CAP || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (g_qcounters[dev]) return g_qcounters[dev];
+    unsigned*& slot_p = g_qcounters[dev][qs_scratch_slot(st)];
+    if (slot_p) return slot_p;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
         (void)hipGetLastError();
@@ -1078,24 +1079,32 @@ unsigned* qs_attn_quant_counters(hipStream_t st, int batch) {
         (void)hipGetLastError();
         return nullptr;
     }
-    g_qcounters[dev] = reinterpret_cast<unsigned*>(p);
-    return g_qcounters[dev];
+    slot_p = reinterpret_cast<unsigned*>(p);
+    return slot_p;
 }
 
-unsigned* qs_attn_error_word() {
+unsigned* qs_attn_error_word(int slot) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !g_qcounters[dev]) return nullptr;
-    return g_qcounters[dev] + QS_ATTNQ_CAP + (size_t)QS_ATTNQ_CAP * QS_ATTNQ_ROW;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || slot < 0 || slot >= QS_MAX_STREAM_SLOTS || !g_qcounters[dev][slot])
+        return nullptr;
+    return g_qcounters[dev][slot] + QS_ATTNQ_CAP + (size_t)QS_ATTNQ_CAP * QS_ATTNQ_ROW;
+}
+void qs_attn_scratch_prealloc(hipStream_t st) {
+    (void)qs_split_workspace(1, st);
+    (void)qs_attn_quant_counters(st, 1);
 }
 int qs_attn_reset_handoff() {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !g_qcounters[dev]) return QS_OK;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return QS_OK;
     const size_t bytes = (size_t)QS_ATTNQ_CAP * 4 + (size_t)QS_ATTNQ_CAP * QS_ATTNQ_ROW * 4 + 64;
-    hipError_t e = hipMemset(g_qcounters[dev], 0, bytes);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) {
-        qs_set_error("qs_device_reset (attention): %s", hipGetErrorString(e));
-        return (int)e;
+    for (int slot = 0; slot < QS_MAX_STREAM_SLOTS; ++slot) {
+        if (!g_qcounters[dev][slot]) continue;
+        hipError_t e = hipMemset(g_qcounters[dev][slot], 0, bytes);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            qs_set_error("qs_device_reset (attention): %s", hipGetErrorString(e));
+            return (int)e;
+        }
     }
     return QS_OK;
 }

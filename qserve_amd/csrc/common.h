@@ -192,15 +192,24 @@ constexpr int QS_SLAB_SENTINEL = (int)0x80808080u;
 
 // Bounded in-launch waits (round 5).  The two cross-workgroup hand-offs that poll inside a launch - the K-slice seam of the ring
 // GEMM and the finisher of the attention + quant fusion - give up after QS_SPIN_CAP polls (each poll is a memory round trip of
-// ~1 us plus a sleep: seconds, i.e. never in a healthy launch), OR a bit into a per-device error word and finish with whatever
-// they have; qs_device_status() reads the word, qs_device_reset() clears it and puts the hand-off areas back into their
+// ~1 us plus a sleep: seconds, i.e. never in a healthy launch), OR a bit into the error word of their scratch slot and finish with whatever
+// they have; qs_device_status() reads the words of every slot, qs_device_reset() clears them and puts the hand-off areas back into their
 // initial state.  qs_debug_inject_fault() arms a one-shot fault (a producer that never delivers) so that the path is testable.
 constexpr int QS_SPIN_CAP = 1 << 20;
 constexpr unsigned QS_ERR_GEMM_SEAM = 1u;     // K-slice seam: a partial tile never arrived
 constexpr unsigned QS_ERR_ATTN_HANDOVER = 2u; // attention + quant: a KV head's result row never arrived
 extern int g_inject_fault;                    // lib.hip: bit 0 next K-sliced ring GEMM launch, bit 1 next attention + quant launch
-unsigned* qs_gemm_error_word();               // gemm_w4a8.hip: nullptr until the split-K workspace exists
-unsigned* qs_attn_error_word();               // attention_mfma.hip: nullptr until the hand-over workspace exists
+// Library scratch (split-K slabs, K-slice slabs, split-KV partials, hand-over rows, argmax keys) exists once per device (slot 0,
+// shared by every stream: launches that use it must not overlap) plus once per stream that asked for its own with
+// qs_stream_scratch_bind() (slots 1 .. QS_MAX_STREAM_SLOTS - 1; lib.hip).  qs_scratch_slot: the slot of a stream on the
+// calling thread's current device.
+constexpr int QS_MAX_STREAM_SLOTS = 8;
+int qs_scratch_slot(hipStream_t stream);
+void qs_gemm_scratch_prealloc(hipStream_t stream);      // gemm_w4a8.hip     } allocate the slot's areas now (qs_stream_scratch_bind:
+void qs_attn_scratch_prealloc(hipStream_t stream);      // attention_mfma.hip } a first use inside a stream capture could not)
+void qs_argmax_scratch_prealloc(hipStream_t stream);    // fused_small.hip   }
+unsigned* qs_gemm_error_word(int slot);       // gemm_w4a8.hip: nullptr until that slot's split-K workspace exists
+unsigned* qs_attn_error_word(int slot);       // attention_mfma.hip: nullptr until that slot's hand-over workspace exists
 int qs_gemm_reset_handoff();                  // gemm_w4a8.hip: sentinel-fill the K-slice slabs, clear the error word
 int qs_attn_reset_handoff();                  // attention_mfma.hip: zero generation words / exchange rows, clear the error word
 

@@ -476,8 +476,8 @@ struct ArgmaxWs {
 };
 constexpr int ARGMAX_WS_ROWS = 8192;
 ArgmaxWs* argmax_ws(hipStream_t stream) {
-    static ArgmaxWs ws[QS_MAX_DEVICES];
-    ArgmaxWs& w = ws[qs_device_slot()];
+    static ArgmaxWs ws[QS_MAX_DEVICES][QS_MAX_STREAM_SLOTS];
+    ArgmaxWs& w = ws[qs_device_slot()][qs_scratch_slot(stream)];
     if (!w.tried) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
@@ -499,6 +499,7 @@ ArgmaxWs* argmax_ws(hipStream_t stream) {
 }
 }  // namespace
 
+void qs_argmax_scratch_prealloc(hipStream_t stream) { (void)argmax_ws(stream); }
 int g_argmax_split = -1;   // qs_debug_argmax_split: -1 heuristic, 1 one workgroup per row, >= 2 forced split (tests, A/B)
 extern "C" void qs_debug_argmax_split(int split) { g_argmax_split = split; }
 

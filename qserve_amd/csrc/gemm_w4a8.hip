@@ -279,12 +279,12 @@ struct Workspace {
     int ncounters = 0;
     bool tried = false;
 };
-Workspace g_ws[16];
+Workspace g_ws[16][QS_MAX_STREAM_SLOTS];   // [device][scratch slot] (common.h)
 
 Workspace* get_workspace(hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    Workspace& w = g_ws[dev];
+    Workspace& w = g_ws[dev][qs_scratch_slot(stream)];
     if (!w.tried) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
@@ -310,24 +310,27 @@ Workspace* get_workspace(hipStream_t stream) {
     return w.slabs ? &w : nullptr;
 }
 }  // namespace
-// the device error word of the GEMM hand-offs: the LAST ticket counter (never used as a ticket: see ring_ws / launch_splitk)
-unsigned* qs_gemm_error_word() {
+// the error word of the GEMM hand-offs of a scratch slot: the LAST ticket counter (never used as a ticket: see ring_ws / launch_splitk)
+unsigned* qs_gemm_error_word(int slot) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    Workspace& w = g_ws[dev];
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || slot < 0 || slot >= QS_MAX_STREAM_SLOTS) return nullptr;
+    Workspace& w = g_ws[dev][slot];
     return w.slabs ? w.counters + (w.ncounters - 1) : nullptr;
 }
+void qs_gemm_scratch_prealloc(hipStream_t stream) { (void)get_workspace(stream); }
 int qs_gemm_reset_handoff() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return QS_OK;
-    Workspace& w = g_ws[dev];
-    if (!w.slabs) return QS_OK;
-    hipError_t e = hipMemset(w.ring_slabs, 0x80, w.slab_bytes);
-    if (e == hipSuccess) e = hipMemset(w.counters, 0, (size_t)w.ncounters * sizeof(unsigned));
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) {
-        qs_set_error("qs_device_reset (gemm): %s", hipGetErrorString(e));
-        return (int)e;
+    for (int slot = 0; slot < QS_MAX_STREAM_SLOTS; ++slot) {
+        Workspace& w = g_ws[dev][slot];
+        if (!w.slabs) continue;
+        hipError_t e = hipMemset(w.ring_slabs, 0x80, w.slab_bytes);
+        if (e == hipSuccess) e = hipMemset(w.counters, 0, (size_t)w.ncounters * sizeof(unsigned));
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            qs_set_error("qs_device_reset (gemm): %s", hipGetErrorString(e));
+            return (int)e;
+        }
     }
     return QS_OK;
 }

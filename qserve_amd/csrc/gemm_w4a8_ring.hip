@@ -763,7 +763,7 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
     dim3 grid((N / (64 * WN)) * mblocks * ksplit);
     int inject = 0;
     if (KSPLIT && OUTK != 3 && ksplit > 1) {
-        counters = qs_gemm_error_word();               // the kernel's `counters` is the device error word of the seam's bounded wait
+        counters = qs_gemm_error_word(qs_scratch_slot(stream));   // the kernel's `counters` is the error word of the seam's bounded wait
         if (g_inject_fault & 1) inject = 128, g_inject_fault &= ~1;
     }
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, A, W, zeros, scales8,

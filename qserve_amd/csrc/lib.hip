@@ -19,8 +19,8 @@ int g_inject_fault = 0;
 extern "C" int qs_device_status(int* error_bits) {
     QS_REQUIRE(error_bits, "qs_device_status: null output");
     *error_bits = 0;
-    unsigned* words[2] = {qs_gemm_error_word(), qs_attn_error_word()};
-    for (unsigned* w : words) {
+    for (int i = 0; i < 2 * QS_MAX_STREAM_SLOTS; ++i) {
+        unsigned* w = i & 1 ? qs_attn_error_word(i >> 1) : qs_gemm_error_word(i >> 1);
         if (!w) continue;
         unsigned v = 0;
         const hipError_t e = hipMemcpy(&v, w, sizeof(v), hipMemcpyDeviceToHost);   // (blocking: orders behind the launches so far)
@@ -44,6 +44,62 @@ extern "C" int qs_device_reset(void) {
     int rc = qs_gemm_reset_handoff();
     if (rc == QS_OK) rc = qs_attn_reset_handoff();
     return rc;
+}
+// ---- scratch slots (common.h) ----------------------------------------------------------------------------------------------------
+#include <mutex>
+namespace {
+std::mutex g_slot_mutex;
+hipStream_t g_slot_stream[QS_MAX_DEVICES][QS_MAX_STREAM_SLOTS];   // [d][0] unused (the shared slot)
+bool g_slot_bound[QS_MAX_DEVICES][QS_MAX_STREAM_SLOTS];
+int g_slots_bound[QS_MAX_DEVICES];                                // fast path: nothing bound -> slot 0 without taking the lock
+}  // namespace
+int qs_scratch_slot(hipStream_t stream) {
+    const int d = qs_device_slot();
+    if (__atomic_load_n(&g_slots_bound[d], __ATOMIC_ACQUIRE) == 0) return 0;
+    std::lock_guard<std::mutex> lock(g_slot_mutex);
+    for (int i = 1; i < QS_MAX_STREAM_SLOTS; ++i)
+        if (g_slot_bound[d][i] && g_slot_stream[d][i] == stream) return i;
+    return 0;
+}
+extern "C" int qs_stream_scratch_bind(qs_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        qs_set_error("qs_stream_scratch_bind: the stream is capturing (bind before the capture: the slot's memory is allocated here)");
+        return QS_EINVAL;
+    }
+    const int d = qs_device_slot();
+    {
+        std::lock_guard<std::mutex> lock(g_slot_mutex);
+        int free_slot = 0;
+        for (int i = QS_MAX_STREAM_SLOTS - 1; i >= 1; --i) {
+            if (g_slot_bound[d][i] && g_slot_stream[d][i] == st) return QS_OK;       // idempotent
+            if (!g_slot_bound[d][i]) free_slot = i;
+        }
+        if (!free_slot) {
+            qs_set_error("qs_stream_scratch_bind: all %d per-stream scratch slots of this device are bound", QS_MAX_STREAM_SLOTS - 1);
+            return QS_ENOSUP;
+        }
+        g_slot_stream[d][free_slot] = st;
+        g_slot_bound[d][free_slot] = true;
+        __atomic_add_fetch(&g_slots_bound[d], 1, __ATOMIC_RELEASE);
+    }
+    qs_gemm_scratch_prealloc(st);
+    qs_attn_scratch_prealloc(st);
+    qs_argmax_scratch_prealloc(st);
+    return QS_OK;
+}
+extern "C" int qs_stream_scratch_unbind(qs_stream_t stream) {
+    const int d = qs_device_slot();
+    std::lock_guard<std::mutex> lock(g_slot_mutex);
+    for (int i = 1; i < QS_MAX_STREAM_SLOTS; ++i)
+        if (g_slot_bound[d][i] && g_slot_stream[d][i] == (hipStream_t)stream) {
+            g_slot_bound[d][i] = false;                 // the slot's memory stays (graphs captured on the stream keep working);
+            __atomic_sub_fetch(&g_slots_bound[d], 1, __ATOMIC_RELEASE);   // the next bind of this device reuses it
+            return QS_OK;
+        }
+    return QS_OK;
 }
 extern "C" int qs_debug_inject_fault(int what) {
     QS_REQUIRE(what >= 0 && what <= 3, "qs_debug_inject_fault: what=%d not in 0..3", what);
