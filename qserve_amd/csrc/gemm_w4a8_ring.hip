@@ -26,6 +26,7 @@
 // A/B switches (qs_set_gemm_variant(5000 + bits); every setting computes the same results):
 //   1 = weight DMA with the default cache policy everywhere, 2 = non-temporal everywhere (default: non-temporal unless several
 //       token blocks share the weight bytes of a channel block and N <= 8192 - see launch_ring and `issue`)
+//   4 / 8 = (QS_TIMING libraries only) no cross-group reduction / leave behind the k loop: the price of the tail (round 5)
 //   32 / 64 = (libraries built with -DQS_TIMING only; ignored by the shipped library) timing only, WRONG RESULTS: no MFMA /
 //        no LDS operand reads (what is left is the DMA + barrier pipeline:
 //        gate_up at M = 64 17.5 us -> 16.3 / 16.8, both off 15.9 us = 4.2 us of head and tail + 512 KB per CU at 44 GB/s,
@@ -488,22 +489,37 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
         // barriers in the timeline trace; as straight-line code the reads of all pieces are in flight together).
         v4i sum[PPG];
         v4i* const red4 = reinterpret_cast<v4i*>(smem);
+#ifdef QS_TIMING
+        // timing builds only, WRONG RESULTS (what would a geometry without the cross-group reduction save?): 8 = leave behind the k
+        // loop (one store per wave keeps the accumulators alive), 4 = no exchange of partial tiles - every wave finishes its pieces
+        // from its own accumulators, epilogue / staging / row stores as usual
+        if (flags & 8) {
+            v4i x = acc[0][0];
+#pragma unroll
+            for (int pc = 1; pc < NP; ++pc) x += acc[pc >> 2][pc & 3];
+            if (x[0] == 0x12345678) *reinterpret_cast<v4i*>(out) = x;
+            return;
+        }
+        const bool t_red = !(flags & 4);
+#else
+        constexpr bool t_red = true;
+#endif
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
-            __syncthreads();                           // rings are dead (every wave drained its DMA queue) / previous pass consumed
+            if (t_red) __syncthreads();                // rings are dead (every wave drained its DMA queue) / previous pass consumed
             if (pass == 0) QS_STAMP(4);
             // partial of piece pc from group kg -> slot [owner][wn][source index among the other groups][pc / KG - pass PPP][lane]
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) {
                 const int own = pc % KG, qq = pc / KG;
                 if (qq < pass * PPP || qq >= (pass + 1) * PPP) continue;
-                if (own != kg) {
+                if (own != kg && t_red) {
                     const int src = kg < own ? kg : kg - 1;
                     red4[((((own * WN + wn) * (KG - 1) + src) * PPP + (qq - pass * PPP)) << 6) + lane] = acc[pc >> 2][pc & 3];
                 }
             }
             if (pass == 0) QS_STAMP(7);
-            __syncthreads();
+            if (t_red) __syncthreads();
             if (pass == 0) QS_STAMP(10);
 #pragma unroll
             for (int q = pass * PPP; q < (pass + 1) * PPP; ++q) {
@@ -517,7 +533,7 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
             for (int q = pass * PPP; q < (pass + 1) * PPP; ++q)
 #pragma unroll
                 for (int sidx = 0; sidx < KG - 1; ++sidx)
-                    sum[q] += red4[((((kg * WN + wn) * (KG - 1) + sidx) * PPP + (q - pass * PPP)) << 6) + lane];
+                    if (t_red) sum[q] += red4[((((kg * WN + wn) * (KG - 1) + sidx) * PPP + (q - pass * PPP)) << 6) + lane];
         }
 #ifdef QS_RING_TRACE
 #pragma unroll
