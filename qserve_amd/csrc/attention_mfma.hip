@@ -1034,7 +1034,7 @@ size_t qs_split_workspace_capacity() { return SPLIT_WS_BYTES; }
 // the number of resident workgroups, so 320 workgroups take as long as 512; F = a workgroup's head + tail; t_cu = one CU's time
 // per page (64 tokens of K and V), t_hbm = the chip's; merge = the second launch (boundary + n partials per head).
 // ns / ps units, integer arithmetic (the plan is part of the ABI: tests/test_dispatch_plan.py pins it).
-int qs_attn_choose_splits(int blocks, int pages, int kv8) {
+int qs_attn_choose_splits(int blocks, int pages, int kv8, int fused_quant) {
     if (blocks >= 512 || pages < 4) return 1;
     const long F = kv8 ? 5000 : 4000, t_cu = kv8 ? 450 : 340, t_hbm_ps = kv8 ? 2540 : 1330;
     long best = -1;
@@ -1043,7 +1043,9 @@ int qs_attn_choose_splits(int blocks, int pages, int kv8) {
         if (n > 1 && pages / n < 2) break;
         const long rounds = ((long)blocks * n + 255) / 256;
         const long per_cu = rounds * pages * t_cu / n, chip = (long)blocks * pages * t_hbm_ps / 1000;
-        const long cost = rounds * F + (per_cu > chip ? per_cu : chip) + (n > 1 ? 2500 + 300 * n : 0);
+        // (fused_quant: qs_single_query_attention_quant - only the un-split launch can finish the row itself; a split one is
+        // followed by the quantiser as a launch of its own, 3.2 us + boundary)
+        const long cost = rounds * F + (per_cu > chip ? per_cu : chip) + (n > 1 ? 2500 + 300 * n + (fused_quant ? 3500 : 0) : 0);
         if (best < 0 || cost < best) best = cost, best_n = n;
     }
     return best_n;
@@ -1127,7 +1129,7 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
     // split-KV (qs_attn_choose_splits above)
     const int blocks = (int)(grid.x * grid.y);
     const int pages_max = (timestep + PAGE_TOK - 1) / PAGE_TOK;
-    int nsplit = force_split > 0 ? force_split : qs_attn_choose_splits(blocks, pages_max, 0);
+    int nsplit = force_split > 0 ? force_split : qs_attn_choose_splits(blocks, pages_max, 0, g_qs_attn_quant.qout != nullptr && H * DH <= 4096);
     if (g_qs_attn_plan.active) {
         g_qs_attn_plan.family = 1, g_qs_attn_plan.nsplit = nsplit, g_qs_attn_plan.waves = NW;
         return QS_OK;

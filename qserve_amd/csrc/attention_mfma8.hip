@@ -510,7 +510,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attention_mfma8_kernel(
 const float2* qs_rope_table(float base, int max_pos, hipStream_t st, int* len_out);
 float* qs_split_workspace(size_t bytes, hipStream_t st);
 size_t qs_split_workspace_capacity();
-int qs_attn_choose_splits(int blocks, int pages, int kv8);
+int qs_attn_choose_splits(int blocks, int pages, int kv8, int fused_quant);
 void qs_launch_attention_merge(const float* ws, _Float16* out, int H, int Hkv, int G, int nsplit, int batch, hipStream_t st);
 
 // called from attention.hip's dispatcher for KV8.  force_split: 0 = heuristic, n > 0 = exactly n splits (tests)
@@ -525,7 +525,7 @@ int qs_launch_decode_mfma8(int G, dim3 grid, hipStream_t st, const _Float16* q, 
     const float2* tab = g_qs_attn_plan.active ? nullptr : qs_rope_table(base, max_pos, st, &tab_len);
     const int blocks = (int)(grid.x * grid.y);
     const int pages_max = (timestep + PAGE_TOK - 1) / PAGE_TOK;
-    int nsplit = force_split > 0 ? force_split : qs_attn_choose_splits(blocks, pages_max, 1);   // attention_mfma.hip
+    int nsplit = force_split > 0 ? force_split : qs_attn_choose_splits(blocks, pages_max, 1, 0);   // attention_mfma.hip
     if (g_qs_attn_plan.active) {
         g_qs_attn_plan.family = 2, g_qs_attn_plan.nsplit = nsplit, g_qs_attn_plan.waves = NW;
         return QS_OK;
