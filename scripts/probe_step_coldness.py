@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Round 5 probe (timing only, results wrong by design in the hacked runs): what keeps the row kernels at ~4.6 us inside the decode
-step when they take 3.1-3.5 us in their own / pair chains?  The same engine, graph-captured, with (a) nothing changed, (b) every
-layer sharing layer 0's norm weights (no cold 8 KB vector per row launch), (c) every layer sharing layer 0's GEMM weights too
-(everything Infinity-Cache-resident: an upper bound on 'cold lines')."""
-import os, sys, time
+"""Round 5 probe (timing only, results wrong by design in the hacked runs): what would Infinity-Cache-resident weights be worth to the
+decode step, GEMM by GEMM?  The same engine, graph-captured, with the layers sharing layer 0's tensors of one kind (every launch of
+that kind then streams bytes that were read 78 us earlier and are still in the 256 MB cache) - the upper bound of any scheme that
+touches a GEMM's weights ahead of its launch."""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from qserve_amd import decode as D
@@ -27,15 +27,21 @@ def timed(eng, steps=32):
     return sorted(res)[1]
 
 
-cfg = D.LLAMA3_8B if hasattr(D, "LLAMA3_8B") else D.CONFIGS["llama3-8b"]
-eng = D.DecodeEngine(cfg, batch=64, prompt_len=1024, max_new=256, device="cuda:0", seed=0, fuse_pairs=True)
+eng = D.DecodeEngine(D.LLAMA3_8B, batch=64, prompt_len=1024, max_new=256, device="cuda:0", seed=0, fuse_pairs=True)
 eng.prefill_cache(1024)
-print(f"as shipped:                      {timed(eng):.4f} ms per step")
-print(f"as shipped, again:               {timed(eng):.4f} ms per step")
-for L in eng.layers:
-    L["ln1"], L["ln2"] = eng.layers[0]["ln1"], eng.layers[0]["ln2"]
-print(f"one norm-weight vector for all:  {timed(eng):.4f} ms per step")
-for L in eng.layers[1:]:
-    for k in ("qkv", "o", "gate_up", "down"):
-        L[k] = eng.layers[0][k]
-print(f"+ one set of GEMM weights:       {timed(eng):.4f} ms per step")
+own = [dict(L) for L in eng.layers]
+
+
+def share(kinds):
+    for L, o in zip(eng.layers, own):
+        for k in ("qkv", "o", "gate_up", "down", "ln1", "ln2"):
+            L[k] = eng.layers[0][k] if k in kinds else o[k]
+    eng.layers[0].update(own[0])
+
+
+base = timed(eng)
+print(f"as shipped:                          {base:.4f} ms per step")
+for kinds in (("ln1", "ln2"), ("qkv",), ("o",), ("qkv", "o"), ("gate_up",), ("down",), ("qkv", "o", "gate_up", "down"), ()):
+    share(kinds)
+    t = timed(eng)
+    print(f"one tensor for all layers: {'+'.join(kinds) or '(none)':22s} {t:.4f} ms per step  ({(t - base) * 1e3:+6.1f} us)")
