@@ -25,21 +25,24 @@ def thrash(stream, bufs, n):
             bufs[(i + 1) % len(bufs)].copy_(bufs[i % len(bufs)])
 
 
-@pytest.fixture(params=[-1, 3003], ids=["dispatcher", "four_wave_tile"])
+# (shape, mode, forced variant): every shape under the dispatcher's own choice (-1: per-group 256-token tiles already take the
+# four-wave tile, gemm_w4a8_wide.hip; g128 gate_up at 128 tokens the 128-token ring workgroups) + the four-wave tile FORCED (3003) on
+# the per-channel prompt shapes, where the dispatcher prefers the eight-wave tile
+CASES = [(M, N, K, mode, -1) for mode in ("per_channel", "per_group") for (M, N, K) in SHAPES] + \
+        [(M, N, K, "per_channel", 3003) for (M, N, K) in SHAPES if M >= 1024]
+
+
+@pytest.fixture
 def gemm_variant(request):
-    """-1: the dispatcher's own choice (per-group 256-token tiles already take the four-wave tile, gemm_w4a8_wide.hip; g128 gate_up
-    at 128 tokens the 128-token ring workgroups); 3003: the four-wave tile forced for the per-channel prompt shapes too."""
     from qserve_amd import _lib
     _lib.lib.qs_set_gemm_variant(request.param)
     yield request.param
     _lib.lib.qs_set_gemm_variant(-1)
 
 
-@pytest.mark.parametrize("M,N,K", SHAPES)
-@pytest.mark.parametrize("mode", ["per_channel", "per_group"])
+@pytest.mark.parametrize("M,N,K,mode,gemm_variant", CASES, indirect=["gemm_variant"],
+                         ids=[f"{m}-{M}x{N}x{K}-{'dispatcher' if v < 0 else 'four_wave_tile'}" for (M, N, K, m, v) in CASES])
 def test_repeated_runs_are_identical_and_exact(gpu, M, N, K, mode, gemm_variant):
-    if gemm_variant == 3003 and (M < 1024 or mode == "per_group"):
-        pytest.skip("the forced four-wave tile is screened on the per-channel prompt shapes (per-group takes it by default)")
     import qserve_backend.qgemm_w4a8_per_chn as opc
     import qserve_backend.qgemm_w4a8_per_group as opg
     from qserve_amd import fused as fz
