@@ -185,10 +185,6 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
         // leave the compiler no choice but counted lgkmcnt waits - with read-then-use in one loop body every MFMA sat behind
         // a full LDS round trip
         v16f sacc[NKB];
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
         if (!(QS_FLASH_DBG & 4)) {
             h8 ka[2][4];
             auto read_k = [&](int g, h8 (&dst)[4]) {       // group g = (kb = g >> 1, s = 4 (g & 1) .. +3)
@@ -206,13 +202,22 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    sacc[g >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[g & 1][j], qf[4 * (g & 1) + j], sacc[g >> 1], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    // the first MFMA of a 32-key block starts from C = 0 (an inline constant operand: no 16-register zero
+                    // fill per block and tile)
+                    const v16f zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    const bool first = (g & 1) == 0 && j == 0;
+                    sacc[g >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[g & 1][j], qf[4 * (g & 1) + j], first ? zero16 : sacc[g >> 1], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (g + 2 < 4) read_k(g + 2, ka[g & 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
             sacc[0][0] = (float)qf[0][0];
         }
         // A operands of O^T += V^T P^T by the LDS transpose read: a 16-lane group (16 consecutive dims, one lane half) reads
@@ -269,7 +274,11 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
         const float m_use = m_new == -INFINITY ? 0.f : m_new;     // fully masked so far: keep exp2 arguments finite
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);                  // m_run = -inf -> 0
         m_run = m_new;
-        float psum = 0.f;
+        // two scores per instruction where the ISA has a packed form (v_pk_fma_f32, v_pk_add_f32; the exponential has none):
+        // round 5, the key loop is as VALU-bound as it is MFMA-bound (HISTORY 5.5)
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f sc2 = {scale_log2, scale_log2}, nm2 = {-m_use, -m_use};
+        v2f psum2 = {0.f, 0.f};
         u32 pb[NKB][2][4];                                           // [kb][m]: 8 probabilities in B-operand order
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
@@ -277,14 +286,16 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float p0 = fmaf(sacc[kb][8 * m + 2 * j], scale_log2, -m_use), p1 = fmaf(sacc[kb][8 * m + 2 * j + 1], scale_log2, -m_use);
+                    const v2f sv = {sacc[kb][8 * m + 2 * j], sacc[kb][8 * m + 2 * j + 1]};
+                    v2f pp = __builtin_elementwise_fma(sv, sc2, nm2);
                     if (!(QS_FLASH_DBG & 1)) {
-                        p0 = __builtin_amdgcn_exp2f(p0);      // -inf stays -inf
-                        p1 = __builtin_amdgcn_exp2f(p1);
+                        pp[0] = __builtin_amdgcn_exp2f(pp[0]);      // -inf stays -inf
+                        pp[1] = __builtin_amdgcn_exp2f(pp[1]);
                     }
-                    psum += p0 + p1;
-                    pb[kb][m][j] = pack_h2(p0, p1);
+                    psum2 += pp;
+                    pb[kb][m][j] = pack_h2(pp[0], pp[1]);
                 }
+        const float psum = psum2[0] + psum2[1];
         l_run = l_run * alpha + psum;
         if (__any(alpha != 1.0f)) {                                // the running max moved for some row of this wave
 #pragma unroll
