@@ -364,6 +364,34 @@ def other_configs(torch, D, dev):
     return res
 
 
+NOMINAL_CLOCK_GHZ = 2.4      # the clock INT8_PEAK_TOPS is quoted at (MI355X_MICROARCH.md)
+
+
+def measured_gemm_clock_ghz(fn, reps, torch, dev):
+    """The engine clock a compute-bound GEMM launch holds under its own load: `reps` launches back to back (the chip settles
+    into the power state of the timed loop), the LAST one stamped from inside the kernel - every workgroup reports its life in
+    shader cycles (s_memtime) and in ticks of the constant 100 MHz counter (include/qserve_amd.h qs_debug_gemm_clock_probe);
+    median over the workgroups of cycles / (ticks x 10 ns).  None if the launch is not one of the probed kernels."""
+    from qserve_amd._lib import lib
+    cap = 4096
+    buf = torch.zeros((cap, 2), dtype=torch.int64, device=dev)
+    for i in range(reps - 1):
+        fn(i)
+    if lib.qs_debug_gemm_clock_probe(buf.data_ptr(), cap) != 0:
+        return None
+    try:
+        fn(reps - 1)
+        torch.cuda.synchronize()
+    finally:
+        lib.qs_debug_gemm_clock_probe(None, 0)
+    b = buf.cpu()
+    live = b[:, 1] > 0
+    if int(live.sum()) == 0:
+        return None
+    ghz = (b[live, 0].double() / (b[live, 1].double() * 10.0)).sort().values     # cycles per ns
+    return float(ghz[len(ghz) // 2])
+
+
 def gemm_config1_bench(torch, dev):
     """BASELINE.json configs[0] on the GPU: 4096 x 4096 x 4096 W4A8 GEMM, per-channel and per-group, compute-bound;
     TOPS against the dense INT8 MFMA peak (north_star: >= 70 %)."""
@@ -384,9 +412,16 @@ def gemm_config1_bench(torch, dev):
     for name, fn, grp in (("per_channel", lambda i: gc.gemm_forward_cuda(A[i % nset], W[i % nset], ws, sa, ws, sa, out), -1),
                           ("per_group", lambda i: gg.gemm_forward_cuda(A[i % nset], W[i % nset], z2, s2, ws, sa, out), 128)):
         us = time_kernel(fn, 8, torch)
-        res.append(dict(kernel=f"w4a8_gemm[config1 {name} M={M} N={N} K={K}]", family="w4a8_gemm_compute_bound", us=us,
-                        bytes=gemm_bytes(M, N, K, grp), tops=ops / us / 1e6, frac_of_int8_mfma_peak=ops / us / 1e6 / INT8_PEAK_TOPS,
-                        peak_tops=INT8_PEAK_TOPS, per_step=0))
+        clk = measured_gemm_clock_ghz(fn, 8, torch, dev)
+        ent = dict(kernel=f"w4a8_gemm[config1 {name} M={M} N={N} K={K}]", family="w4a8_gemm_compute_bound", us=us,
+                   bytes=gemm_bytes(M, N, K, grp), tops=ops / us / 1e6, frac_of_int8_mfma_peak=ops / us / 1e6 / INT8_PEAK_TOPS,
+                   peak_tops=INT8_PEAK_TOPS, per_step=0)
+        if clk:
+            # "compute peak from the measured engine clock during the run and state it" - the nominal 5.0 POPS are
+            # 256 CUs x 4 SIMDs x 2048 int8 ops per clock at 2.4 GHz; under this launch's own load the chip holds `clk` GHz
+            ent.update(sustained_clock_ghz=clk, peak_tops_at_measured_clock=INT8_PEAK_TOPS * clk / NOMINAL_CLOCK_GHZ,
+                       frac_of_peak_at_measured_clock=ops / us / 1e6 / (INT8_PEAK_TOPS * clk / NOMINAL_CLOCK_GHZ))
+        res.append(ent)
     return res
 
 
@@ -731,13 +766,29 @@ def main():
             roof.update(plain_attention_us=round(plain["us"], 2), plain_attention_frac=round(plain["gbs"] / HBM_PEAK_GBS, 4),
                         note="timed as the step launches it: attention + invoke_quant(_fuse_sum) of its output in one launch; "
                              "plain_attention_* = qs_single_query_attention alone (the launch rounds 1-3 quoted)")
+            # the whole generation: plain-kernel fractions at the measured contexts and their average over
+            # the steps prompt_len + 1 .. prompt_len + max_new (launch time interpolated linearly between the measured contexts;
+            # bytes exact per step): total algorithmic bytes / total attention time of a layer over the generation
+            pts = sorted((int(r["kernel"].split(" L=")[1].rstrip("]")), r["us"]) for r in kernels if r["family"] == "decode_attention")
+            roof["plain_attention_frac_by_context"] = {
+                str(L): round(attn_bytes(eng.B, eng.H, eng.Hkv, L - 1, eng.int4) / us / 1e3 / HBM_PEAK_GBS, 4) for L, us in pts}
+            if len(pts) >= 2:
+                tb = tu = 0.0
+                for L in range(args.prompt_len + 1, args.prompt_len + args.max_new + 1):
+                    lo = max([p_ for p_ in pts if p_[0] <= L] or [pts[0]], key=lambda p_: p_[0])
+                    hi = min([p_ for p_ in pts if p_[0] >= L] or [pts[-1]], key=lambda p_: p_[0])
+                    us = lo[1] if hi[0] == lo[0] else lo[1] + (hi[1] - lo[1]) * (L - lo[0]) / (hi[0] - lo[0])
+                    tb += attn_bytes(eng.B, eng.H, eng.Hkv, L - 1, eng.int4)
+                    tu += us
+                roof["plain_attention_generation_average_frac"] = round(tb / tu / 1e3 / HBM_PEAK_GBS, 4)
         fam = [r for r in step_k if r["family"] == "w4a8_gemm"]
         fb, fu = sum(r["bytes"] for r in fam), sum(r["us"] for r in fam)
         roof_family = dict(bound="hbm", family="w4a8_gemm (the four decode GEMMs of a layer)", achieved=round(fb / fu / 1e3, 1),
                            peak=HBM_PEAK_GBS, unit="GB/s", frac=round(fb / fu / 1e3 / HBM_PEAK_GBS, 4), us_per_layer=round(fu, 2),
                            algorithmic_bytes=fb, step_share=round(fu * len(eng.layers) / (ms * 1e3), 3))
         for r in kernels:
-            for k2, nd in (("us", 2), ("gbs", 1), ("tops", 1), ("frac_of_hbm_peak", 4), ("frac_of_int8_mfma_peak", 4)):
+            for k2, nd in (("us", 2), ("gbs", 1), ("tops", 1), ("frac_of_hbm_peak", 4), ("frac_of_int8_mfma_peak", 4),
+                           ("sustained_clock_ghz", 3), ("peak_tops_at_measured_clock", 1), ("frac_of_peak_at_measured_clock", 4)):
                 if k2 in r:
                     r[k2] = round(r[k2], nd)
     headline = (args.model == "llama3-8b" and per_gpu_batch == 64 and args.group_size == -1 and not args.kv8

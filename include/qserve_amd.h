@@ -148,6 +148,26 @@ void qs_set_gemm_variant(int variant);
 int qs_set_gemm_epilogue(int convention);
 int qs_get_gemm_epilogue(void);
 
+/* Order of the per-token ROW SUM `a_ssums` written by qs_rms_norm_general (input_sum != NULL),
+ * qs_add_residual_rms_norm_general and qs_add_residual_rms_norm_general_planes (process-wide; read at launch time).  It is the
+ * value the per-channel GEMM epilogue multiplies by w_sz (w4a8_per_chn/gemm_cuda.cu:586).
+ *   0 [default] = this library's order: fp32 chains per thread over 8-element chunks, wave butterfly, waves left to right;
+ *   1 = the reference's own order (generalLayerNorm_fuse_sum, kernels/csrc/layernorm_kernels.cu:275-306): min(hidden, 1024)
+ *       threads, thread t accumulates elements t, t + nt, ... in a HALF variable (one fp16 rounding per addition), partials
+ *       all-reduced in fp32 by the 32-lane xor butterfly inside a warp and again over the warp slots
+ *       (reduction_utils.cuh:25-30,68-85) - bit-equal to oracle/fused.py rms_norm_general(with_sum=True, sum_order="reference").
+ * Int8 rows and scales do not depend on it.  invoke_quant_fuse_sum sums in fp32 in the reference too (fused_kernels.cu:104-122)
+ * and has no second form.  Returns QS_EINVAL for any other value. */
+int qs_set_row_sum_order(int order);
+int qs_get_row_sum_order(void);
+
+/* Measurement hook (no reference counterpart; SURVEY 8(d): "compute peak from the measured engine clock during the run").  While a
+ * buffer is set, every launch of the compute-bound GEMM kernels (tiled / wide: M > 1024 or forced) with at most `workgroups`
+ * workgroups makes workgroup b write buf[2 b] = its life in shader cycles (s_memtime) and buf[2 b + 1] = the same interval in
+ * ticks of the constant 100 MHz counter (s_memrealtime): cycles / (ticks * 10 ns) = the engine clock that launch held under its own
+ * load.  buf = device memory of 16 * workgroups bytes owned by the caller; (NULL, 0) stops it.  Results are unaffected. */
+int qs_debug_gemm_clock_probe(void* buf, int workgroups);
+
 /* Plan only: runs the W4A8 GEMM dispatcher for an (M, N, K) problem without touching the device and reports its choice
  * in plan5 = {family, p0, p1, p2, p3}: family 1 = split-K kernel (m_tiles, waves, cross-block slices, xcd mapping),
  * 2 = LDS-pair kernel, 3 = ring kernel (m_tiles, units, token blocks, K slices), 4 = tiled kernel (8 = 256-token tile,

@@ -35,3 +35,28 @@ def attention_varlen(q, k, v, cu_q, cu_k, scale=None, causal=True):
             O = np.where(l > 0, (P @ V) / np.where(l > 0, l, 1.0), 0.0)
             out[qs:qe, h] = O.astype(np.float32)
     return out
+
+
+def attention_rows(q, k, v, cu_q, cu_k, rows, heads, scale=None, causal=True):
+    """The same definition for SAMPLED (global query row, head) pairs only: float32 [len(rows), len(heads), D].  For sequences
+    whose full score matrix would not fit (BASELINE config 5: 8 k tokens)."""
+    D = q.shape[2]
+    G = q.shape[1] // k.shape[1]
+    scale = 1.0 / np.sqrt(D) if scale is None else scale
+    out = np.zeros((len(rows), len(heads), D), np.float32)
+    cu_q = np.asarray(cu_q); cu_k = np.asarray(cu_k)
+    for ri, t in enumerate(rows):
+        b = int(np.searchsorted(cu_q, t, side="right") - 1)
+        i = t - int(cu_q[b])
+        lq, ks, ke = int(cu_q[b + 1] - cu_q[b]), int(cu_k[b]), int(cu_k[b + 1])
+        lk = ke - ks
+        nvis = min(lk, i + (lk - lq) + 1) if causal else lk
+        for hi, h in enumerate(heads):
+            if nvis <= 0:
+                continue
+            K = k[ks:ks + nvis, h // G].astype(np.float64)
+            V = v[ks:ks + nvis, h // G].astype(np.float64)
+            sc = (K @ q[t, h].astype(np.float64)) * scale
+            p = np.exp(sc - sc.max())
+            out[ri, hi] = ((p @ V) / p.sum()).astype(np.float32)
+    return out

@@ -42,7 +42,37 @@ def _threads_for(hidden):
     return 32 * ((b + 31) // 32)   # layernorm_kernels.cu:436-437
 
 
-def rms_norm_general(x, gamma, eps, with_sum=False):
+def _butterfly_sum32(f):
+    """warpReduceSum (reduction_utils.cuh:25-30): xor butterfly 16, 8, 4, 2, 1 over the last axis (32 lanes), fp32 adds;
+    every lane ends with the same value (fp32 addition commutes), returned from lane 0."""
+    f = np.asarray(f, np.float32)
+    lanes = np.arange(32)
+    for m in (16, 8, 4, 2, 1):
+        f = (f + f[..., lanes ^ m]).astype(np.float32)
+    return f[..., 0]
+
+
+def reference_order_row_sum(val16):
+    """`input_sum` of generalLayerNorm_fuse_sum exactly as the reference orders it (layernorm_kernels.cu:275,286,306,323):
+    nt = min(H, 1024) threads rounded up to 32 (:480-481); thread t adds elements t, t + nt, ... into a HALF accumulator
+    (`T_scalar sum`; `sum += float` resolves to __half::operator+=: one fp16 rounding per addition - computed here in float64,
+    which holds any sum of two halves exactly, then rounded once); blockAllReduceSum (reduction_utils.cuh:68-85): butterfly
+    inside each warp, warp results to shared[wid], the butterfly again over the 32 slots (unused ones = 0); half_rn."""
+    val16 = np.asarray(val16, np.float16)
+    T, H = val16.shape
+    nt = _threads_for(H)
+    part = np.zeros((T, nt), np.float16)
+    for i0 in range(0, H, nt):
+        seg = val16[:, i0:i0 + nt].astype(np.float64)
+        w = seg.shape[1]
+        part[:, :w] = (part[:, :w].astype(np.float64) + seg).astype(np.float16)
+    warp = _butterfly_sum32(part.astype(np.float32).reshape(T, nt // 32, 32))      # [T, nwarps]
+    slots = np.zeros((T, 32), np.float32)
+    slots[:, : nt // 32] = warp
+    return _butterfly_sum32(slots).astype(np.float16)
+
+
+def rms_norm_general(x, gamma, eps, with_sum=False, sum_order="reference"):
     """generalLayerNorm(_fuse_sum), per-token dynamic scaling branch (layernorm_kernels.cu:207-326).
 
     mean = sum(x)/H; var = sum((x-mean)^2)/H; rstd = rsqrt(var+eps);
@@ -51,6 +81,8 @@ def rms_norm_general(x, gamma, eps, with_sum=False):
     strided elements, then reduced over the block in fp32 (:275,:286) and stored as half;
     q = rni_sat_s8( ((x-mean)*rstd*gamma) * (127/amax) )  - the un-rounded fp32 value is re-computed (:312);
     scale = half_rn(amax/127).
+    sum_order: "reference" (default) = reference_order_row_sum above - what the HIP kernels compute under
+    qs_set_row_sum_order(1), bit for bit; "fp32" = the order-free exact sum (the HIP default order is an fp32 association of it).
     """
     xf = np.asarray(x, np.float16).astype(np.float32)
     g = np.asarray(gamma, np.float16).astype(np.float32)
@@ -68,13 +100,10 @@ def rms_norm_general(x, gamma, eps, with_sum=False):
     q = rni_sat_s8(pre)
     if not with_sum:
         return q, scale, pre
-    nt = _threads_for(H)
-    part = np.zeros((T, nt), np.float16)
-    for i0 in range(0, H, nt):                         # thread t adds element i0+t, rounding to half each time
-        seg = val16[:, i0:i0 + nt].astype(np.float32)
-        w = seg.shape[1]
-        part[:, :w] = (part[:, :w].astype(np.float32) + seg).astype(np.float16)
-    s = part.astype(np.float64).sum(axis=-1).astype(np.float32).astype(np.float16)
+    if sum_order == "reference":
+        s = reference_order_row_sum(val16)
+    else:                                              # "fp32": the exact sum of the fp16 values, rounded once (order-free)
+        s = val16.astype(np.float64).sum(axis=-1).astype(np.float32).astype(np.float16)
     return q, scale, s, pre
 
 

@@ -26,6 +26,9 @@ SIGNATURES = {
     "qs_set_gemm_variant": (None, [_i]),
     "qs_set_gemm_epilogue": (_i, [_i]),
     "qs_get_gemm_epilogue": (_i, []),
+    "qs_debug_gemm_clock_probe": (_i, [_vp, _i]),
+    "qs_set_row_sum_order": (_i, [_i]),
+    "qs_get_row_sum_order": (_i, []),
     "qs_w4a8_gemm_plan": (_i, [_i, _i, _i, _i, _vp]),
     "qs_w4a8_gemm_planes_plan": (_i, [_i, _i, _i, _i, _vp]),
     "qs_w4a8_per_chn_gemm_planes": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -77,15 +80,23 @@ def _load():
             "qserve_amd has no CPU / PyTorch fallback."
         )
     lib = C.CDLL(LIB_PATH)
+    missing = []
     for name, (res, args) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)   # AttributeError if the symbol is missing: loud by design
         except AttributeError:
-            if os.environ.get("QS_AMD_LIBRARY"):   # measurement scripts loading an OLDER build for an in-run A/B: entry points
-                continue                           # added since are simply absent there
+            # measurement scripts loading an OLDER build for an in-run A/B ask for it explicitly (QS_AMD_LIBRARY_AB=1): entry
+            # points added since are simply absent there.  A mere QS_AMD_LIBRARY (a wrong or stale path) stays an error.
+            if os.environ.get("QS_AMD_LIBRARY") and os.environ.get("QS_AMD_LIBRARY_AB") == "1":
+                missing.append(name)
+                continue
             raise
         fn.restype = res
         fn.argtypes = args
+    if missing:
+        import sys
+        print(f"[qserve_amd] QS_AMD_LIBRARY_AB=1: {LIB_PATH} lacks {len(missing)} entry point(s): {', '.join(missing)}",
+              file=sys.stderr)
     return lib
 
 
@@ -94,8 +105,8 @@ lib = _load()
 
 def device_status():
     """Error bits of the bounded in-launch waits on the current device (0 = healthy); blocking.  include/qserve_amd.h."""
-    if os.environ.get("QS_AMD_LIBRARY") and not hasattr(lib, "qs_device_status"):
-        return 0                                   # (an older build loaded for an A/B)
+    if not hasattr(lib, "qs_device_status"):       # (only possible under QS_AMD_LIBRARY_AB=1: an older build in an A/B)
+        raise RuntimeError(f"{LIB_PATH} has no qs_device_status: the health of its bounded waits cannot be read")
     bits = C.c_int(0)
     rc = lib.qs_device_status(C.byref(bits))
     if rc != 0:

@@ -24,34 +24,13 @@
 //   * numerics: KV4 dequantisation reproduces the reference bit for bit (exact nibble -> fp16, then one
 //     hfma2(h, half(scale), half(-scale*zero)), Utils.h:2190-2213); dot products and P.V accumulate in fp32.
 #include "common.h"
+#include "kv_quant.h"
 
 namespace {
 
 constexpr int TPB = 256;
 constexpr int PAGE_TOK = 64;
 constexpr int DH = 128;
-
-struct RopeCS {
-    float c, s;
-};
-// cos/sin of pos / base^(2i/dim): every step rounded to float32 from a double evaluation, so that host oracle and
-// device agree bit for bit (the reference's fast-math __powf/__cosf are not reproducible anyway).
-__device__ __forceinline__ RopeCS rope_coef(int pair, int pos, float base, int dim) {
-    const float expo = (float)(2 * pair) / (float)dim;
-    const float denom = (float)pow((double)base, (double)expo);
-    const float ang = (float)pos / denom;
-    RopeCS r;
-    r.c = (float)cos((double)ang);
-    r.s = (float)sin((double)ang);
-    return r;
-}
-__device__ __forceinline__ void rope_pair(float a, float b, RopeCS cs, _Float16& oa, _Float16& ob) {
-#pragma clang fp contract(off)
-    const float ra = cs.c * a - cs.s * b;   // Utils.h:1157-1158
-    const float rb = cs.c * b + cs.s * a;
-    oa = (_Float16)ra;
-    ob = (_Float16)rb;
-}
 
 // exact uint4 -> fp16 for the 8 nibbles of x, in the order (e0,e4),(e1,e5),(e2,e6),(e3,e7) (Utils.h:2125-2188)
 __device__ __forceinline__ void nib8_to_h2(u32 x, h2 (&o)[4]) {
@@ -69,24 +48,6 @@ __device__ __forceinline__ void nib8_to_h2(u32 x, h2 (&o)[4]) {
     o[3] = __builtin_elementwise_fma(__builtin_bit_cast(h2, w3), k16, km64);
 }
 
-struct QParams {
-    _Float16 scale, zero;
-    float inv;
-};
-// scale / zero / 1/scale of one (token, head) vector from its min and max (Template.hpp:1067, 1078-1079)
-__device__ __forceinline__ QParams make_qparams(float mn, float mx, bool int4) {
-    const float levels = int4 ? 15.f : 255.f;
-    QParams p;
-    const float rng = mx - mn;
-    p.scale = (_Float16)(rng / levels);
-    p.zero = (_Float16)((-levels * mn) / rng);
-    p.inv = 1.0f / (float)p.scale;
-    return p;
-}
-__device__ __forceinline__ unsigned quant_u8(_Float16 x, const QParams& p) {
-    return rni_sat_u8(fmaf((float)x, p.inv, (float)p.zero));   // Utils.h:2045-2077 (nvcc contracts mul+add)
-}
-
 // Quantise 128 fp16 values held as `vals[lane*2], vals[lane*2+1]` by the 64 lanes of ONE wave into dst (bytes of one
 // token/head) and write scale / zero.  All 64 lanes must call.
 template <bool INT4>
@@ -94,7 +55,7 @@ __device__ __forceinline__ void wave_quant_store(_Float16 v0, _Float16 v1, uint8
                                                  __half* zero_p, int lane) {
     const float mx = wave_max(fmaxf((float)v0, (float)v1));
     const float mn = wave_min(fminf((float)v0, (float)v1));
-    const QParams p = make_qparams(mn, mx, INT4);
+    const QParams p = make_qparams<INT4>(mn, mx);
     const unsigned u0 = quant_u8(v0, p), u1 = quant_u8(v1, p);
     if (INT4) {
         dst[lane] = (uint8_t)((u0 & 0xFu) | (u1 << 4));               // Utils.h:1838-1852
@@ -489,7 +450,7 @@ __device__ __forceinline__ void group_quant_store(const h8& lo, const h8& hi, ui
         mx = fmaxf(mx, __shfl_xor(mx, m, 64));
         mn = fminf(mn, __shfl_xor(mn, m, 64));
     }
-    const QParams p = make_qparams(mn, mx, INT4);
+    const QParams p = make_qparams<INT4>(mn, mx);
     unsigned ul[8], uh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

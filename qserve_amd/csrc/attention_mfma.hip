@@ -34,6 +34,8 @@
 //   * cache integers are exact in fp16 and every accumulation is fp32: the result is the exact attention over the
 //     de-quantised cache up to fp16 rounding of q, P' and the output (parity bar 1e-3, tests/test_attention_gpu.py).
 #include "common.h"
+#include "kv_quant.h"
+#include <mutex>
 
 namespace {
 
@@ -50,38 +52,6 @@ constexpr int QS_ATTNQ_ROW = 4096;   // values per row at most (H x 128 <= 4096:
 constexpr int SVC = NW - 1;    // the service wave (RoPE, operand build, new token) - the wave that owns the fewest units
 constexpr int MAXP = 192;      // longest page table this kernel is dispatched for (dispatcher: max_blocks <= MAXP)
 
-struct RopeCS {
-    float c, s;
-};
-__device__ __forceinline__ RopeCS rope_coef(int pair, int pos, float base, int dim) {
-    const float expo = (float)(2 * pair) / (float)dim;
-    const float denom = (float)pow((double)base, (double)expo);
-    const float ang = (float)pos / denom;
-    RopeCS r;
-    r.c = (float)cos((double)ang);
-    r.s = (float)sin((double)ang);
-    return r;
-}
-__device__ __forceinline__ void rope_pair(float a, float b, RopeCS cs, _Float16& oa, _Float16& ob) {
-#pragma clang fp contract(off)
-    const float ra = cs.c * a - cs.s * b;
-    const float rb = cs.c * b + cs.s * a;
-    oa = (_Float16)ra;
-    ob = (_Float16)rb;
-}
-
-struct QParams {
-    _Float16 scale, zero;
-    float inv;
-};
-__device__ __forceinline__ QParams make_qparams(float mn, float mx) {
-    QParams p;
-    const float rng = mx - mn;
-    p.scale = (_Float16)(rng / 15.f);
-    p.zero = (_Float16)((-15.f * mn) / rng);
-    p.inv = 1.0f / (float)p.scale;
-    return p;
-}
 // (explicit global address space: a generic pointer would make these FLAT stores, and a flat access may alias LDS, so
 // the compiler drains the LDS-DMA queue - vmcnt(0) - in front of it)
 typedef __attribute__((address_space(1))) uint8_t* g_u8;
@@ -92,9 +62,8 @@ __device__ __forceinline__ void wave_quant_store4(_Float16 v0, _Float16 v1, uint
     g_u16 scale_p = (g_u16)reinterpret_cast<uint16_t*>(scale_p_), zero_p = (g_u16)reinterpret_cast<uint16_t*>(zero_p_);
     const float mx = wave_max_dpp(fmaxf((float)v0, (float)v1));   // (max / min are order-independent: bit-exact)
     const float mn = wave_min_dpp(fminf((float)v0, (float)v1));
-    const QParams p = make_qparams(mn, mx);
-    const unsigned u0 = rni_sat_u8(fmaf((float)v0, p.inv, (float)p.zero));
-    const unsigned u1 = rni_sat_u8(fmaf((float)v1, p.inv, (float)p.zero));
+    const QParams p = make_qparams<true>(mn, mx);
+    const unsigned u0 = quant_u8(v0, p), u1 = quant_u8(v1, p);
     dst[lane] = (uint8_t)((u0 & 0xFu) | (u1 << 4));
     if (lane == 0) {
         *scale_p = __builtin_bit_cast(uint16_t, p.scale);
@@ -957,6 +926,8 @@ RopeTable g_rope[16][ROPE_SLOTS];
 // Library-managed RoPE table (per device, per base).  Returns nullptr when it cannot be (re)built right now, e.g.
 // while the stream is being captured into a graph before the first eager call; callers then compute in-kernel.
 const float2* qs_rope_table(float base, int max_pos, hipStream_t st, int* len_out) {
+    static std::mutex g_rope_mutex;   // host state of the slots (several host threads may drive their own bound streams)
+    std::lock_guard<std::mutex> lock(g_rope_mutex);
     int dev = 0;
     *len_out = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
@@ -982,10 +953,18 @@ const float2* qs_rope_table(float base, int max_pos, hipStream_t st, int* len_ou
         (void)hipGetLastError();
         return nullptr;
     }
-    slot->tab = reinterpret_cast<float2*>(p);
+    // The table is shared by every stream of the device: fill it and WAIT before publishing it (a launch on another stream
+    // issued right after this call must not read it half-built; the eager first build happens once per (device, base)).
+    hipLaunchKernelGGL(rope_table_kernel, dim3((max_pos * 64 + 255) / 256), dim3(256), 0, st, reinterpret_cast<float2*>(p),
+                       max_pos, base);
+    if (hipStreamSynchronize(st) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(p);
+        return nullptr;
+    }
     slot->len = max_pos;
     slot->base = base;
-    hipLaunchKernelGGL(rope_table_kernel, dim3((max_pos * 64 + 255) / 256), dim3(256), 0, st, slot->tab, max_pos, base);
+    slot->tab = reinterpret_cast<float2*>(p);
     *len_out = slot->len;
     return slot->tab;
 }
@@ -1091,9 +1070,10 @@ unsigned* qs_attn_error_word(int slot) {
         return nullptr;
     return g_qcounters[dev][slot] + QS_ATTNQ_CAP + (size_t)QS_ATTNQ_CAP * QS_ATTNQ_ROW;
 }
-void qs_attn_scratch_prealloc(hipStream_t st) {
-    (void)qs_split_workspace(1, st);
-    (void)qs_attn_quant_counters(st, 1);
+bool qs_attn_scratch_prealloc(hipStream_t st) {
+    const bool a = qs_split_workspace(1, st) != nullptr;
+    const bool b = qs_attn_quant_counters(st, 1) != nullptr;
+    return a && b;
 }
 int qs_attn_reset_handoff() {
     int dev = 0;

@@ -13,6 +13,7 @@
 //     chunk at position p of row r holds chunk p ^ ((r >> 1) & 7); V rows are stored in slot s = tok ^ ((tok >> 2) & 1)
 //     (the probabilities are packed in the same order, so the contraction is unchanged).
 #include "common.h"
+#include "kv_quant.h"
 
 namespace {
 
@@ -23,41 +24,17 @@ constexpr int NW = 4;          // waves per workgroup
 constexpr int MAXP = 192;      // page-table entries cached in LDS per sequence (dispatcher: max_blocks <= MAXP)
 constexpr int NVM = 9;         // VMEM instructions of one page-slice fetch (8 x 1 KiB + scales|zeros)
 
-struct RopeCS {
-    float c, s;
-};
-__device__ __forceinline__ RopeCS rope_coef(int pair, int pos, float base, int dim) {
-    const float expo = (float)(2 * pair) / (float)dim;
-    const float denom = (float)pow((double)base, (double)expo);
-    const float ang = (float)pos / denom;
-    RopeCS r;
-    r.c = (float)cos((double)ang);
-    r.s = (float)sin((double)ang);
-    return r;
-}
-__device__ __forceinline__ void rope_pair(float a, float b, RopeCS cs, _Float16& oa, _Float16& ob) {
-#pragma clang fp contract(off)
-    const float ra = cs.c * a - cs.s * b;
-    const float rb = cs.c * b + cs.s * a;
-    oa = (_Float16)ra;
-    ob = (_Float16)rb;
-}
-
 // 8-bit quantiser of one (token, head) vector held two elements per lane (Template.hpp:1045-1082, Utils.h:2045-2053)
 __device__ __forceinline__ void wave_quant_store8(_Float16 v0, _Float16 v1, uint8_t* dst, __half* scale_p,
                                                   __half* zero_p, int lane) {
     const float mx = wave_max(fmaxf((float)v0, (float)v1));
     const float mn = wave_min(fminf((float)v0, (float)v1));
-    const float rng = mx - mn;
-    const _Float16 scale = (_Float16)(rng / 255.f);
-    const _Float16 zero = (_Float16)((-255.f * mn) / rng);
-    const float inv = 1.0f / (float)scale;
-    const unsigned u0 = rni_sat_u8(fmaf((float)v0, inv, (float)zero));
-    const unsigned u1 = rni_sat_u8(fmaf((float)v1, inv, (float)zero));
+    const QParams p = make_qparams<false>(mn, mx);
+    const unsigned u0 = quant_u8(v0, p), u1 = quant_u8(v1, p);
     *reinterpret_cast<uint16_t*>(dst + 2 * lane) = (uint16_t)(u0 | (u1 << 8));
     if (lane == 0) {
-        *scale_p = __builtin_bit_cast(__half, scale);
-        *zero_p = __builtin_bit_cast(__half, zero);
+        *scale_p = __builtin_bit_cast(__half, p.scale);
+        *zero_p = __builtin_bit_cast(__half, p.zero);
     }
 }
 

@@ -89,6 +89,8 @@ __device__ __forceinline__ float epi_per_group(int acc, float ws, float sa) {
     return (float)acc * sc;
 }
 extern int g_epi_fma;   // gemm_w4a8.hip: qs_set_gemm_epilogue
+extern unsigned long long* g_gemm_clk;   // gemm_w4a8.hip: qs_debug_gemm_clock_probe (device buffer, 2 words per workgroup) or null
+extern int g_gemm_clk_cap;               // workgroups the buffer holds
 
 // compute units of the current device (cached per device; 256 on MI355X)
 static inline int qs_num_cus() {
@@ -205,9 +207,9 @@ extern int g_inject_fault;                    // lib.hip: bit 0 next K-sliced ri
 // calling thread's current device.
 constexpr int QS_MAX_STREAM_SLOTS = 8;
 int qs_scratch_slot(hipStream_t stream);
-void qs_gemm_scratch_prealloc(hipStream_t stream);      // gemm_w4a8.hip     } allocate the slot's areas now (qs_stream_scratch_bind:
-void qs_attn_scratch_prealloc(hipStream_t stream);      // attention_mfma.hip } a first use inside a stream capture could not)
-void qs_argmax_scratch_prealloc(hipStream_t stream);    // fused_small.hip   }
+bool qs_gemm_scratch_prealloc(hipStream_t stream);      // gemm_w4a8.hip     } allocate the slot's areas now (qs_stream_scratch_bind:
+bool qs_attn_scratch_prealloc(hipStream_t stream);      // attention_mfma.hip } a first use inside a stream capture could not)
+bool qs_argmax_scratch_prealloc(hipStream_t stream);    // fused_small.hip   }
 unsigned* qs_gemm_error_word(int slot);       // gemm_w4a8.hip: nullptr until that slot's split-K workspace exists
 unsigned* qs_attn_error_word(int slot);       // attention_mfma.hip: nullptr until that slot's hand-over workspace exists
 int qs_gemm_reset_handoff();                  // gemm_w4a8.hip: sentinel-fill the K-slice slabs, clear the error word

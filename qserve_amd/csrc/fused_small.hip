@@ -92,18 +92,22 @@ __global__ __launch_bounds__(NT) void quant_kernel(int8_t* __restrict__ out, con
 
 // ---------------------------------------------------------------------------------------------------------
 
-template <int NC>
+// REFSUM instantiations (qs_set_row_sum_order(1)): the row sum in the reference's order, `hidden` halves of dynamic LDS.
+extern __shared__ __attribute__((aligned(16))) _Float16 s_hv_dyn[];
+
+template <int NC, bool REFSUM = false>
 __global__ __launch_bounds__(TPB) void general_norm_quant_kernel(int8_t* __restrict__ out,
                                                                  const _Float16* __restrict__ in,
                                                                  const _Float16* __restrict__ gamma,
                                                                  __half* __restrict__ sum_out,
                                                                  __half* __restrict__ scale_out, float eps,
                                                                  int hidden) {
-    __shared__ float sm[4 * (TPB / 64)];
+    __shared__ float sm[4 * (TPB / 64) + (REFSUM ? 32 : 0)];
     const size_t base = (size_t)blockIdx.x * hidden;
-    qs_row::norm_quant_row<NC, TPB / 64, TPB / 64, false, false>(
+    qs_row::norm_quant_row<NC, TPB / 64, TPB / 64, false, false, qs_row::NoHook, qs_row::FromRow, false, REFSUM>(
         out + base, const_cast<_Float16*>(in) + base, nullptr, gamma, sum_out ? sum_out + blockIdx.x : nullptr,
-        scale_out + blockIdx.x, eps, hidden, sm, (int)threadIdx.x);
+        scale_out + blockIdx.x, eps, hidden, sm, (int)threadIdx.x, qs_row::NoHook(), qs_row::FromRow(),
+        REFSUM ? s_hv_dyn : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(TPB) void residual_add_kernel(_Float16* __restrict_
 // the intermediate fp16 rounding of the op pair they replace, i.e. they are bit-identical to calling the two ops.
 //
 //   add_residual_norm_quant : hidden += delta (fp16 add, written back) ; rms_norm_general(_fuse_sum)(hidden)
-template <int NC, bool FULL>
+template <int NC, bool FULL, bool REFSUM = false>
 __global__ __launch_bounds__(TPB) void add_residual_norm_quant_kernel(int8_t* __restrict__ out,
                                                                       _Float16* __restrict__ hidden_io,
                                                                       const _Float16* __restrict__ delta,
@@ -172,23 +176,24 @@ __global__ __launch_bounds__(TPB) void add_residual_norm_quant_kernel(int8_t* __
                                                                       __half* __restrict__ sum_out,
                                                                       __half* __restrict__ scale_out, float eps,
                                                                       int hidden) {
-    __shared__ float sm[4 * (TPB / 64)];
+    __shared__ float sm[4 * (TPB / 64) + (REFSUM ? 32 : 0)];
     const size_t base = (size_t)blockIdx.x * hidden;
-    qs_row::norm_quant_row<NC, TPB / 64, TPB / 64, true, false, qs_row::NoHook, qs_row::FromRow, FULL>(
+    qs_row::norm_quant_row<NC, TPB / 64, TPB / 64, true, false, qs_row::NoHook, qs_row::FromRow, FULL, REFSUM>(
         out + base, hidden_io + base, delta + base, gamma, sum_out ? sum_out + blockIdx.x : nullptr,
-        scale_out + blockIdx.x, eps, hidden, sm, (int)threadIdx.x);
+        scale_out + blockIdx.x, eps, hidden, sm, (int)threadIdx.x, qs_row::NoHook(), qs_row::FromRow(),
+        REFSUM ? s_hv_dyn : nullptr);
 }
 
 //   add_residual_norm_quant over K-slice PLANES (round 4): the residual branch arrives as the int32 planes a W4A8 GEMM left
 //   (qs_w4a8_*_gemm_planes) instead of its fp16 output; delta = fp16(GEMM epilogue(sum of the planes)) is formed here, bit for
 //   bit what the GEMM would have stored, then everything is add_residual_norm_quant.  `ascale` / `asum` are the activation scale /
 //   sum the GEMM's INPUT was quantised with; they may alias scale_out / sum_out (a row reads its own values before it writes).
-template <int NC, int KS, int MODE, bool FULL>
+template <int NC, int KS, int MODE, bool FULL, bool REFSUM = false>
 __global__ __launch_bounds__(TPB) void add_residual_norm_quant_planes_kernel(
     int8_t* __restrict__ out, _Float16* __restrict__ hidden_io, const int* __restrict__ planes, size_t pstride,
     const _Float16* __restrict__ wscales, const _Float16* __restrict__ wszs, const __half* ascale, const __half* asum,
     const _Float16* __restrict__ gamma, __half* sum_out, __half* scale_out, float eps, int hidden, int epi_fma) {
-    __shared__ float sm[4 * (TPB / 64)];
+    __shared__ float sm[4 * (TPB / 64) + (REFSUM ? 32 : 0)];
     const size_t base = (size_t)blockIdx.x * hidden;
     qs_row::FromPlanes<KS, MODE> dfn;
     dfn.fma = epi_fma;
@@ -198,9 +203,9 @@ __global__ __launch_bounds__(TPB) void add_residual_norm_quant_planes_kernel(
     dfn.wz = wszs;
     dfn.sa = __half2float(ascale[blockIdx.x]);
     dfn.ss = MODE == 0 ? __half2float(asum[blockIdx.x]) : 0.f;
-    qs_row::norm_quant_row<NC, TPB / 64, TPB / 64, true, false, qs_row::NoHook, qs_row::FromPlanes<KS, MODE>, FULL>(
+    qs_row::norm_quant_row<NC, TPB / 64, TPB / 64, true, false, qs_row::NoHook, qs_row::FromPlanes<KS, MODE>, FULL, REFSUM>(
         out + base, hidden_io + base, nullptr, gamma, sum_out ? sum_out + blockIdx.x : nullptr, scale_out + blockIdx.x, eps,
-        hidden, sm, (int)threadIdx.x, qs_row::NoHook(), dfn);
+        hidden, sm, (int)threadIdx.x, qs_row::NoHook(), dfn, REFSUM ? s_hv_dyn : nullptr);
 }
 
 //   silu_mul_quant : act = silu_and_mul(input) rounded to fp16 (never written) ; invoke_quant(_fuse_sum)(act)
@@ -255,7 +260,16 @@ __global__ __launch_bounds__(NT) void silu_mul_quant_kernel(int8_t* __restrict__
     }
 }
 
+int g_row_refsum = 0;
+
 }  // namespace
+
+extern "C" int qs_set_row_sum_order(int order) {
+    QS_REQUIRE(order == 0 || order == 1, "qs_set_row_sum_order: %d not in {0 = this library's fp32 chains, 1 = the reference's order}", order);
+    g_row_refsum = order;
+    return QS_OK;
+}
+extern "C" int qs_get_row_sum_order(void) { return g_row_refsum; }
 
 extern "C" int qs_invoke_quant(int8_t* out, const void* input, void* input_sum, void* scale, int num_tokens,
                                int hidden, qs_stream_t stream) {
@@ -286,10 +300,18 @@ extern "C" int qs_rms_norm_general(int8_t* out, const void* input, const void* w
     if (num_tokens <= 0) return QS_OK;
     QS_REQUIRE(hidden <= 8 * TPB * 8, "rms_norm_general: hidden=%d larger than %d is not supported", hidden, 8 * TPB * 8);
     const int nc = (hidden + TPB * 8 - 1) / (TPB * 8);
-#define QS_N(NC)                                                                                                   \
-    hipLaunchKernelGGL(general_norm_quant_kernel<NC>, dim3(num_tokens), dim3(TPB), 0, (hipStream_t)stream, out,     \
-                       (const _Float16*)input, (const _Float16*)weight, (__half*)input_sum, (__half*)scaling, epsilon, \
-                       hidden)
+    const bool refsum = g_row_refsum && input_sum;   // (the order of the row sum matters only where a sum is asked for)
+#define QS_N(NC)                                                                                                         \
+    do {                                                                                                                 \
+        if (refsum)                                                                                                      \
+            hipLaunchKernelGGL((general_norm_quant_kernel<NC, true>), dim3(num_tokens), dim3(TPB), hidden * 2,           \
+                               (hipStream_t)stream, out, (const _Float16*)input, (const _Float16*)weight,                \
+                               (__half*)input_sum, (__half*)scaling, epsilon, hidden);                                   \
+        else                                                                                                             \
+            hipLaunchKernelGGL((general_norm_quant_kernel<NC, false>), dim3(num_tokens), dim3(TPB), 0,                   \
+                               (hipStream_t)stream, out, (const _Float16*)input, (const _Float16*)weight,                \
+                               (__half*)input_sum, (__half*)scaling, epsilon, hidden);                                   \
+    } while (0)
     switch (nc) {
         case 1: QS_N(1); break;
         case 2: QS_N(2); break;
@@ -499,7 +521,7 @@ ArgmaxWs* argmax_ws(hipStream_t stream) {
 }
 }  // namespace
 
-void qs_argmax_scratch_prealloc(hipStream_t stream) { (void)argmax_ws(stream); }
+bool qs_argmax_scratch_prealloc(hipStream_t stream) { return argmax_ws(stream) != nullptr; }
 int g_argmax_split = -1;   // qs_debug_argmax_split: -1 heuristic, 1 one workgroup per row, >= 2 forced split (tests, A/B)
 extern "C" void qs_debug_argmax_split(int split) { g_argmax_split = split; }
 
@@ -549,9 +571,14 @@ extern "C" int qs_add_residual_rms_norm_general(int8_t* out, void* hidden_io, co
     QS_REQUIRE(hidden <= 8 * TPB * 8, "add_residual_rms_norm_general: hidden=%d larger than %d is not supported", hidden,
                8 * TPB * 8);
     const int nc = (hidden + TPB * 8 - 1) / (TPB * 8);
+    const bool refsum = g_row_refsum && input_sum;
 #define QS_N(NC)                                                                                                      \
     do {                                                                                                              \
-        if (hidden == NC * TPB * 8)                                                                                   \
+        if (refsum)                                                                                                   \
+            hipLaunchKernelGGL((add_residual_norm_quant_kernel<NC, false, true>), dim3(num_tokens), dim3(TPB),        \
+                               hidden * 2, (hipStream_t)stream, out, (_Float16*)hidden_io, (const _Float16*)delta,    \
+                               (const _Float16*)weight, (__half*)input_sum, (__half*)scaling, epsilon, hidden);       \
+        else if (hidden == NC * TPB * 8)                                                                              \
             hipLaunchKernelGGL((add_residual_norm_quant_kernel<NC, true>), dim3(num_tokens), dim3(TPB), 0,            \
                                (hipStream_t)stream, out, (_Float16*)hidden_io, (const _Float16*)delta,                \
                                (const _Float16*)weight, (__half*)input_sum, (__half*)scaling, epsilon, hidden);       \
@@ -589,18 +616,23 @@ extern "C" int qs_add_residual_rms_norm_general_planes(int8_t* out, void* hidden
     QS_REQUIRE(hidden <= 2 * TPB * 8, "add_residual_rms_norm_general_planes: hidden=%d larger than %d is not supported", hidden,
                2 * TPB * 8);
     const int nc = (hidden + TPB * 8 - 1) / (TPB * 8);
+    const bool refsum = g_row_refsum && input_sum;
 #define QS_P(NC, KS, MODE)                                                                                                \
-    hipLaunchKernelGGL((add_residual_norm_quant_planes_kernel<NC, KS, MODE, FULLV>), dim3(num_tokens), dim3(TPB), 0,        \
-                       (hipStream_t)stream, out, (_Float16*)hidden_io, planes, (size_t)plane_stride, (const _Float16*)wscales, \
-                       (const _Float16*)w_szs, (const __half*)ascales, (const __half*)a_ssums, (const _Float16*)weight,     \
-                       (__half*)input_sum, (__half*)scaling, epsilon, hidden, g_epi_fma)
+    hipLaunchKernelGGL((add_residual_norm_quant_planes_kernel<NC, KS, MODE, FULLV, REFV>), dim3(num_tokens), dim3(TPB),    \
+                       REFV ? hidden * 2 : 0, (hipStream_t)stream, out, (_Float16*)hidden_io, planes, (size_t)plane_stride, \
+                       (const _Float16*)wscales, (const _Float16*)w_szs, (const __half*)ascales, (const __half*)a_ssums,  \
+                       (const _Float16*)weight, (__half*)input_sum, (__half*)scaling, epsilon, hidden, g_epi_fma)
 #define QS_PF(NC, KS, MODE)                                       \
     do {                                                          \
-        if (hidden == NC * TPB * 8) {                             \
+        if (refsum) {                                             \
+            constexpr bool FULLV = false, REFV = true;            \
+            QS_P(NC, KS, MODE);                                   \
+        } else if (hidden == NC * TPB * 8) {                      \
+            constexpr bool REFV = false;                          \
             constexpr bool FULLV = true;                          \
             QS_P(NC, KS, MODE);                                   \
         } else {                                                  \
-            constexpr bool FULLV = false;                         \
+            constexpr bool FULLV = false, REFV = false;           \
             QS_P(NC, KS, MODE);                                   \
         }                                                         \
     } while (0)

@@ -317,7 +317,7 @@ unsigned* qs_gemm_error_word(int slot) {
     Workspace& w = g_ws[dev][slot];
     return w.slabs ? w.counters + (w.ncounters - 1) : nullptr;
 }
-void qs_gemm_scratch_prealloc(hipStream_t stream) { (void)get_workspace(stream); }
+bool qs_gemm_scratch_prealloc(hipStream_t stream) { return get_workspace(stream) != nullptr; }
 int qs_gemm_reset_handoff() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return QS_OK;
@@ -665,6 +665,15 @@ extern "C" int qs_set_gemm_epilogue(int convention) {
     return QS_OK;
 }
 extern "C" int qs_get_gemm_epilogue(void) { return g_epi_fma; }
+
+unsigned long long* g_gemm_clk = nullptr;
+int g_gemm_clk_cap = 0;
+extern "C" int qs_debug_gemm_clock_probe(void* buf, int workgroups) {
+    QS_REQUIRE((buf == nullptr) == (workgroups == 0) && workgroups >= 0, "qs_debug_gemm_clock_probe: buffer and capacity come together");
+    g_gemm_clk = reinterpret_cast<unsigned long long*>(buf);
+    g_gemm_clk_cap = workgroups;
+    return QS_OK;
+}
 
 extern "C" int qs_w4a8_gemm_plan(int per_group, int M, int N, int K, int* plan5) {
     QS_REQUIRE(plan5, "w4a8 gemm plan: null output");

@@ -67,7 +67,15 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
                                                           const __half* __restrict__ ascales,
                                                           const __half* __restrict__ wszs,
                                                           const __half* __restrict__ assums, void* __restrict__ out,
-                                                          int M, int N, int K, int nbm, int order, int epi_fma) {
+                                                          int M, int N, int K, int nbm, int order, int epi_fma,
+                                                          unsigned long long* __restrict__ clk) {
+    // clk != nullptr (qs_debug_gemm_clock_probe, bench.py): this workgroup's life in shader cycles (s_memtime) and in ticks of
+    // the constant 100 MHz counter (s_memrealtime) -> the engine clock the launch actually held.  Four scalar instructions.
+    unsigned long long ck0 = 0, rt0 = 0;
+    if (clk) {
+        ck0 = __builtin_amdgcn_s_memtime();
+        rt0 = __builtin_amdgcn_s_memrealtime();
+    }
     constexpr int BM = 32 * MT;                       // tokens per workgroup
     constexpr int APAIR = BM * 128;                   // activation bytes per stage pair (128 k)
     constexpr int NA2 = APAIR / 8192;                 // 8 KiB all-thread DMA instructions per activation pair
@@ -486,6 +494,10 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
         if (!PERSIST || next >= ntiles) break;
         tile = next;
     }
+    if (clk && threadIdx.x == 0) {
+        clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - ck0;
+        clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
 }
 
 template <int MT, int MODE, int OUTK, int DBG = 0>
@@ -515,7 +527,7 @@ int launch_tiled(const int8_t* A, const uint8_t* W, const int8_t* zeros, const i
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, A, W, zeros, scales8,
                        reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
                        reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K,
-                       nbm, g_tiled_order % 10, g_epi_fma);
+                       nbm, g_tiled_order % 10, g_epi_fma, grid.x <= (unsigned)g_gemm_clk_cap ? g_gemm_clk : nullptr);
     return qs_launch_status("w4a8 gemm (tiled)");
 }
 

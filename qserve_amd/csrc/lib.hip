@@ -19,6 +19,13 @@ int g_inject_fault = 0;
 extern "C" int qs_device_status(int* error_bits) {
     QS_REQUIRE(error_bits, "qs_device_status: null output");
     *error_bits = 0;
+    {   // a null-stream copy does not order behind non-blocking streams (torch's pool / side streams are): wait for the device
+        const hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            qs_set_error("qs_device_status: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+    }
     for (int i = 0; i < 2 * QS_MAX_STREAM_SLOTS; ++i) {
         unsigned* w = i & 1 ? qs_attn_error_word(i >> 1) : qs_gemm_error_word(i >> 1);
         if (!w) continue;
@@ -70,6 +77,7 @@ extern "C" int qs_stream_scratch_bind(qs_stream_t stream) {
         return QS_EINVAL;
     }
     const int d = qs_device_slot();
+    int taken = 0;
     {
         std::lock_guard<std::mutex> lock(g_slot_mutex);
         int free_slot = 0;
@@ -84,10 +92,18 @@ extern "C" int qs_stream_scratch_bind(qs_stream_t stream) {
         g_slot_stream[d][free_slot] = st;
         g_slot_bound[d][free_slot] = true;
         __atomic_add_fetch(&g_slots_bound[d], 1, __ATOMIC_RELEASE);
+        taken = free_slot;
     }
-    qs_gemm_scratch_prealloc(st);
-    qs_attn_scratch_prealloc(st);
-    qs_argmax_scratch_prealloc(st);
+    const bool ok_g = qs_gemm_scratch_prealloc(st), ok_a = qs_attn_scratch_prealloc(st), ok_m = qs_argmax_scratch_prealloc(st);
+    if (!(ok_g && ok_a && ok_m)) {   // (what was allocated stays with the slot; an area whose allocation failed is not retried - `tried`)
+        std::lock_guard<std::mutex> lock(g_slot_mutex);
+        g_slot_bound[d][taken] = false;
+        __atomic_sub_fetch(&g_slots_bound[d], 1, __ATOMIC_RELEASE);
+        qs_set_error("qs_stream_scratch_bind: allocating the slot's scratch areas failed (GEMM workspace %s, attention workspace %s, "
+                     "argmax workspace %s); the stream stays on the shared set", ok_g ? "ok" : "FAILED", ok_a ? "ok" : "FAILED",
+                     ok_m ? "ok" : "FAILED");
+        return QS_ENOSUP;
+    }
     return QS_OK;
 }
 extern "C" int qs_stream_scratch_unbind(qs_stream_t stream) {

@@ -155,6 +155,40 @@ __device__ __forceinline__ void reduce_max_sum(float (&mx)[NVW / PW], float (&su
     sum_out = s;
 }
 
+// ---- the row sum in the REFERENCE's order (qs_set_row_sum_order(1)) ------------------------------------------------------
+// generalLayerNorm_fuse_sum (layernorm_kernels.cu:275-306) runs min(hidden, 1024) threads (rounded up to 32) per token; thread t
+// adds the normalised fp16 values of elements t, t + nt, ... into a HALF accumulator (`T_scalar sum`; `sum += float` is the
+// half + half operator: one fp16 rounding per addition), the partials are widened to fp32 and all-reduced: xor butterfly
+// 16, 8, 4, 2, 1 inside each 32-thread warp, warp results through shared memory, the same butterfly over the (at most 32) warp
+// slots (reduction_utils.cuh:68-85).  `hv` = the row's normalised fp16 values in LDS (written by every thread, barrier done);
+// `sm` = 32 floats of LDS.  256 physical threads play the nt reference threads four at a time; a wave64 half is a reference warp.
+// Returns the sum to thread 0 (other threads: unspecified).
+__device__ __forceinline__ float ref_order_row_sum(const _Float16* hv, int hidden, float* sm, int tid) {
+#pragma clang fp contract(off)
+    int nt = hidden < 1024 ? hidden : 1024;
+    nt = 32 * ((nt + 31) / 32);                                          // layernorm_kernels.cu:480-481
+    if (tid < 32) sm[tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rt = tid + 256 * j;                                    // reference thread; 32-aligned groups stay together
+        _Float16 acc = (_Float16)0.f;
+        if (rt < nt)
+            for (int i = rt; i < hidden; i += nt) {
+                acc = acc + hv[i];                                       // fp16 add (v_add_f16), one rounding (:286)
+            }
+        float f = (float)acc;
+#pragma unroll
+        for (int m = 16; m > 0; m >>= 1) f = f + __shfl_xor(f, m, 32);   // warpReduceSum, reduction_utils.cuh:25-30
+        if ((tid & 31) == 0 && rt < nt) sm[rt >> 5] = f;
+    }
+    __syncthreads();
+    float w = tid < 32 ? sm[tid] : 0.f;                                  // slots beyond nt / 32 hold 0 (:82)
+#pragma unroll
+    for (int m = 16; m > 0; m >>= 1) w = w + __shfl_xor(w, m, 32);
+    return w;
+}
+
 // ---- invoke_quant(_fuse_sum) of one row -------------------------------------------------------------------------------
 // out int8 [hidden], in fp16 [hidden]; sum_out may be null.  sm: 2 * NVW floats of LDS.  SC: `in` was published by other
 // workgroups of this launch (cache-bypassing loads).  `ready` runs before the first load of `in` (the GEMM tail waits there
@@ -235,11 +269,15 @@ __device__ __forceinline__ void quant_row(int8_t* __restrict__ out, const _Float
 // ADD = false: no residual (plain general_norm_quant; `delta` unused, hidden_io read only).  sm: 4 * NVW floats of LDS.
 // SC: `delta` was published by other workgroups of this launch.  `ready` runs after the loads of hidden / gamma were
 // requested and before the first load of `delta`.
-template <int NC, int NVW, int PW, bool ADD, bool SC, class Hook = NoHook, class DeltaFn = FromRow, bool FULL = false>
+// REFSUM (round 6): the row sum in the reference's own order (ref_order_row_sum above) instead of this kernel's fp32 chains;
+// `hvbuf` = `hidden` halves of LDS, `sm` then needs 4 * NVW + 32 floats.  Everything else is unchanged, bit for bit.
+template <int NC, int NVW, int PW, bool ADD, bool SC, class Hook = NoHook, class DeltaFn = FromRow, bool FULL = false,
+          bool REFSUM = false>
 __device__ __forceinline__ void norm_quant_row(int8_t* __restrict__ out, _Float16* __restrict__ hidden_io,
                                                const _Float16* __restrict__ delta, const _Float16* __restrict__ gamma,
                                                __half* __restrict__ sum_out, __half* __restrict__ scale_out, float eps,
-                                               int hidden, float* sm, int tid, Hook ready = Hook(), DeltaFn dfn = DeltaFn()) {
+                                               int hidden, float* sm, int tid, Hook ready = Hook(), DeltaFn dfn = DeltaFn(),
+                                               _Float16* hvbuf = nullptr) {
     // FULL: the row is exactly NC * NT * 8 values wide (every chunk of every thread exists): no exec-masked blocks, so the compiler
     // can count the outstanding loads across them and issue the final stores back to back (round 4: with the masks it put a
     // vmcnt(0) - a store acknowledgement - between the two chunks' stores).
@@ -250,6 +288,7 @@ __device__ __forceinline__ void norm_quant_row(int8_t* __restrict__ out, _Float1
 #pragma clang fp contract(off)
     constexpr int VPW = NVW / PW, NT = 64 * NVW;
     static_assert(NVW % PW == 0, "virtual waves must split evenly over the physical waves");
+    static_assert(!REFSUM || (NVW == 4 && PW == 4), "the reference-order row sum is written for the 256-thread row kernels");
     const int wave = tid >> 6, lane = tid & 63;
     constexpr bool active = true;   // (every thread of the workgroup owns elements: the launch has exactly 64 PW threads.  The
                                     //  round-3 GEMM tails ran these functions on a subset of a larger workgroup; as a run-time
@@ -365,14 +404,19 @@ __device__ __forceinline__ void norm_quant_row(int8_t* __restrict__ out, _Float1
                         QS_SEQ(hvf);
                         const _Float16 hv = (_Float16)hvf;                                                     // cast to half, :292
                         amax[j] = fmaxf(amax[j], fabsf((float)hv));
-                        sum[j] += (float)hv;
-                        QS_SEQ(sum[j]);
+                        if (REFSUM) {
+                            hvbuf[(c * NT + tid + j * 64 * PW) * 8 + e] = hv;
+                        } else {
+                            sum[j] += (float)hv;
+                            QS_SEQ(sum[j]);
+                        }
                     }
                 }
         }
     }
     float mx, sm_row;
-    reduce_max_sum<NVW, PW>(amax, sum, sm + 2 * NVW, sm + 3 * NVW, sum_out != nullptr, wave, lane, active, mx, sm_row);
+    reduce_max_sum<NVW, PW>(amax, sum, sm + 2 * NVW, sm + 3 * NVW, !REFSUM && sum_out != nullptr, wave, lane, active, mx, sm_row);
+    if (REFSUM) sm_row = ref_order_row_sum(hvbuf, hidden, sm + 4 * NVW, tid);   // (reduce_max_sum's barrier published hvbuf)
     const float mul = 127.f / mx;                                        // :308
     if (active) {
 #pragma unroll

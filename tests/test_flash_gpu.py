@@ -49,6 +49,35 @@ def test_llama_shape_prefill(gpu):
     _case(gpu, [1024, 700], [1024, 700], 32, 8, True, seed=9)
 
 
+def test_config5_prompt_8k_sampled_rows(gpu):
+    """BASELINE config 5's prompt: one 8 192-token sequence next to a 5 000-token one, Llama-3-8B heads, causal, q / k / v as
+    views of the packed qkv buffer (llama_w4a8_unpad.py:232-242).  The float64 oracle on sampled (query row, head) pairs - rows
+    at both ends, around the 64-key tile and 128-row workgroup boundaries, deep into the sequence - within 2e-3; every output
+    finite; and a size-independent property over ALL rows: the first row of each sequence attends to one key, so it equals v[0]."""
+    from flash_attn.flash_attn_interface import flash_attn_varlen_func
+    H, Hkv = 32, 8
+    lens = [8192, 5000]
+    T = sum(lens)
+    g = torch.Generator(device=gpu).manual_seed(58)
+    qkv = torch.randn((T, (H + 2 * Hkv) * 128), generator=g, device=gpu, dtype=torch.float16)
+    q, k, v = qkv.split([H * 128, Hkv * 128, Hkv * 128], dim=-1)
+    q, k, v = q.reshape(T, H, 128), k.reshape(T, Hkv, 128), v.reshape(T, Hkv, 128)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    out = flash_attn_varlen_func(q, k, v, dev(cu), dev(cu), max(lens), max(lens), dropout_p=0.0, causal=True)
+    torch.cuda.synchronize()
+    assert out.shape == (T, H, 128) and torch.isfinite(out.float()).all()
+    rows = [0, 1, 63, 64, 127, 128, 129, 2999, 3000, 4095, 4096, 6000, 8127, 8190, 8191,
+            8192, 8192 + 1, 8192 + 2999, 8192 + 4096, 8192 + 4999]
+    heads = [0, 5, 17, 31]
+    ref = oflash.attention_rows(q.cpu().numpy(), k.cpu().numpy(), v.cpu().numpy(), cu, cu, rows, heads)
+    got = out[torch.tensor(rows, device=gpu)][:, torch.tensor(heads, device=gpu)].cpu().numpy().astype(np.float32)
+    err = np.abs(got - ref)
+    assert err.max() <= TOL, f"max abs err {err.max():.2e} at {np.unravel_index(err.argmax(), err.shape)}"
+    for b in range(2):
+        t0 = int(cu[b])
+        assert torch.equal(out[t0].reshape(Hkv, H // Hkv, 128), v[t0][:, None, :].expand(Hkv, H // Hkv, 128))
+
+
 def test_rejects_unsupported(gpu):
     from flash_attn.flash_attn_interface import flash_attn_varlen_func
     q = torch.zeros((4, 2, 128), dtype=torch.float16, device=gpu)
