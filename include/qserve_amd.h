@@ -128,6 +128,8 @@ int qs_w8a8_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscal
  *   3003 ... the four-wave compute-bound tile forced (3001: the eight-wave one), 3400 + bits ... [QS_TIMING builds] its ablations,
  *   4100 + 100*(k_slices-1) + 10*m_tiles + units ... forced ring geometry;
  *   5000 + bits ... A/B switches of the ring kernel (1: weight DMA without the non-temporal hint; 256 * d: ring depth d;
+ *                   4096: K slices of a channel block on ONE XCD, the mapping of rounds 3-5 - default since round 6: slices across the
+ *                   XCDs so that an L2 holds only its K slice of the activations;
  *                   [QS_TIMING builds: 32 / 64 no MFMA / no operand reads]); sticky until reset with 5000;
  *   3200 + 10*p + o ... tiled kernel A/B, sticky until reset with 3200: tile order o (0 super-tiles with the XCD-aware 4 x 8
  *                   placement inside a super-tile, 3 super-tiles without it, 1 / 2 token- / channel-fastest bands); p = 1 one

@@ -21,7 +21,43 @@ def rni_sat_s8(x):
     return np.clip(r, -128, 127).astype(np.int8)
 
 
-def quant_per_token(x, with_sum=False):
+def _wave64_butterfly_sum(f):
+    """qserve_amd/csrc/common.h wave_sum: xor butterfly 32, 16, 8, 4, 2, 1 over the last axis (64 lanes), fp32."""
+    f = np.asarray(f, np.float32)
+    lanes = np.arange(64)
+    for m in (32, 16, 8, 4, 2, 1):
+        f = (f + f[..., lanes ^ m]).astype(np.float32)
+    return f[..., 0]
+
+
+def hip_order_row_sum(contrib, nt=256):
+    """The row sums exactly as qserve_amd/csrc/row_ops.h orders them (the LIBRARY's own order, stated here so that the GPU tests can
+    demand bit-equality instead of "equal up to the association of an fp32 sum"): `nt` virtual threads per row (256; 1024 for
+    invoke_quant / silu_and_mul_quant rows wider than 4096); thread t owns the 8-element chunks (c * nt + t) * 8 .. + 7 and adds
+    its fp32 contributions sequentially (c outer, element inner, starting from +0); wave64 butterfly; waves left to right.
+    contrib: float32 [T, H] (H % 8 == 0)."""
+    contrib = np.asarray(contrib, np.float32)
+    T, H = contrib.shape
+    nc = (H + nt * 8 - 1) // (nt * 8)
+    pad = np.zeros((T, nc * nt * 8), np.float32)
+    pad[:, :H] = contrib
+    a = pad.reshape(T, nc, nt, 8)
+    acc = np.zeros((T, nt), np.float32)
+    for c in range(nc):
+        for e in range(8):
+            acc = (acc + a[:, c, :, e]).astype(np.float32)
+    w = _wave64_butterfly_sum(acc.reshape(T, nt // 64, 64))          # [T, waves]
+    tot = w[:, 0]
+    for k in range(1, nt // 64):
+        tot = (tot + w[:, k]).astype(np.float32)
+    return tot
+
+
+def _quant_threads(hidden):
+    return 1024 if hidden > 4096 else 256          # row_ops.h WIDE_ROW
+
+
+def quant_per_token(x, with_sum=False, sum_order="exact"):
     """fused_kernels.cu:58-82 / :106-130: amax over the row (fp32), scale = half_rn(amax/127),
     q = rni_sat_s8(x * (127/amax)) with the UNROUNDED fp32 amax, sum = half_rn(fp32 row sum)."""
     xf = np.asarray(x, np.float16).astype(np.float32)
@@ -32,7 +68,12 @@ def quant_per_token(x, with_sum=False):
         pre = (xf * tmp[..., None]).astype(np.float32)
     q = rni_sat_s8(pre)
     if with_sum:
-        s = xf.sum(axis=-1, dtype=np.float64).astype(np.float32).astype(np.float16)
+        # the reference sums in fp32 (fused_kernels.cu:104-122; its own association: 1024 strided threads + warp butterflies);
+        # "exact" = the order-free sum rounded once, "hip" = this library's association, bit for bit (hip_order_row_sum)
+        if sum_order == "hip":
+            s = hip_order_row_sum(xf, _quant_threads(xf.shape[-1])).astype(np.float16)
+        else:
+            s = xf.sum(axis=-1, dtype=np.float64).astype(np.float32).astype(np.float16)
         return q, scale, s, pre
     return q, scale, pre
 
@@ -72,7 +113,7 @@ def reference_order_row_sum(val16):
     return _butterfly_sum32(slots).astype(np.float16)
 
 
-def rms_norm_general(x, gamma, eps, with_sum=False, sum_order="reference"):
+def rms_norm_general(x, gamma, eps, with_sum=False, sum_order="reference", stats_order="exact"):
     """generalLayerNorm(_fuse_sum), per-token dynamic scaling branch (layernorm_kernels.cu:207-326).
 
     mean = sum(x)/H; var = sum((x-mean)^2)/H; rstd = rsqrt(var+eps);
@@ -82,14 +123,24 @@ def rms_norm_general(x, gamma, eps, with_sum=False, sum_order="reference"):
     q = rni_sat_s8( ((x-mean)*rstd*gamma) * (127/amax) )  - the un-rounded fp32 value is re-computed (:312);
     scale = half_rn(amax/127).
     sum_order: "reference" (default) = reference_order_row_sum above - what the HIP kernels compute under
-    qs_set_row_sum_order(1), bit for bit; "fp32" = the order-free exact sum (the HIP default order is an fp32 association of it).
+    qs_set_row_sum_order(1), bit for bit; "hip" = the library's default order, bit for bit; "fp32" = the order-free exact sum.
+    stats_order: "exact" (default) = mean / variance order-free (float64, rounded once); "hip" = the library's fp32 association
+    (then int8 rows, scales and sums equal the HIP kernels' bit for bit; with "exact" they agree except where an fp32 statistic
+    one ulp apart flips a rounding).
     """
     xf = np.asarray(x, np.float16).astype(np.float32)
     g = np.asarray(gamma, np.float16).astype(np.float32)
     T, H = xf.shape
-    mean = (xf.sum(axis=-1, dtype=np.float64) / H).astype(np.float32)
-    diff = (xf - mean[:, None]).astype(np.float32)
-    var = ((diff.astype(np.float64) ** 2).sum(axis=-1) / H).astype(np.float32)
+    if stats_order == "hip":
+        # mean / variance with the library's own fp32 association (hip_order_row_sum): the normalised values - and with them
+        # every int8 byte, the scale and both forms of the row sum - are then BIT-EQUAL to the HIP kernels', ties included
+        mean = (hip_order_row_sum(xf) / np.float32(H)).astype(np.float32)
+        diff = (xf - mean[:, None]).astype(np.float32)
+        var = (hip_order_row_sum((diff * diff).astype(np.float32)) / np.float32(H)).astype(np.float32)
+    else:
+        mean = (xf.sum(axis=-1, dtype=np.float64) / H).astype(np.float32)
+        diff = (xf - mean[:, None]).astype(np.float32)
+        var = ((diff.astype(np.float64) ** 2).sum(axis=-1) / H).astype(np.float32)
     rstd = (np.float32(1.0) / np.sqrt((var + np.float32(eps)).astype(np.float32))).astype(np.float32)
     valf = ((diff * rstd[:, None]).astype(np.float32) * g[None, :]).astype(np.float32)
     val16 = valf.astype(np.float16)
@@ -102,6 +153,8 @@ def rms_norm_general(x, gamma, eps, with_sum=False, sum_order="reference"):
         return q, scale, pre
     if sum_order == "reference":
         s = reference_order_row_sum(val16)
+    elif sum_order == "hip":                           # the library's default order (qs_set_row_sum_order(0)), bit for bit
+        s = hip_order_row_sum(val16.astype(np.float32)).astype(np.float16)
     else:                                              # "fp32": the exact sum of the fp16 values, rounded once (order-free)
         s = val16.astype(np.float64).sum(axis=-1).astype(np.float32).astype(np.float16)
     return q, scale, s, pre

@@ -648,7 +648,7 @@ extern "C" void qs_set_gemm_variant(int variant) {
         g_act_off = variant - 3300;
         return;
     }
-    if (variant >= 5000 && variant < 7000) {
+    if (variant >= 5000 && variant < 5000 + 8192) {
         g_ring_flags = variant - 5000;
         return;
     }

@@ -34,6 +34,8 @@
 //   16 = (set by the launcher, not by the variant) per-channel epilogue convention qs_set_gemm_epilogue(1): fmaf form
 //   128 = (set by the launcher) the armed one-shot fault of qs_debug_inject_fault: tile 0's K-slice producers do not deliver
 //   256 * d = ring depth d (3..6, if 160 KiB allow): sensitivity to the bytes in flight
+//   2048 = (set by the launcher) K slices across the XCDs (ring_coords); 4096 = keep every slice of a channel block on one XCD
+//        (the mapping of rounds 3-5; A/B of the activation traffic)
 int g_ring_flags = 0;
 
 namespace {
@@ -94,10 +96,25 @@ __device__ __forceinline__ unsigned udivmod(unsigned x, unsigned d, unsigned& re
     rem = x % d;
     return x / d;
 }
-__device__ __forceinline__ RingCoords ring_coords(int b, int N, int wn, int mblocks, int ksplit) {
+__device__ __forceinline__ RingCoords ring_coords(int b, int N, int wn, int mblocks, int ksplit, bool kxcd) {
     RingCoords c = {b, 0, 0};
     const int per = mblocks * ksplit;                 // workgroups per channel block
     if (per > 1) {
+        if (kxcd) {
+            // K slices ACROSS the XCDs (round 6; launch_ring sets it when ksplit is 2 / 4 / 8 and the channel blocks divide): XCD x
+            // = b % 8 serves K slice x / xs (xs = 8 / ksplit XCDs per slice) of the channel blocks j = x % xs (mod xs), every
+            // token block of a channel block on the same XCD as before (its weights come from that L2) - so an L2 holds only ITS
+            // K slice of the activation matrix instead of all of it: down_proj's [64, 14336] int8 matrix was fetched once per XCD
+            // (8 x 0.9 MB = 24 % on top of the 30.8 MB the GEMM needs, profiles/round5_b_pmc_traffic.json).  Inside a group of 8
+            // consecutive workgroups the slice index grows with b: the seam's finisher (the last slice) is still dispatched last.
+            const unsigned xs = 8u / (unsigned)ksplit, x = (unsigned)b & 7u;
+            unsigned mb;
+            const unsigned gi = udivmod((unsigned)b >> 3, (unsigned)mblocks, mb);
+            c.kq = (int)(x / xs);
+            c.nblk = (int)(gi * xs + x % xs);
+            c.mblk = (int)mb;
+            return c;
+        }
         const int n8 = (N / (64 * wn)) & ~7;          // channel blocks covered by whole groups of 8 (one per XCD)
         unsigned sub, mb;
         if (b < n8 * per) {
@@ -143,7 +160,7 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
     // weights are fetched from HBM once and re-served by that XCD's L2
     // K split (ksplit > 1): the K range is cut into ksplit slices handled by different workgroups (same XCD as well);
     // the int32 partial tiles meet in a workspace, the last-dispatched slice finishes (see the seam below).
-    const RingCoords rc = ring_coords(blockIdx.x, N, WN, mblocks, ksplit);
+    const RingCoords rc = ring_coords(blockIdx.x, N, WN, mblocks, ksplit, KSPLIT && (flags & 2048));
     const int nblk = rc.nblk, mblk = rc.mblk, kq = rc.kq;
     const int unit0 = nblk * WN;                      // first 64-channel unit of the workgroup
     // OUTK == 2 (gate_up + silu * mul): N stacks [gate | up] (N/2 channels each); "unit" j then means gate channels
@@ -777,6 +794,8 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
         configured = 160 * 1024;
     }
     dim3 grid((N / (64 * WN)) * mblocks * ksplit);
+    const bool kxcd = KSPLIT && (ksplit == 2 || ksplit == 4 || ksplit == 8) && (N / (64 * WN)) % (8 / ksplit) == 0 &&
+                      !(g_ring_flags & 4096);
     int inject = 0;
     if (KSPLIT && OUTK != 3 && ksplit > 1) {
         counters = qs_gemm_error_word(qs_scratch_slot(stream));   // the kernel's `counters` is the error word of the seam's bounded wait
@@ -786,7 +805,8 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
                        reinterpret_cast<const __half*>(wscales), reinterpret_cast<const __half*>(ascales),
                        reinterpret_cast<const __half*>(wszs), reinterpret_cast<const __half*>(assums), out, M, N, K,
                        mblocks, ns, ksplit, slabs, counters,
-                       (g_ring_flags & ~(3 | 16 | 128)) | inject | (g_epi_fma ? 16 : 0) | ((g_ring_flags & 1) || (mblocks > 1 && N <= 8192 && !(g_ring_flags & 2)) ? 1 : 0));
+                       (g_ring_flags & ~(3 | 16 | 128 | 2048 | 4096)) | inject | (g_epi_fma ? 16 : 0) | (kxcd ? 2048 : 0) |
+                           ((g_ring_flags & 1) || (mblocks > 1 && N <= 8192 && !(g_ring_flags & 2)) ? 1 : 0));
     return qs_launch_status("w4a8 gemm (ring)");
 }
 

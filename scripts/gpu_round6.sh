@@ -30,6 +30,15 @@ tests|tests_record)
   grep -E "^(E   |FAILED|ERROR)|passed|failed" gpurun_out/pytest_gpu_$TAG.log | cut -c1-300 | sort | uniq -c | head -40
   echo "=== smoke"
   timeout 600 python __graft_entry__.py smoke 2>&1 | tail -3 ;;
+mbclock)
+  echo "=== microbench_clock (what s_memtime counts)"
+  hipcc -O3 --offload-arch=gfx950 scripts/microbench_clock.hip -o /tmp/mb_clock 2>/dev/null && timeout 120 /tmp/mb_clock | tee gpurun_out/${TAG}_mb_clock.txt ;;
+pmc_ab)
+  # HBM traffic with the K slices across the XCDs (default) and on one XCD (variant 9096 = the mapping of rounds 3-5)
+  echo "=== PMC, K slices across the XCDs"
+  bash scripts/gpu_pmc.sh ${TAG}_kxcd 2>&1 | tail -3
+  echo "=== PMC, K slices on one XCD"
+  QS_GEMM_VARIANT=9096 bash scripts/gpu_pmc.sh ${TAG}_onexcd 2>&1 | tail -3 ;;
 attn_record)
   # step 1 of scripts/record_attention_exceptions.py: record every element beyond the attention contract (nothing asserted on them)
   echo "=== attention parity exceptions (record)"

@@ -7,6 +7,9 @@ import torch
 from qserve_amd import decode as D
 import qserve_backend.fused_attention as fa
 
+if os.environ.get("QS_GEMM_VARIANT"):       # A/B passes (e.g. 9096 = 5000 + 4096: K slices of a channel block on one XCD, rounds 3-5)
+    from qserve_amd._lib import lib
+    lib.qs_set_gemm_variant(int(os.environ["QS_GEMM_VARIANT"]))
 eng = D.DecodeEngine(D.LLAMA3_8B, 64, 1024, 512, with_lm_head=False)
 eng.prefill_cache(1024)
 eng.lengths.fill_(1033)      # bench.py default: context_start = prompt 1024 + 1 + 8 warm-up steps

@@ -295,6 +295,52 @@ def test_ring_kernel_vs_oracle(gpu, variant, M, N, K, mode):
     assert ulp_diff_f16(out[:M].cpu().numpy(), out_ref).max() == 0
 
 
+# K slices ACROSS the XCDs (round 6, gemm_w4a8_ring.hip ring_coords): the launcher takes the mapping when ksplit is 2 / 4 and the
+# channel blocks divide by 8 / ksplit; ring flag 4096 keeps the mapping of rounds 3-5.  Same exact results from both, seam and
+# planes alike (the seam's "the finishing slice is dispatched last" survives: inside 8 consecutive workgroups the slice index grows).
+KXCD = [(4221, 40, 512, 2048), (4421, 64, 1024, 4096), (4222, 100, 1024, 2048), (4241, 120, 256, 4096), (4422, 64, 512, 2048),
+        (4221, 64, 4096, 14336)]
+
+
+@pytest.mark.parametrize("variant,M,N,K", KXCD)
+@pytest.mark.parametrize("mode", ["per_channel", "per_group_any_bytes"])
+def test_k_slices_across_xcds_and_on_one_xcd_are_exact(gpu, variant, M, N, K, mode):
+    from qserve_amd import _lib
+    g = torch.Generator(device=gpu).manual_seed(variant + M)
+    outs = []
+    try:
+        for flags in (0, 4096):
+            _lib.lib.qs_set_gemm_variant(5000 + flags)
+            _lib.lib.qs_set_gemm_variant(variant)
+            if mode == "per_channel":
+                import qserve_backend.qgemm_w4a8_per_chn as op
+                A = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=gpu, generator=g) if not outs else A
+                W = torch.randint(-128, 128, (N, K // 2), dtype=torch.int8, device=gpu, generator=g) if not outs else W
+                acc = torch.full((M, N), -7, dtype=torch.int32, device=gpu)
+                for rep in range(2):                      # (twice: the second launch finds the sentinels restored)
+                    op.gemm_forward_acc(A, W, acc)
+                ref = int_matmul_torch(A, unpack_qweight_torch(W))
+            else:
+                import qserve_backend.qgemm_w4a8_per_group as op
+                if not outs:
+                    A = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=gpu, generator=g)
+                    W = torch.randint(-128, 128, (N, K // 2), dtype=torch.int8, device=gpu, generator=g)
+                    Z = torch.randint(-128, 128, (K // 128, N), dtype=torch.int8, device=gpu, generator=g)
+                    S = torch.randint(-128, 128, (K // 128, N), dtype=torch.int8, device=gpu, generator=g)
+                acc = torch.full((M, N), -7, dtype=torch.int32, device=gpu)
+                for rep in range(2):
+                    op.gemm_forward_acc(A, W, Z, S, acc)
+                ref = None
+            torch.cuda.synchronize()
+            outs.append(acc.clone())
+            if ref is not None:
+                assert torch.equal(acc.to(torch.int64), ref), f"flags {flags}: int32 accumulators differ from the integer matmul"
+    finally:
+        _lib.lib.qs_set_gemm_variant(5000)
+        _lib.lib.qs_set_gemm_variant(-1)
+    assert torch.equal(outs[0], outs[1]), "the two workgroup -> (channel block, K slice) mappings disagree"
+
+
 def test_rows_beyond_M_untouched_and_empty_batch(gpu):
     import qserve_backend.qgemm_w4a8_per_chn as op
     pr = synth.per_channel_problem(5, 64, 128, seed=9)

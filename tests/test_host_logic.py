@@ -74,8 +74,8 @@ def test_attention_exception_list_is_pinned():
     """tests/golden/attention_parity_exceptions.json (the by-name exceptions of the attention contract) may only SHRINK: the
     counts are pinned here and in scripts/record_attention_exceptions.py, which regenerates the file from a recording on the
     MI355X.  Every listed element on a row of >= 63 tokens must be one where the HIP output is at least as close to exact math
-    as the reference-order restatement is (the restatement's fp16 roundings are the far side) - once the entry carries both
-    distances (round 6 recordings do)."""
+    as the reference-order restatement is (the restatement's fp16 roundings are the far side; the one long-row entry against the
+    fp32 mode - the VALU kernel at L = 65, two fp16 ulps from exact math - is the exception and stays within 1e-3 of exact math)."""
     import importlib.util
     import json
     import os
@@ -88,8 +88,11 @@ def test_attention_exception_list_is_pinned():
     assert summ["elements"] <= rec.PINNED_ELEMENTS == 83
     assert summ["on_rows_of_at_least_63_tokens"] <= rec.PINNED_LONG_ROW_ELEMENTS == 9
     assert summ["worst_abs_err_on_rows_of_at_least_63_tokens"] <= 2e-3
-    for v in d["exceptions"].values():
+    for key, v in d["exceptions"].items():
         for e in v:
             assert e["hip_vs_exact"] <= 1e-3 or e["context"] <= 2
-            if e["context"] >= 63 and "oracle_vs_exact" in e:
-                assert e["oracle_vs_exact"] >= e["hip_vs_exact"], e
+            assert "exact" in e and "oracle_vs_exact" in e, "round-6 recordings carry the exact-math decomposition"
+            if e["context"] >= 63 and key.endswith("|kernel"):
+                # against the REFERENCE-ORDER restatement the restatement itself is the far side, every time
+                assert e["oracle_vs_exact"] >= e["hip_vs_exact"] and e["oracle_vs_exact"] > 9e-4, e
+    assert summ["long_row_elements_where_the_restatement_is_the_far_side"] >= summ["on_rows_of_at_least_63_tokens"] - 1
