@@ -139,6 +139,48 @@ int qs_w8a8_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscal
  *   3100 + bits ... [QS_TIMING builds only] kernel parts of the tiled kernel switched off. */
 void qs_set_gemm_variant(int variant);
 
+/* The codes above by name (round 6; the dispatcher in qserve_amd/csrc/gemm_w4a8.hip uses these, nothing else defines them).
+ * The selection state is PROCESS-GLOBAL and NOT THREAD-SAFE: a test / measurement hook, set between launches by one host
+ * thread; a serving process never calls it.  Codes that pick a kernel are remembered until the next call; the sticky families
+ * (ring flags, tile order, activation split) keep their own word and are reset by their family's base code. */
+enum qs_gemm_variant_code {
+    QS_GEMM_DEFAULT = -1,              /* the measured heuristic */
+    QS_GEMM_SPLITK_BASE = 1000,        /* + 100 * m_tiles + 10 * cross_block_slices + waves: round-1 split-K kernel geometry */
+    QS_GEMM_PAIR_OFF = 2000,           /* the round-1 LDS-pair kernel never / ... */
+    QS_GEMM_PAIR_FORCED = 2001,        /* ... always (where its preconditions hold) */
+    QS_GEMM_TILED_OFF = 3000,          /* compute-bound kernels off */
+    QS_GEMM_TILED_256 = 3001,          /* eight-wave 256-token tile forced */
+    QS_GEMM_TILED_128 = 3002,          /* 128-token tile forced */
+    QS_GEMM_WIDE_256 = 3003,           /* four-wave 256-token tile forced */
+    QS_GEMM_TILED_DEBUG_BASE = 3100,   /* + bits: [QS_TIMING builds] parts of the tiled kernel off (sticky) */
+    QS_GEMM_TILE_ORDER_BASE = 3200,    /* + 10 * persist_mode + order (sticky until QS_GEMM_TILE_ORDER_BASE) */
+    QS_GEMM_ACT_FUSED = 3300,          /* qs_w4a8_*_gemm_silu_mul as one launch where it can [default] (sticky) */
+    QS_GEMM_ACT_SPLIT = 3301,          /* ... always as two launches (sticky) */
+    QS_GEMM_WIDE_DEBUG_BASE = 3400,    /* + bits: [QS_TIMING builds] parts of the wide kernel off (sticky) */
+    QS_GEMM_RING_OFF = 4000,           /* decode ring kernel off (the round-1 kernels serve its shapes) */
+    QS_GEMM_RING_NO_KSLICES = 4001,    /* ring kernel without K slices */
+    QS_GEMM_RING_NO_GROUP_TERM = 4002, /* cost model without the per-group term */
+    QS_GEMM_RING_NO_DOWN_OVERRIDE = 4003, /* without the measured <2,1> x 2 override for Llama-3's down_proj */
+    QS_GEMM_RING_NO_MT8 = 4004,        /* without the 128-token geometry <8,2> */
+    QS_GEMM_RING_GEOMETRY_BASE = 4100, /* + 100 * (k_slices - 1) + 10 * m_tiles + units: forced ring geometry */
+    QS_GEMM_RING_GEOMETRY_END = 4500,
+    QS_GEMM_PLANES_GEOMETRY_BASE = 4600, /* the same for the K-slice planes launches */
+    QS_GEMM_PLANES_GEOMETRY_END = 5000,
+    QS_GEMM_RING_FLAGS_BASE = 5000,    /* + bits (QS_RING_FLAG_*), sticky until QS_GEMM_RING_FLAGS_BASE */
+    QS_GEMM_RING_FLAGS_END = 5000 + 16384
+};
+enum qs_ring_flag {                    /* qs_set_gemm_variant(QS_GEMM_RING_FLAGS_BASE + bits); results never change unless noted */
+    QS_RING_FLAG_WEIGHTS_DEFAULT_POLICY = 1,  /* weight DMA without the non-temporal hint everywhere */
+    QS_RING_FLAG_WEIGHTS_NT = 2,              /* ... non-temporal everywhere */
+    QS_RING_FLAG_T_NO_REDUCTION = 4,          /* [QS_TIMING, wrong results] no cross-group reduction */
+    QS_RING_FLAG_T_LEAVE_AFTER_LOOP = 8,      /* [QS_TIMING, wrong results] leave behind the k loop */
+    QS_RING_FLAG_T_NO_MFMA = 32,              /* [QS_TIMING, wrong results] */
+    QS_RING_FLAG_T_NO_OPERAND_READS = 64,     /* [QS_TIMING, wrong results] */
+    QS_RING_FLAG_DEPTH_UNIT = 256,            /* * d: ring depth d = 3 .. 6 */
+    QS_RING_FLAG_KSLICES_ONE_XCD = 4096,      /* K slices of a channel block on one XCD (the mapping of rounds 3-5) */
+    QS_RING_FLAG_T_NO_LEVEL2 = 8192           /* [QS_TIMING, wrong results] per-group launches without the level-2 arithmetic */
+};
+
 /* Per-channel epilogue CONVENTION (process-wide; read at launch time by every per-channel W4A8 GEMM launch and by
  * qs_add_residual_rms_norm_general_planes, which finishes such a GEMM).  The reference statement
  *   (float(acc) * wscale) * ascale - w_sz * a_ssum          (w4a8_per_chn/gemm_cuda.cu:586-587)

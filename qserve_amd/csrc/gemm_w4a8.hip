@@ -264,7 +264,7 @@ __global__ __launch_bounds__(MT <= 2 ? 512 : 256, 2) void w4a8_gemm_splitk(const
     }
 }
 
-int g_variant = -1;
+int g_variant = QS_GEMM_DEFAULT;   // process-global test / measurement hook (include/qserve_amd.h qs_gemm_variant_code): not thread-safe
 }  // namespace
 thread_local QsGemmPlan g_qs_plan = {0, 0, {0, 0, 0, 0}};
 namespace {
@@ -436,9 +436,9 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
     // tiles fill the chip; variant 3000 disables it, 3001 / 3002 force the 256- / 128-token tile
     if (N % 256 == 0 && K >= 256 && K < (1 << 24) && (size_t)M * K < (1ull << 32) && (size_t)N * K / 2 < (1ull << 32)) {
         int tmt = 0;
-        if (g_variant == 3001 || g_variant == 3003) tmt = 8;
-        else if (g_variant == 3002) tmt = 4;
-        else if (g_variant < 1000 || g_variant > 3003) {
+        if (g_variant == QS_GEMM_TILED_256 || g_variant == QS_GEMM_WIDE_256) tmt = 8;
+        else if (g_variant == QS_GEMM_TILED_128) tmt = 4;
+        else if (g_variant < QS_GEMM_SPLITK_BASE || g_variant > QS_GEMM_WIDE_256) {
             const long nb = N / 256;
             // measured crossovers (scripts/bench_gemm_big.py, N=4096..28672): the tiles must (nearly) fill 256 CUs
             // (M >= 192: a 256-token tile must be mostly real tokens - without this bound every N >= 49 152 took the tiled
@@ -450,7 +450,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         // 256 tokens instead of two: +10 ... 18 % in-run (profiles/round5_wide_ab.txt: 4096^3 70.2 -> 64.0 us, 8192 x 4096 x 14336
         // 436 -> 369 us).  Per-channel the two tiles measure the same within +-3 % (both ~3.2 POPS marginal): the eight-wave one
         // stays.  Variant 3003 forces the four-wave tile for any problem, 3001 the eight-wave one (A/B, tests).
-        if (tmt == 8 && (g_variant == 3003 || (MODE == 1 && g_variant != 3001)))
+        if (tmt == 8 && (g_variant == QS_GEMM_WIDE_256 || (MODE == 1 && g_variant != QS_GEMM_TILED_256)))
             return qs_launch_gemm_wide(MODE, outk, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,
                                        g_tiled_order / 10, stream);
         if (tmt)
@@ -472,8 +472,8 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         *counters = ws->counters;
         return true;
     };
-    if (g_variant >= 4100 && g_variant < 4500) {       // tests: force geometry 4100 + 100*(ksplit-1) + 10*mt + wn
-        const int v = g_variant - 4100, ks = v / 100 + 1, mt = (v % 100) / 10, wn = v % 10;
+    if (g_variant >= QS_GEMM_RING_GEOMETRY_BASE && g_variant < QS_GEMM_RING_GEOMETRY_END) {       // tests: forced geometry
+        const int v = g_variant - QS_GEMM_RING_GEOMETRY_BASE, ks = v / 100 + 1, mt = (v % 100) / 10, wn = v % 10;
         const int mb = ((M + 15) / 16 + mt - 1) / mt;
         if (act && ks > 1) return QS_UNFUSED;
         QS_REQUIRE((mt == 1 || mt == 2 || mt == 4 || mt == 8) && (wn == 1 || wn == 2 || (wn == 4 && mt == 4)) &&
@@ -492,7 +492,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
     // through its CU, one workgroup per CU at a time, and the per-CU fill rate (~47 GB/s) is what bounds these shapes -
     // so take the geometry with the fewest bytes per CU over all its rounds; ties go to the two-unit workgroups (the
     // activation tile is shared by two waves).  Short K (< 1024) at M <= 64 stays on the split-K kernel (fixed costs).
-    if (M <= 1024 && !(K < 1024 && M <= 64) && g_variant != 4000 && (g_variant < 1000 || g_variant >= 4000) &&
+    if (M <= 1024 && !(K < 1024 && M <= 64) && g_variant != QS_GEMM_RING_OFF && (g_variant < QS_GEMM_SPLITK_BASE || g_variant >= QS_GEMM_RING_OFF) &&
         (size_t)M * K < (1ull << 32) && (size_t)N * K / 2 < (1ull << 32)) {
         const int mt_all = (M + 15) / 16;
         // <8,2> = 128-token workgroups (round 5): PER-GROUP only, un-split, from 65 tokens on - one level-2 dequant of a weight byte
@@ -514,10 +514,10 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         };
         long best = -1;
         int bmt = 0, bwn = 0, bks = 1;
-        for (int ks = 1; ks <= (g_variant == 4001 || act ? 1 : 4); ks *= 2)
+        for (int ks = 1; ks <= (g_variant == QS_GEMM_RING_NO_KSLICES || act ? 1 : 4); ks *= 2)
             for (int i = 0; i < 7; ++i) {
                 const int mt = geo[i][0], wn = geo[i][1];
-                if (mt == 8 && (MODE != 1 || ks > 1 || mt_all <= 4 || mt_all > 8 || g_variant == 4004)) continue;   // (65 .. 128 tokens)
+                if (mt == 8 && (MODE != 1 || ks > 1 || mt_all <= 4 || mt_all > 8 || g_variant == QS_GEMM_RING_NO_MT8)) continue;   // (65 .. 128 tokens)
                 if (N % (64 * wn) != 0 || (K / 64) % ks != 0 || (K / 64 / ks) % (8 / wn) != 0) continue;
                 if (ks > 1 && K / ks > 32768) continue;        // the seam's sentinel must stay out of reach of a partial sum
                 const int mb = (mt_all + mt - 1) / mt;
@@ -525,7 +525,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
                 if (ks > 1 && (long)mb * (N / (64 * wn)) > 256) continue;   // K slices are for under-filled grids only
                 // per-group: the level-2 dequant is VALU work per weight byte a workgroup streams (measured at M = 128, g128:
                 // qkv 16.0 us with (4,1) against 18.2 with the equal-bytes (2,2)) - charged as a quarter of the weight bytes
-                const long pg = MODE == 1 && g_variant != 4002 ? 8 * wn : 0;
+                const long pg = MODE == 1 && g_variant != QS_GEMM_RING_NO_GROUP_TERM ? 8 * wn : 0;
                 const long cost = ((blocks + 255) / 256) * (16 * mt + 32 * wn + pg) * (long)(K / ks) * (ks > 1 ? 11 : 10) / 10 +
                                   seam(ks, mt);
                 if (best < 0 || cost < best) best = cost, bmt = mt, bwn = wn, bks = ks;
@@ -538,7 +538,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
         // model puts the two 1 KB apart and cannot be tuned to separate them without flipping M = 32 (measured the other way).
         // (Inside the decode step the two are equal, 2.809 vs 2.813 ms: kept for the traffic - one slab per tile instead of three.)
         if (best >= 0 && bmt == 2 && bwn == 2 && bks == 4 && (mt_all + 1) / 2 == 2 && (long)2 * (N / 64) * 2 == 256 &&
-            (K / 64) % 2 == 0 && (K / 64 / 2) % 8 == 0 && g_variant != 4003)
+            (K / 64) % 2 == 0 && (K / 64 / 2) % 8 == 0 && g_variant != QS_GEMM_RING_NO_DOWN_OVERRIDE)
             bwn = 1, bks = 2;
         // the older register-staged split-K kernel takes any K and cuts the tokens down to 16 per workgroup: same byte
         // model, ~20 % slower at equal bytes (measured) - it wins where K leaves the ring kernel only coarse geometries
@@ -578,7 +578,7 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
     if (act) return QS_UNFUSED;
     // many channels: LDS-shared activation tiles + LDS-DMA rings (gemm_w4a8_lds.hip); variant 2000 forces the
     // split-K kernel, 2001 forces the LDS kernel (A/B tests)
-    if ((((units >= 256 && M > 16) || M >= 384) && g_variant != 2000 || g_variant == 2001) && N % 128 == 0 && K >= 256)
+    if ((((units >= 256 && M > 16) || M >= 384) && g_variant != QS_GEMM_PAIR_OFF || g_variant == QS_GEMM_PAIR_FORCED) && N % 128 == 0 && K >= 256)
         return qs_launch_gemm_pair(MODE, OUTK, A, Wu, zeros, scales8, wscales, ascales, wszs, assums, out, M, N, K,
                                    stream);
     int mtile = M <= 16 ? 1 : M <= 32 ? 2 : M <= 48 ? 3 : 4;
@@ -596,8 +596,8 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
     }
     int NW = nsteps >= 16 && mtile <= 2 ? 8 : nsteps >= 4 ? 4 : (nsteps >= 2 ? 2 : 1);
     int S = 1;
-    if (g_variant >= 1000 && g_variant < 100000) {   // A/B: variant = 1000 + 100*mtile_override + 10*S + NW
-        const int v = g_variant - 1000;
+    if (g_variant >= QS_GEMM_SPLITK_BASE && g_variant < QS_GEMM_PAIR_OFF) {   // A/B: QS_GEMM_SPLITK_BASE + 100*mtile_override + 10*S + NW
+        const int v = g_variant - QS_GEMM_SPLITK_BASE;
         NW = v % 10;
         S = (v / 10) % 10;
         const int mo = v / 100;
@@ -631,25 +631,26 @@ extern int g_wide_dbg;    // gemm_w4a8_wide.hip: timing experiments (3400 + bits
 extern int g_ring_flags;  // gemm_w4a8_ring.hip: A/B switches of the decode kernel (5000 + bits), results unchanged
 extern int g_act_off;
 extern "C" void qs_set_gemm_variant(int variant) {
-    if (variant >= 3100 && variant < 3200) {
-        g_tiled_dbg = variant - 3100;
+    // the sticky families keep their own word (include/qserve_amd.h qs_gemm_variant_code)
+    if (variant >= QS_GEMM_TILED_DEBUG_BASE && variant < QS_GEMM_TILE_ORDER_BASE) {
+        g_tiled_dbg = variant - QS_GEMM_TILED_DEBUG_BASE;
         return;
     }
-    if (variant >= 3200 && variant < 3300) {
-        g_tiled_order = variant - 3200;
-        g_wide_order = (variant - 3200) % 10;
+    if (variant >= QS_GEMM_TILE_ORDER_BASE && variant < QS_GEMM_ACT_FUSED) {
+        g_tiled_order = variant - QS_GEMM_TILE_ORDER_BASE;
+        g_wide_order = (variant - QS_GEMM_TILE_ORDER_BASE) % 10;
         return;
     }
-    if (variant >= 3400 && variant < 3500) {
-        g_wide_dbg = variant - 3400;
+    if (variant >= QS_GEMM_WIDE_DEBUG_BASE && variant < QS_GEMM_WIDE_DEBUG_BASE + 100) {
+        g_wide_dbg = variant - QS_GEMM_WIDE_DEBUG_BASE;
         return;
     }
-    if (variant == 3300 || variant == 3301) {
-        g_act_off = variant - 3300;
+    if (variant == QS_GEMM_ACT_FUSED || variant == QS_GEMM_ACT_SPLIT) {
+        g_act_off = variant - QS_GEMM_ACT_FUSED;
         return;
     }
-    if (variant >= 5000 && variant < 5000 + 8192) {
-        g_ring_flags = variant - 5000;
+    if (variant >= QS_GEMM_RING_FLAGS_BASE && variant < QS_GEMM_RING_FLAGS_END) {
+        g_ring_flags = variant - QS_GEMM_RING_FLAGS_BASE;
         return;
     }
     g_variant = variant;
@@ -756,7 +757,7 @@ bool planes_geometry(int mode, int M, int N, int K, PlanesGeo& g) {
         return false;
     const int mt_all = (M + 15) / 16;
     static const int geo[7][2] = {{4, 2}, {2, 2}, {4, 1}, {2, 1}, {1, 1}, {4, 4}, {8, 2}};   // <8,2>: forced only (tests)
-    const int force = g_variant >= 4600 && g_variant < 5000 ? g_variant - 4600 : -1;   // tests / A-B: 4600 + 100*(ks-1) + 10*mt + wn
+    const int force = g_variant >= QS_GEMM_PLANES_GEOMETRY_BASE && g_variant < QS_GEMM_PLANES_GEOMETRY_END ? g_variant - QS_GEMM_PLANES_GEOMETRY_BASE : -1;   // tests / A-B: 4600 + 100*(ks-1) + 10*mt + wn
     long best = -1;
     for (int ks = 1; ks <= 4; ks *= 2)
         for (int i = 0; i < 7; ++i) {

@@ -36,6 +36,7 @@
 //   256 * d = ring depth d (3..6, if 160 KiB allow): sensitivity to the bytes in flight
 //   2048 = (set by the launcher) K slices across the XCDs (ring_coords); 4096 = keep every slice of a channel block on one XCD
 //        (the mapping of rounds 3-5; A/B of the activation traffic)
+//   8192 = (QS_TIMING libraries only, WRONG RESULTS) per-group launches without the level-2 dequant arithmetic
 int g_ring_flags = 0;
 
 namespace {
@@ -362,6 +363,19 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
     };
     auto build = [&](const Raw& q, int cl) -> v4i {
         u32 s = 0, zb = 0;
+#ifdef QS_TIMING
+        // timing builds only, WRONG RESULTS (flags & 8192): per-group launches keep their meta DMA and LDS reads but skip the level-2
+        // arithmetic - what the dequant VALU costs on top of the per-channel stream (round 6, config 3 decomposition)
+        if (MODE == 1 && (flags & 8192)) {
+            v4i a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const u32 raw = ((cl & 1) ? q.r[e].y : q.r[e].x) ^ (q.sdw & q.zdw & 1u);
+                a[e] = (int)((cl & 2) ? unpack_hi<0>(raw, 0, 0) : unpack_lo<0>(raw, 0, 0));
+            }
+            return a;
+        }
+#endif
         if (MODE == 1) {
             s = (q.sdw >> (8 * cl)) & 0xFFu;
             zb = ((q.zdw >> (8 * cl)) & 0xFFu) * 0x01010101u;
@@ -429,6 +443,15 @@ __device__ __forceinline__ void ring_body(const int8_t* __restrict__ A, const ui
 #pragma unroll
                     for (int cl = 0; cl < 4; ++cl) nxt.a[cl] = build(qn, cl);
                 }
+            }
+            // Per-group (round 6): the operands built for the NEXT round must be finished INSIDE this round, under its MFMAs.  Left to
+            // itself the compiler sinks the second round's level-2 dequant (20 multiplies, ~120 VALU instructions) across the loop's
+            // back edge to its use - in front of the first round's MFMAs: one round then carries 240 VALU instructions and its
+            // MFMAs wait for them, the other round's 16 MFMAs run with nothing beside them (seen in the ISA: blocks of 16 MFMAs +
+            // 40 v_mul_lo_u32 and of 16 MFMAs + 0).  An empty asm that reads the registers pins the computation here.
+            if (MODE == 1) {
+#pragma unroll
+                for (int cl = 0; cl < 4; ++cl) asm volatile("" ::"v"(nxt.a[cl]));
             }
         }
     };
@@ -794,8 +817,12 @@ int launch_ring(const int8_t* A, const uint8_t* W, const int8_t* zeros, const in
         configured = 160 * 1024;
     }
     dim3 grid((N / (64 * WN)) * mblocks * ksplit);
-    const bool kxcd = KSPLIT && (ksplit == 2 || ksplit == 4 || ksplit == 8) && (N / (64 * WN)) % (8 / ksplit) == 0 &&
-                      !(g_ring_flags & 4096);
+    // K slices across the XCDs (ring_coords): always for the planes form (no finisher); for the seam form with TWO slices only -
+    // with four, every finishing workgroup (the last slice: polls, adds, epilogue, row stores) sits on XCDs 6 and 7 and the launch
+    // waits for a quarter of the chip (measured: g128 down_proj at 128 tokens, <4,2> x 2 token blocks x 4 slices, 25.4 -> 26.4 us;
+    // with two slices the finishers are half the chip: per-channel down at 64 tokens 14.4 -> 13.4 us, g128 18.9 -> 17.7)
+    const bool kxcd = KSPLIT && (ksplit == 2 || (OUTK == 3 && (ksplit == 4 || ksplit == 8))) &&
+                      (N / (64 * WN)) % (8 / ksplit) == 0 && !(g_ring_flags & 4096);
     int inject = 0;
     if (KSPLIT && OUTK != 3 && ksplit > 1) {
         counters = qs_gemm_error_word(qs_scratch_slot(stream));   // the kernel's `counters` is the error word of the seam's bounded wait

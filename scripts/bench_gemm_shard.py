@@ -30,6 +30,8 @@ def shard_shapes():
 
 def main():
     torch.cuda.set_device(0)
+    if os.environ.get("RING_FLAGS"):     # sticky A/B switches of the ring kernel (qs_set_gemm_variant(5000 + bits), gemm_w4a8_ring.hip)
+        _lib.lib.qs_set_gemm_variant(5000 + int(os.environ["RING_FLAGS"]))
     shapes = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]] or shard_shapes()
     g = torch.Generator(device="cuda").manual_seed(0)
     for M, N, K in shapes:

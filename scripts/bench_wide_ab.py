@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Compute-bound W4A8 GEMM: the eight-wave tile (qs_set_gemm_variant 3001) against the four-wave tile of round 5 (3003 / the
 dispatcher's default), alternating inside ONE process (box-to-box spread of this kernel reaches 15 %), medians of ROUNDS rounds.
-usage: bench_wide_ab.py [MxNxK ...]   env ROUNDS (default 5), MODES=chn,grp, ACT=1 adds gate_up + silu*mul for N % 512 == 0"""
+usage: bench_wide_ab.py [MxNxK ...]   env ROUNDS (default 5), MODES=chn,grp, ACT=1 adds gate_up + silu*mul for N % 512 == 0,
+VARIANTS=3001,3002,3003 (round 6): any list of forced variants instead of the pair (3002 = the 128-token tile); the two-variant
+summary line is printed for the first and the last of the list"""
 import os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -57,12 +59,17 @@ for M, N, K in shapes:
     for mode, fn in fns.items():
         if mode.split("+")[0] not in MODES:
             continue
-        t = {3001: [], 3003: []}
+        VARS = [int(x) for x in os.environ.get("VARIANTS", "3001,3003").split(",")]
+        t = {v: [] for v in VARS}
         for _ in range(ROUNDS):
-            for v in (3001, 3003):
+            for v in VARS:
                 lib.qs_set_gemm_variant(v)
                 t[v].append(timeit(fn))
         lib.qs_set_gemm_variant(-1)
+        if len(VARS) != 2 or VARS != [3001, 3003]:
+            print(f"M={M:6d} N={N:6d} K={K:6d} {mode:8s}: " + "  ".join(
+                f"{v}: {statistics.median(t[v]):8.1f} us ({2.0 * M * N * K / statistics.median(t[v]) / 1e6:6.0f} TOPS)" for v in VARS), flush=True)
+            continue
         a, b = statistics.median(t[3001]), statistics.median(t[3003])
         tops = lambda us: 2.0 * M * N * K / us / 1e6
         print(f"M={M:6d} N={N:6d} K={K:6d} {mode:8s}: eight-wave {a:9.1f} us {tops(a):7.1f} TOPS | four-wave {b:9.1f} us {tops(b):7.1f} TOPS "

@@ -295,9 +295,10 @@ def test_ring_kernel_vs_oracle(gpu, variant, M, N, K, mode):
     assert ulp_diff_f16(out[:M].cpu().numpy(), out_ref).max() == 0
 
 
-# K slices ACROSS the XCDs (round 6, gemm_w4a8_ring.hip ring_coords): the launcher takes the mapping when ksplit is 2 / 4 and the
-# channel blocks divide by 8 / ksplit; ring flag 4096 keeps the mapping of rounds 3-5.  Same exact results from both, seam and
-# planes alike (the seam's "the finishing slice is dispatched last" survives: inside 8 consecutive workgroups the slice index grows).
+# K slices ACROSS the XCDs (round 6, gemm_w4a8_ring.hip ring_coords): the launcher takes the mapping for two-slice seams and for
+# the planes form (2 / 4 slices) when the channel blocks divide by 8 / ksplit; ring flag 4096 keeps the mapping of rounds 3-5.
+# Same exact results from both (the seam's "the finishing slice is dispatched last" survives: inside 8 consecutive workgroups the
+# slice index grows); the four-slice seam cases below run the old mapping either way and stay as a control.
 KXCD = [(4221, 40, 512, 2048), (4421, 64, 1024, 4096), (4222, 100, 1024, 2048), (4241, 120, 256, 4096), (4422, 64, 512, 2048),
         (4221, 64, 4096, 14336)]
 
