@@ -415,6 +415,11 @@ int qs_stream_scratch_unbind(qs_stream_t stream);
  * by shuffles} per 64-value block. */
 int qs_debug_wave_reduce_selftest(const float* in, float* out, int n, qs_stream_t stream);
 
+/* A/B hook of the prefill attention provider (process-wide, not thread-safe): 0 [default] = lazy running maximum + the tile loop
+ * unrolled over its two LDS buffers (round 6); 1 = the loop of rounds 2-5.  Both compute the same softmax within the provider's
+ * tolerance (tests/test_flash_gpu.py runs both).  QS_EINVAL for any other value. */
+int qs_debug_flash_variant(int variant);
+
 /* Timing tool (scripts/trace_attn.py): device-to-device copy of the first `bytes` of the split-KV workspace, where the
  * trace instantiation of the KV4 decode attention (qs_set_attention_variant(232)) leaves its s_memtime stamps.
  * (A library built with -DQS_RING_TRACE additionally exports qs_debug_ring_trace(void* buf) for scripts/trace_gemm.py;

@@ -68,6 +68,7 @@ SIGNATURES = {
     "qs_comm_error": (_i, [_vp]),
     "qs_comm_destroy": (_i, [_vp]),
     "qs_debug_copy_split_workspace": (_i, [_vp, C.c_size_t]),
+    "qs_debug_flash_variant": (_i, [_i]),
     "qs_flash_attn_varlen_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _f,
                                       _i, _vp]),
 }

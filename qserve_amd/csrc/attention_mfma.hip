@@ -1018,6 +1018,11 @@ int qs_attn_choose_splits(int blocks, int pages, int kv8, int fused_quant) {
     const long F = kv8 ? 5000 : 4000, t_cu = kv8 ? 450 : 340, t_hbm_ps = kv8 ? 2540 : 1330;
     long best = -1;
     int best_n = 1;
+    // (n <= 8: within this kernel's range - page tables of <= 192 entries, 12 288 tokens; longer tables go to the VALU kernels -
+    //  more splits do not pay: 1 / 2 / 4 sequences at 8 191 and 12 200 tokens, forced 4 / 8 / 12 / 16 / 24 splits against this
+    //  choice, KV4 and KV8: the choice is the best or within 1 % of it everywhere except one sequence of 12 200 tokens over an INT8
+    //  cache, where 12 splits measure 20.4 against 21.7 us - profiles/round6_split_long.txt.  ADVICE r05 extrapolated the cost
+    //  formula to 512 pages, which this function is never asked about.)
     for (int n = 1; n <= 8; ++n) {
         if (n > 1 && pages / n < 2) break;
         const long rounds = ((long)blocks * n + 255) / 256;

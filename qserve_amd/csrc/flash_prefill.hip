@@ -19,6 +19,8 @@
 //     O^T = V^T P^T  (A = V^T fragments, two transpose reads each; k-slot <-> key mapping chosen to match the S^T layout);
 //   * exp2 with the scale folded into one fp32 multiply; rescaling of O only through the running max.
 #include "common.h"
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -41,6 +43,9 @@ constexpr int PPW = 16 / NWV;     // 1 KiB DMA pieces of a K (and of a V) tile p
 #ifndef QS_FLASH_OCC
 #define QS_FLASH_OCC 2
 #endif
+#ifndef QS_FLASH_PIN
+#define QS_FLASH_PIN 0            // experiment: O accumulators pinned to v[192:255] through asm (see mfma_o)
+#endif
 constexpr int NKB = QS_FLASH_NKB;  // 32-key blocks per tile
 constexpr int BN = 32 * NKB;      // keys per tile
 constexpr int KS_BYTES = BN * DH * 2;             // 16 KiB
@@ -51,6 +56,49 @@ __device__ __forceinline__ u32 pack_h2(float a, float b) {
     return __builtin_bit_cast(u32, v);
 }
 
+// compile-time loop (register numbers of the asm-owned accumulators must be immediates)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+// R6: the output accumulators O^T (4 blocks of 32 dims x 32 rows = 64 registers per lane) are PINNED to v[192:255]: every statement
+// of the key loop that touches them is inline asm with that physical-register constraint (tied in / out), so they never move.
+// (Compiler-managed, the conditional rescale `if (any row's maximum moved) O *= alpha` made the register allocator give the
+// rescaled O new registers and copy all 64 on the not-taken path: 32 v_mov_b64 per tile and wave in a loop whose VALU is as
+// loaded as its matrix pipe.  Accumulator registers a[..] were tried first: as soon as a kernel touches them the compiler splits
+// the wave's 256 registers 128 / 128 and moves the score tiles into AGPRs - 800 v_accvgpr moves.)  Hazards nothing pads inside
+// asm statements: a VALU result needs two wait states before an MFMA reads it (s_nop in front of the first P.V MFMA of a tile),
+// an MFMA result 18 before a VALU instruction reads it (s_nop block in front of the epilogue).
+template <int D>
+__device__ __forceinline__ void mfma_o(v16f& o, const h8& a, const h8& b) {
+    static_assert(D >= 0 && D < 4, "four output blocks");
+    if constexpr (D == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+{v[192:207]}"(o) : "v"(a), "v"(b));
+    if constexpr (D == 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+{v[208:223]}"(o) : "v"(a), "v"(b));
+    if constexpr (D == 2) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+{v[224:239]}"(o) : "v"(a), "v"(b));
+    if constexpr (D == 3) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+{v[240:255]}"(o) : "v"(a), "v"(b));
+}
+// O block D *= alpha, in place: 8 v_pk_mul_f32 on the pinned registers (a2 = {alpha, alpha})
+#define QS_PKMUL8(B)                                                                                                         \
+    "v_pk_mul_f32 v[" #B "+0:" #B "+1], v[" #B "+0:" #B "+1], %1\n\tv_pk_mul_f32 v[" #B "+2:" #B "+3], v[" #B "+2:" #B "+3], %1\n\t"      \
+    "v_pk_mul_f32 v[" #B "+4:" #B "+5], v[" #B "+4:" #B "+5], %1\n\tv_pk_mul_f32 v[" #B "+6:" #B "+7], v[" #B "+6:" #B "+7], %1\n\t"      \
+    "v_pk_mul_f32 v[" #B "+8:" #B "+9], v[" #B "+8:" #B "+9], %1\n\tv_pk_mul_f32 v[" #B "+10:" #B "+11], v[" #B "+10:" #B "+11], %1\n\t"  \
+    "v_pk_mul_f32 v[" #B "+12:" #B "+13], v[" #B "+12:" #B "+13], %1\n\tv_pk_mul_f32 v[" #B "+14:" #B "+15], v[" #B "+14:" #B "+15], %1"
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rescale_o(v16f (&o)[4], v2f_t a2) {
+    asm volatile(QS_PKMUL8(192) : "+{v[192:207]}"(o[0]) : "v"(a2));
+    asm volatile(QS_PKMUL8(208) : "+{v[208:223]}"(o[1]) : "v"(a2));
+    asm volatile(QS_PKMUL8(224) : "+{v[224:239]}"(o[2]) : "v"(a2));
+    asm volatile(QS_PKMUL8(240) : "+{v[240:255]}"(o[3]) : "v"(a2));
+}
+// ordering point + wait states in front of compiler-visible reads of the pinned registers (epilogue)
+__device__ __forceinline__ void settle_o(v16f (&o)[4]) {
+    asm volatile("s_nop 15\n\ts_nop 7" : "+{v[192:207]}"(o[0]), "+{v[208:223]}"(o[1]), "+{v[224:239]}"(o[2]), "+{v[240:255]}"(o[3]));
+}
+
 #ifdef QS_FLASH_TRACE
 // timing builds only (scripts/trace_flash.py): cycles per phase of the key loop, summed per wave
 __device__ unsigned long long* g_flash_trace = nullptr;
@@ -59,7 +107,13 @@ __device__ unsigned long long* g_flash_trace = nullptr;
 #define QS_FT(i) do { } while (0)
 #endif
 
-template <bool CAUSAL>
+// R6 (round 6, the default): (1) LAZY running maximum - a row's reference maximum moves only when a tile exceeds it by more than
+// 2^8 (probabilities stay <= 256 in fp16, sums in fp32: the same softmax), so the 64-multiply rescale of the O accumulators,
+// which ran on ~85 % of the tiles of a 1 024-token prompt, becomes rare; (2) the tile loop unrolled by two with the LDS buffer
+// index a compile-time constant - every ds_read address is then a loop-invariant register + an immediate offset (the loop
+// carried ~47 v_add_u32 of address arithmetic per tile and wave in a kernel that is VALU-bound: profiles/round6_flash_*).
+// R6 = false: the loop of rounds 2-5 (qs_debug_flash_variant(1); A/B and the timing / trace builds).
+template <bool CAUSAL, bool R6>
 __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
                                                           const _Float16* __restrict__ v, _Float16* __restrict__ out,
                                                           const int* __restrict__ cu_q, const int* __restrict__ cu_k,
@@ -119,29 +173,36 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
     };
     static_assert(NKB == 2, "the DMA staging below is written for 64-key tiles");
-    u32 koff[PPW], voff[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int key = 4 * (PPW * wave + i) + (lane >> 4), pos = lane & 15;
-        koff[i] = (u32)key * (u32)k_stride0 * 2u + (u32)((pos ^ (key & 15)) * 16);
-        voff[i] = (u32)key * (u32)v_stride0 * 2u + (u32)((pos ^ ((key & 3) << 2)) * 16);
-    }
+    // Per-lane source offsets: ONE register each for K and V (round 6; were PPW each).  Piece i of a wave covers keys
+    // 4 (PPW wave + i) + (lane >> 4): the rows of piece i are 4 i keys further on - a wave-uniform distance that goes into the scalar
+    // base -, the V swizzle depends on key & 3 = (lane >> 4) & 3 only, and the K swizzle pos ^ (key & 15) differs between the pieces
+    // by an XOR with 4 i on the 16-byte position (PPW = 4: key & 15 = 4 i + (lane >> 4)), i.e. by `^ 64 i` on the byte offset.
+    static_assert(PPW == 4, "the per-piece offsets below are derived for four pieces per wave");
+    const int l4 = lane >> 4, pos = lane & 15;
+    const u32 koff0 = (u32)l4 * (u32)k_stride0 * 2u + (u32)((pos ^ l4) * 16);
+    const u32 voff0 = (u32)l4 * (u32)v_stride0 * 2u + (u32)((pos ^ (l4 << 2)) * 16);
     auto load_tile = [&](int t, int buf) {
-        const _Float16* kb_ = kg + (size_t)t * BN * k_stride0;
-        const _Float16* vb_ = vg + (size_t)t * BN * v_stride0;
+        const _Float16* kb_ = kg + ((size_t)t * BN + 4 * PPW * wave) * k_stride0;   // first key of this wave's pieces
+        const _Float16* vb_ = vg + ((size_t)t * BN + 4 * PPW * wave) * v_stride0;
         const bool ragged = t * BN + BN > len_k;        // wave-uniform: only the last tile of a sequence
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            u32 ko = koff[i], vo = voff[i];
-            if (ragged) {                                 // clamp the row to the sequence's last key
-                const int key = 4 * (PPW * wave + i) + (lane >> 4), pos = lane & 15;
+            if (ragged) {                                 // clamp the row to the sequence's last key (offsets from the TILE's base)
+                const int key = 4 * (PPW * wave + i) + l4;
                 int kc = len_k - 1 - t * BN;
                 kc = key < kc ? key : kc;
-                ko = (u32)kc * (u32)k_stride0 * 2u + (u32)((pos ^ (key & 15)) * 16);
-                vo = (u32)kc * (u32)v_stride0 * 2u + (u32)((pos ^ ((key & 3) << 2)) * 16);
+                const u32 ko = (u32)kc * (u32)k_stride0 * 2u + (u32)((pos ^ (key & 15)) * 16);
+                const u32 vo = (u32)kc * (u32)v_stride0 * 2u + (u32)((pos ^ ((key & 3) << 2)) * 16);
+                dma16(ko, kg + (size_t)t * BN * k_stride0, lds_k + buf * KS_BYTES + (PPW * wave + i) * 1024);
+                dma16(vo, vg + (size_t)t * BN * v_stride0, lds_v + buf * VT_BYTES + (PPW * wave + i) * 1024);
+            } else {
+                // (the XOR is re-done per tile by an opaque statement: hoisted out of the loop - as the compiler does with the plain
+                //  expression - the three extra offsets are exactly what it spills to scratch once O is pinned)
+                u32 ko = koff0;
+                if (i > 0) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ko) : "n"(64 * i), "v"(koff0));
+                dma16(ko, kb_ + (size_t)(4 * i) * k_stride0, lds_k + buf * KS_BYTES + (PPW * wave + i) * 1024);
+                dma16(voff0, vb_ + (size_t)(4 * i) * v_stride0, lds_v + buf * VT_BYTES + (PPW * wave + i) * 1024);
             }
-            dma16(ko, kb_, lds_k + buf * KS_BYTES + (PPW * wave + i) * 1024);
-            dma16(vo, vb_, lds_v + buf * VT_BYTES + (PPW * wave + i) * 1024);
         }
     };
     auto tiles_landed = [&]() {                       // every wave's pieces: own queue drained, then the barrier
@@ -149,7 +210,7 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
         __syncthreads();
     };
 
-    v16f oacc[4];
+    v16f oacc[4];                                      // (R6: pinned to v[192:255], see mfma_o)
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -157,6 +218,16 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
     float m_run = -INFINITY, l_run = 0.f;
 
     if (ntiles > 0) load_tile(0, 0);
+    // The Q fragments must be COMPLETE FOR THE COMPILER before the key loop (round 6).  They come from ordinary global loads; the
+    // only wait in front of the loop was the asm vmcnt(0) of tiles_landed(), which the compiler's wait-count pass does not see - so
+    // it kept the fragments "load pending" into the loop and put counted waits in front of the first Q.K^T MFMAs of EVERY tile
+    // (s_waitcnt vmcnt(7) ... vmcnt(0), one per fragment).  The hardware counter it waits on also counts the LDS-DMA of tile
+    // t + 1, issued a few instructions earlier by asm the compiler does not see either: every wave sat through the L2 round trip
+    // of its own prefetch inside Q.K^T of every tile (the "1 430 cycles for DMA issue + Q.K^T" of the round-2 trace, 512 of them
+    // MFMA).  An empty asm that rewrites the fragments makes the compiler wait HERE, once (tests/test_kernel_contracts.py pins:
+    // no vmcnt wait between the loop's barriers other than the explicit one of tiles_landed()).
+#pragma unroll
+    for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(qf[s]));
     tiles_landed();
 #ifdef QS_FLASH_STAGGER
     // experiment: the two workgroups of a CU run identical code with identical timing and can settle in lockstep (both in
@@ -169,15 +240,17 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
     unsigned ft[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long ft_t = __builtin_amdgcn_s_memtime();
 #endif
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
+    // one tile; BUFC = std::integral_constant<int, 0 / 1> (R6: the buffer index is a compile-time constant) or a run-time int
+    auto tile_body = [&](auto bufc, int t) {
+        const int buf = bufc;
         QS_FT(0);
         if (!(QS_FLASH_DBG & 8) && t + 1 < ntiles) load_tile(t + 1, buf ^ 1);   // lands in the other buffers during this tile
         // causal: the workgroup's key range ends at its LAST row's diagonal; a wave whose 32 rows all lie before this tile
         // has nothing to add (every score masked) - it only takes part in the staging and the barrier
-        if (CAUSAL && t * BN > qt * BM + wave * 32 + 31 + shift) {
+        // (R6: such tiles never reach this body - see the loops below)
+        if (!R6 && CAUSAL && t * BN > qt * BM + wave * 32 + 31 + shift) {
             tiles_landed();
-            continue;
+            return;
         }
 
         // ---------------- S^T = K Q^T : two blocks of 32 keys ----------------
@@ -270,7 +343,8 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2;      // scale > 0: max commutes with it
-        const float m_new = fmaxf(m_run, mx);
+        // R6: lazy reference maximum (see the kernel's header)
+        const float m_new = R6 ? (mx > m_run + 8.0f ? mx : m_run) : fmaxf(m_run, mx);
         const float m_use = m_new == -INFINITY ? 0.f : m_new;     // fully masked so far: keep exp2 arguments finite
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);                  // m_run = -inf -> 0
         m_run = m_new;
@@ -297,11 +371,18 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
                 }
         const float psum = psum2[0] + psum2[1];
         l_run = l_run * alpha + psum;
-        if (__any(alpha != 1.0f)) {                                // the running max moved for some row of this wave
+        if (__builtin_expect(__any(alpha != 1.0f), 0)) {           // the running max moved for some row of this wave
+            if constexpr (R6 && QS_FLASH_PIN) {
+                // rare with the lazy maximum (the first tile and jumps of more than 2^8).  The P.V MFMAs of the previous tile are
+                // complete - the matrix pipe is in order and Q.K^T of THIS tile, issued behind them, has been read by the
+                // maximum above.
+                rescale_o(oacc, (v2f_t){alpha, alpha});
+            } else {
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
+                for (int d = 0; d < 4; ++d)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+            }
         }
 
         QS_FT(2);                                                  // mask + softmax + O rescale
@@ -311,23 +392,51 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
         } else {
             read_v(1, va[1]);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
+            if constexpr (R6 && QS_FLASH_PIN) asm volatile("s_nop 1" ::: "memory");      // the probabilities are VALU results (see mfma_o)
+            static_for<4>([&](auto dc) {
+                constexpr int d = decltype(dc)::value;
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         const h8 pbv = __builtin_bit_cast(h8, (v4u){pb[kb][m][0], pb[kb][m][1], pb[kb][m][2], pb[kb][m][3]});
-                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[d & 1][2 * kb + m], pbv, oacc[d], 0, 0, 0);
+                        if constexpr (R6 && QS_FLASH_PIN) mfma_o<d>(oacc[d], va[d & 1][2 * kb + m], pbv);
+                        else oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[d & 1][2 * kb + m], pbv, oacc[d], 0, 0, 0);
                     }
                 __builtin_amdgcn_sched_barrier(0);
                 if (d + 2 < 4) read_v(d + 2, va[d & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            });
         }
         QS_FT(3);                                                  // P.V
         tiles_landed();
         QS_FT(4);                                                  // wait for the next tile + barrier
+    };
+    if constexpr (R6) {
+        // tiles this WAVE computes: a causal tile whose first key lies beyond the wave's last row has nothing to add - for those
+        // the wave only takes part in the staging and the barrier (second loop).  Kept out of the first loop on purpose: a skip
+        // path that rejoins the computing path inside the loop is a control-flow merge the 64 O accumulators are carried
+        // through, and the compiler resolves such merges with register copies.
+        int nt_w = ntiles;
+        if (CAUSAL) {
+            const int last_key = qt * BM + wave * 32 + 31 + shift;
+            nt_w = last_key < 0 ? 0 : min(ntiles, last_key / BN + 1);
+        }
+        int t = 0;
+        for (; t + 1 < nt_w; t += 2) {
+            tile_body(std::integral_constant<int, 0>(), t);
+            tile_body(std::integral_constant<int, 1>(), t + 1);
+        }
+        if (t < nt_w) {
+            tile_body(std::integral_constant<int, 0>(), t);
+            ++t;
+        }
+        for (; t < ntiles; ++t) {
+            if (!(QS_FLASH_DBG & 8) && t + 1 < ntiles) load_tile(t + 1, (t + 1) & 1);
+            tiles_landed();
+        }
+    } else {
+        for (int t = 0; t < ntiles; ++t) tile_body(t & 1, t);
     }
 #ifdef QS_FLASH_TRACE
     if (g_flash_trace && lane == 0) {
@@ -340,17 +449,22 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
     // ---- epilogue: normalise, fp16, 8-byte stores (4 consecutive dims per accumulator quad) ---------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    if (row < len_q) {
-        _Float16* op = out + (size_t)(q_start + row) * o_stride0 + (size_t)h * DH;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
+    // (the row index is re-derived from a lane id the compiler cannot merge with the one above: kept alive across the key loop
+    //  it costs a register the causal instantiation does not have)
+    const int row_e = qt * BM + wave * 32 + (int)(fresh_lane_id() & 31u);
+    if constexpr (R6 && QS_FLASH_PIN) settle_o(oacc);                                      // the last P.V results -> VALU reads
+    if (row_e < len_q) {
+        _Float16* op = out + (size_t)(q_start + row_e) * o_stride0 + (size_t)h * DH;
+        static_for<4>([&](auto dc) {
+            constexpr int d = decltype(dc)::value;
+            static_for<4>([&](auto rc) {
+                constexpr int rq = decltype(rc)::value;
                 h4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (_Float16)(oacc[d][4 * rq + j] * inv);
                 *reinterpret_cast<h4*>(op + 32 * d + 8 * rq + 4 * hi) = o;
-            }
+            });
+        });
     }
 }
 
@@ -362,6 +476,15 @@ extern "C" int qs_debug_flash_trace(void* buf) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_flash_trace), &p, sizeof(p));
 }
 #endif
+
+static int g_flash_variant = 0;
+// A/B hook (include/qserve_amd.h): 0 = lazy running maximum + tile loop unrolled over the two LDS buffers (round 6, default),
+// 1 = the loop of rounds 2-5.  The same softmax; the reference maximum differs, so low-order bits may.
+extern "C" int qs_debug_flash_variant(int variant) {
+    QS_REQUIRE(variant == 0 || variant == 1, "qs_debug_flash_variant: %d not in {0, 1}", variant);
+    g_flash_variant = variant;
+    return QS_OK;
+}
 
 extern "C" int qs_flash_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out,
                                         const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int batch,
@@ -389,23 +512,31 @@ extern "C" int qs_flash_attn_varlen_fwd(const void* q, const void* k, const void
     static bool configured_dev[QS_MAX_DEVICES] = {};   // the attribute belongs to the (kernel, device) pair
     bool& configured = configured_dev[qs_device_slot()];
     if (!configured) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_fwd_kernel<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_fwd_kernel<false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e1 != hipSuccess || e2 != hipSuccess) {
+        hipError_t e1 = hipSuccess;
+        for (const void* fn : {reinterpret_cast<const void*>(flash_fwd_kernel<true, true>),
+                               reinterpret_cast<const void*>(flash_fwd_kernel<true, false>),
+                               reinterpret_cast<const void*>(flash_fwd_kernel<false, true>),
+                               reinterpret_cast<const void*>(flash_fwd_kernel<false, false>)}) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+            if (e != hipSuccess) e1 = e;
+        }
+        if (e1 != hipSuccess) {
             qs_set_error("flash_attn_varlen: cannot reserve %d bytes of LDS", SMEM);
-            return (int)(e1 != hipSuccess ? e1 : e2);
+            return (int)e1;
         }
         configured = true;
     }
-    if (causal)
-        hipLaunchKernelGGL(flash_fwd_kernel<true>, grid, dim3(64 * NWV), SMEM, (hipStream_t)stream, (const _Float16*)q,
-                           (const _Float16*)k, (const _Float16*)v, (_Float16*)out, cu_seqlens_q, cu_seqlens_k, num_heads,
-                           num_kv_heads, q_stride0, k_stride0, v_stride0, o_stride0, scale_log2);
-    else
-        hipLaunchKernelGGL(flash_fwd_kernel<false>, grid, dim3(64 * NWV), SMEM, (hipStream_t)stream, (const _Float16*)q,
-                           (const _Float16*)k, (const _Float16*)v, (_Float16*)out, cu_seqlens_q, cu_seqlens_k, num_heads,
-                           num_kv_heads, q_stride0, k_stride0, v_stride0, o_stride0, scale_log2);
+#define QS_FL(C, P)                                                                                                    \
+    hipLaunchKernelGGL((flash_fwd_kernel<C, P>), grid, dim3(64 * NWV), SMEM, (hipStream_t)stream, (const _Float16*)q,   \
+                       (const _Float16*)k, (const _Float16*)v, (_Float16*)out, cu_seqlens_q, cu_seqlens_k, num_heads,  \
+                       num_kv_heads, q_stride0, k_stride0, v_stride0, o_stride0, scale_log2)
+    if (causal) {
+        if (g_flash_variant == 0) QS_FL(true, true);
+        else QS_FL(true, false);
+    } else {
+        if (g_flash_variant == 0) QS_FL(false, true);
+        else QS_FL(false, false);
+    }
+#undef QS_FL
     return qs_launch_status("flash_attn_varlen");
 }

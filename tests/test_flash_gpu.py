@@ -10,6 +10,16 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-3   # fp16 inputs / probabilities rounded to fp16 for the matrix cores; outputs are O(1)
 
 
+@pytest.fixture(params=[0, 1], ids=["block_pipelined", "per_tile_loop"], autouse=True)
+def flash_variant(request):
+    """Every case runs through both key loops of the provider (include/qserve_amd.h qs_debug_flash_variant): the default
+    block-pipelined one with the lazy running maximum (round 6) and the per-tile loop of rounds 2-5."""
+    from qserve_amd._lib import lib
+    assert lib.qs_debug_flash_variant(request.param) == 0
+    yield request.param
+    lib.qs_debug_flash_variant(0)
+
+
 def _case(gpu, lens_q, lens_k, H, Hkv, causal, seed, packed=True):
     from flash_attn.flash_attn_interface import flash_attn_varlen_func
     r = np.random.default_rng(seed)
