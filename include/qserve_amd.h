@@ -415,9 +415,10 @@ int qs_stream_scratch_unbind(qs_stream_t stream);
  * by shuffles} per 64-value block. */
 int qs_debug_wave_reduce_selftest(const float* in, float* out, int n, qs_stream_t stream);
 
-/* A/B hook of the prefill attention provider (process-wide, not thread-safe): 0 [default] = lazy running maximum + the tile loop
- * unrolled over its two LDS buffers (round 6); 1 = the loop of rounds 2-5.  Both compute the same softmax within the provider's
- * tolerance (tests/test_flash_gpu.py runs both).  QS_EINVAL for any other value. */
+/* A/B hook of the prefill attention provider (process-wide, not thread-safe): 0 [default] = the round-6 kernel (Q fragments
+ * complete before the key loop, no accumulator copies in it, lazy running maximum, whole-row output through LDS); 1 = the
+ * kernel of rounds 2-5.  Both compute the same softmax within the provider's tolerance (tests/test_flash_gpu.py runs both).
+ * QS_EINVAL for any other value. */
 int qs_debug_flash_variant(int variant);
 
 /* Timing tool (scripts/trace_attn.py): device-to-device copy of the first `bytes` of the split-KV workspace, where the

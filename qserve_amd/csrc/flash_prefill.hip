@@ -28,7 +28,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef u32 v2u __attribute__((ext_vector_type(2)));
 
 #ifndef QS_FLASH_DBG
-#define QS_FLASH_DBG 0            // timing experiments (scripts/bench_flash.py; results wrong): 1 no exp2, 2 no P.V, 4 no Q.K^T, 8 no tile loads
+#define QS_FLASH_DBG 0            // timing experiments (scripts/bench_flash.py; results wrong): 1 no exp2, 2 no P.V, 4 no Q.K^T, 8 no tile loads, 16 no key loop
 #endif
 constexpr int DH = 128;
 #ifndef QS_FLASH_NW
@@ -43,9 +43,6 @@ constexpr int PPW = 16 / NWV;     // 1 KiB DMA pieces of a K (and of a V) tile p
 #ifndef QS_FLASH_OCC
 #define QS_FLASH_OCC 2
 #endif
-#ifndef QS_FLASH_PIN
-#define QS_FLASH_PIN 0            // experiment: O accumulators pinned to v[192:255] through asm (see mfma_o)
-#endif
 constexpr int NKB = QS_FLASH_NKB;  // 32-key blocks per tile
 constexpr int BN = 32 * NKB;      // keys per tile
 constexpr int KS_BYTES = BN * DH * 2;             // 16 KiB
@@ -56,7 +53,7 @@ __device__ __forceinline__ u32 pack_h2(float a, float b) {
     return __builtin_bit_cast(u32, v);
 }
 
-// compile-time loop (register numbers of the asm-owned accumulators must be immediates)
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>)
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -65,40 +62,6 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
-// R6: the output accumulators O^T (4 blocks of 32 dims x 32 rows = 64 registers per lane) are PINNED to v[192:255]: every statement
-// of the key loop that touches them is inline asm with that physical-register constraint (tied in / out), so they never move.
-// (Compiler-managed, the conditional rescale `if (any row's maximum moved) O *= alpha` made the register allocator give the
-// rescaled O new registers and copy all 64 on the not-taken path: 32 v_mov_b64 per tile and wave in a loop whose VALU is as
-// loaded as its matrix pipe.  Accumulator registers a[..] were tried first: as soon as a kernel touches them the compiler splits
-// the wave's 256 registers 128 / 128 and moves the score tiles into AGPRs - 800 v_accvgpr moves.)  Hazards nothing pads inside
-// asm statements: a VALU result needs two wait states before an MFMA reads it (s_nop in front of the first P.V MFMA of a tile),
-// an MFMA result 18 before a VALU instruction reads it (s_nop block in front of the epilogue).
-template <int D>
-__device__ __forceinline__ void mfma_o(v16f& o, const h8& a, const h8& b) {
-    static_assert(D >= 0 && D < 4, "four output blocks");
-    if constexpr (D == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+{v[192:207]}"(o) : "v"(a), "v"(b));
-    if constexpr (D == 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+{v[208:223]}"(o) : "v"(a), "v"(b));
-    if constexpr (D == 2) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+{v[224:239]}"(o) : "v"(a), "v"(b));
-    if constexpr (D == 3) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+{v[240:255]}"(o) : "v"(a), "v"(b));
-}
-// O block D *= alpha, in place: 8 v_pk_mul_f32 on the pinned registers (a2 = {alpha, alpha})
-#define QS_PKMUL8(B)                                                                                                         \
-    "v_pk_mul_f32 v[" #B "+0:" #B "+1], v[" #B "+0:" #B "+1], %1\n\tv_pk_mul_f32 v[" #B "+2:" #B "+3], v[" #B "+2:" #B "+3], %1\n\t"      \
-    "v_pk_mul_f32 v[" #B "+4:" #B "+5], v[" #B "+4:" #B "+5], %1\n\tv_pk_mul_f32 v[" #B "+6:" #B "+7], v[" #B "+6:" #B "+7], %1\n\t"      \
-    "v_pk_mul_f32 v[" #B "+8:" #B "+9], v[" #B "+8:" #B "+9], %1\n\tv_pk_mul_f32 v[" #B "+10:" #B "+11], v[" #B "+10:" #B "+11], %1\n\t"  \
-    "v_pk_mul_f32 v[" #B "+12:" #B "+13], v[" #B "+12:" #B "+13], %1\n\tv_pk_mul_f32 v[" #B "+14:" #B "+15], v[" #B "+14:" #B "+15], %1"
-typedef float v2f_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void rescale_o(v16f (&o)[4], v2f_t a2) {
-    asm volatile(QS_PKMUL8(192) : "+{v[192:207]}"(o[0]) : "v"(a2));
-    asm volatile(QS_PKMUL8(208) : "+{v[208:223]}"(o[1]) : "v"(a2));
-    asm volatile(QS_PKMUL8(224) : "+{v[224:239]}"(o[2]) : "v"(a2));
-    asm volatile(QS_PKMUL8(240) : "+{v[240:255]}"(o[3]) : "v"(a2));
-}
-// ordering point + wait states in front of compiler-visible reads of the pinned registers (epilogue)
-__device__ __forceinline__ void settle_o(v16f (&o)[4]) {
-    asm volatile("s_nop 15\n\ts_nop 7" : "+{v[192:207]}"(o[0]), "+{v[208:223]}"(o[1]), "+{v[224:239]}"(o[2]), "+{v[240:255]}"(o[3]));
-}
-
 #ifdef QS_FLASH_TRACE
 // timing builds only (scripts/trace_flash.py): cycles per phase of the key loop, summed per wave
 __device__ unsigned long long* g_flash_trace = nullptr;
@@ -107,19 +70,30 @@ __device__ unsigned long long* g_flash_trace = nullptr;
 #define QS_FT(i) do { } while (0)
 #endif
 
-// R6 (round 6, the default): (1) LAZY running maximum - a row's reference maximum moves only when a tile exceeds it by more than
-// 2^8 (probabilities stay <= 256 in fp16, sums in fp32: the same softmax), so the 64-multiply rescale of the O accumulators,
-// which ran on ~85 % of the tiles of a 1 024-token prompt, becomes rare; (2) the tile loop unrolled by two with the LDS buffer
-// index a compile-time constant - every ds_read address is then a loop-invariant register + an immediate offset (the loop
-// carried ~47 v_add_u32 of address arithmetic per tile and wave in a kernel that is VALU-bound: profiles/round6_flash_*).
-// R6 = false: the loop of rounds 2-5 (qs_debug_flash_variant(1); A/B and the timing / trace builds).
-template <bool CAUSAL, bool R6>
+// VAR = 1 (round 6, the default) against VAR = 0 (the kernel of rounds 2-5, kept for the A/B: qs_debug_flash_variant(1)):
+//  (1) the Q fragments are complete FOR THE COMPILER before the key loop: it had kept them "load pending" and put counted vmcnt
+//      waits in front of the first Q.K^T MFMAs of every tile - waits that also drain the LDS-DMA of tile t + 1, issued a few
+//      instructions earlier by asm it does not see.  Every wave sat through the L2 round trip of its own prefetch, every tile;
+//  (2) no register copies of the O accumulators in the key loop: 32 v_mov_b64 per tile and wave came from two control-flow merges
+//      the 64 accumulators were carried through - the rescale branch (now marked unlikely: its copies live on the cold path) and the
+//      skip of fully masked causal tiles (now a loop of its own behind the computing loop).  Pinning O to fixed registers through
+//      asm (physical-register constraints) and asm-owned accumulator registers were tried first: the former spills 30 registers in
+//      the loop, the latter makes the compiler split the wave's 256 registers 128 / 128 and move the score tiles into AGPRs;
+//  (3) LAZY running maximum - a row's reference maximum moves only when a tile exceeds it by more than 2^8 (probabilities stay
+//      <= 256 in fp16, sums in fp32: the same softmax), so the rescale, which ran on ~85 % of the tiles of a 1 024-token prompt,
+//      becomes rare;
+//  (4) the tile loop unrolled by two with the LDS buffer index a compile-time constant (every ds_read address a loop-invariant
+//      register + an immediate offset; the loop carried ~47 v_add_u32 of address arithmetic per tile and wave);
+//  (5) O leaves through LDS as whole rows (see the epilogue).
+// In-run A/B (profiles/round6_flash_ab7.txt): 64 x 1 024 tokens 0.233 -> 0.277 of the dense fp16 MFMA peak, 4 x 8 192: 0.345 -> 0.397.
+template <bool CAUSAL, int VAR>
 __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const _Float16* __restrict__ q, const _Float16* __restrict__ k,
                                                           const _Float16* __restrict__ v, _Float16* __restrict__ out,
                                                           const int* __restrict__ cu_q, const int* __restrict__ cu_k,
                                                           int num_heads, int num_kv_heads, int64_t q_stride0,
                                                           int64_t k_stride0, int64_t v_stride0, int64_t o_stride0,
                                                           float scale_log2) {
+    constexpr bool R6 = VAR != 0;      // VAR: 0 = the kernel of rounds 2-5 (A/B: qs_debug_flash_variant(1)), 1 = round 6 (default)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t (*s_k)[KS_BYTES] = reinterpret_cast<uint8_t (*)[KS_BYTES]>(smem);                    // [2][16 KiB]
     uint8_t (*s_vt)[VT_BYTES] = reinterpret_cast<uint8_t (*)[VT_BYTES]>(smem + 2 * KS_BYTES);    // [2][16 KiB]
@@ -158,7 +132,7 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
         const int last = qt * BM + BM - 1 + shift;     // largest key any row of this workgroup may see
         kv_end = last + 1 < len_k ? last + 1 : len_k;
     }
-    const int ntiles = kv_end > 0 ? (kv_end + BN - 1) / BN : 0;
+    const int ntiles = (QS_FLASH_DBG & 16) ? 0 : kv_end > 0 ? (kv_end + BN - 1) / BN : 0;   // (DBG 16: prologue + epilogue only)
 
     // ---- tile staging by LDS-DMA: a 1 KiB piece = 4 keys x 256 B; wave w copies K pieces 4w .. 4w+3 and the same V pieces.
     // The DMA writes lane-linear (lane l -> key l >> 4 of the piece, 16-byte position l & 15), so the XOR swizzles of the
@@ -210,7 +184,7 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
         __syncthreads();
     };
 
-    v16f oacc[4];                                      // (R6: pinned to v[192:255], see mfma_o)
+    v16f oacc[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -226,8 +200,10 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
     // of its own prefetch inside Q.K^T of every tile (the "1 430 cycles for DMA issue + Q.K^T" of the round-2 trace, 512 of them
     // MFMA).  An empty asm that rewrites the fragments makes the compiler wait HERE, once (tests/test_kernel_contracts.py pins:
     // no vmcnt wait between the loop's barriers other than the explicit one of tiles_landed()).
+    if constexpr (R6) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(qf[s]));
+        for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(qf[s]));
+    }
     tiles_landed();
 #ifdef QS_FLASH_STAGGER
     // experiment: the two workgroups of a CU run identical code with identical timing and can settle in lockstep (both in
@@ -244,6 +220,9 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
     auto tile_body = [&](auto bufc, int t) {
         const int buf = bufc;
         QS_FT(0);
+        // (round 6, measured and dropped: the pieces of tile t + 1 requested LATER - K behind Q.K^T, V behind the exponentials, where an
+        //  LDS-DMA instruction should cost the wave fewer issue cycles than next to 16 ds_read_b128: equal at 64 x 1 024 tokens, -0.8 %
+        //  at 4 x 8 192, profiles/round6_flash_ab6.txt)
         if (!(QS_FLASH_DBG & 8) && t + 1 < ntiles) load_tile(t + 1, buf ^ 1);   // lands in the other buffers during this tile
         // causal: the workgroup's key range ends at its LAST row's diagonal; a wave whose 32 rows all lie before this tile
         // has nothing to add (every score masked) - it only takes part in the staging and the barrier
@@ -371,18 +350,13 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
                 }
         const float psum = psum2[0] + psum2[1];
         l_run = l_run * alpha + psum;
-        if (__builtin_expect(__any(alpha != 1.0f), 0)) {           // the running max moved for some row of this wave
-            if constexpr (R6 && QS_FLASH_PIN) {
-                // rare with the lazy maximum (the first tile and jumps of more than 2^8).  The P.V MFMAs of the previous tile are
-                // complete - the matrix pipe is in order and Q.K^T of THIS tile, issued behind them, has been read by the
-                // maximum above.
-                rescale_o(oacc, (v2f_t){alpha, alpha});
-            } else {
+        // (R6: marked unlikely - with the lazy maximum it is the first tile and jumps of more than 2^8.  The not-taken path must not
+        //  carry register copies of the 64 accumulators: see the loop structure below)
+        if (R6 ? __builtin_expect(__any(alpha != 1.0f), 0) : __any(alpha != 1.0f)) {   // the running max moved for some row of this wave
 #pragma unroll
-                for (int d = 0; d < 4; ++d)
+            for (int d = 0; d < 4; ++d)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
-            }
+                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
         }
 
         QS_FT(2);                                                  // mask + softmax + O rescale
@@ -392,7 +366,6 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
         } else {
             read_v(1, va[1]);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (R6 && QS_FLASH_PIN) asm volatile("s_nop 1" ::: "memory");      // the probabilities are VALU results (see mfma_o)
             static_for<4>([&](auto dc) {
                 constexpr int d = decltype(dc)::value;
 #pragma unroll
@@ -400,8 +373,7 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         const h8 pbv = __builtin_bit_cast(h8, (v4u){pb[kb][m][0], pb[kb][m][1], pb[kb][m][2], pb[kb][m][3]});
-                        if constexpr (R6 && QS_FLASH_PIN) mfma_o<d>(oacc[d], va[d & 1][2 * kb + m], pbv);
-                        else oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[d & 1][2 * kb + m], pbv, oacc[d], 0, 0, 0);
+                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[d & 1][2 * kb + m], pbv, oacc[d], 0, 0, 0);
                     }
                 __builtin_amdgcn_sched_barrier(0);
                 if (d + 2 < 4) read_v(d + 2, va[d & 1]);
@@ -452,8 +424,40 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
     // (the row index is re-derived from a lane id the compiler cannot merge with the one above: kept alive across the key loop
     //  it costs a register the causal instantiation does not have)
     const int row_e = qt * BM + wave * 32 + (int)(fresh_lane_id() & 31u);
-    if constexpr (R6 && QS_FLASH_PIN) settle_o(oacc);                                      // the last P.V results -> VALU reads
-    if (row_e < len_q) {
+    // whole-row stores need 16-byte alignment of every row (wave-uniform)
+    const bool rows16 = R6 && (o_stride0 % 8 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    if (rows16) {
+        // Round 6: O goes through LDS and leaves as WHOLE ROWS.  In the accumulator layout a lane owns one query row, so the direct
+        // form below is 16 stores of 8 bytes per lane at a row stride (o_stride0, 8 KiB for 32 heads): every store instruction touches
+        // 64 different cache lines, and the store tail of a workgroup lasts ~2 key tiles (MI355X_MICROARCH.md: "attention epilogue
+        // store tail ... store-ISSUE-bound").  Here a wave writes its 32 x 128 fp16 block into its own 8.5 KiB of the (dead) K / V
+        // buffers - row stride 272 B: the rows of a half-wave fall on banks 4 li, two-way conflicts at most - and reads it back 16
+        // bytes per lane, 16 lanes per row: 8 stores per lane, each instruction 4 complete 256-byte rows.  No barrier: every wave has
+        // passed the last tile's barrier (all reads of the buffers are over) and touches only its own block; the LDS serves a wave's
+        // accesses in order.
+        constexpr int OST = 272;
+        uint8_t* const so = smem + wave * (32 * OST);
+        const int li_e = (int)(fresh_lane_id() & 31u), hi_e = (int)(fresh_lane_id() >> 5);
+        static_for<4>([&](auto dc) {
+            constexpr int d = decltype(dc)::value;
+            static_for<4>([&](auto rc) {
+                constexpr int rq = decltype(rc)::value;
+                h4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (_Float16)(oacc[d][4 * rq + j] * inv);
+                *reinterpret_cast<h4*>(so + li_e * OST + (32 * d + 8 * rq + 4 * hi_e) * 2) = o;
+            });
+        });
+        const int lid = (int)fresh_lane_id(), rr = lid >> 4, cc = lid & 15;
+        const int row0 = qt * BM + wave * 32;
+        _Float16* const ob = out + (size_t)(q_start + row0) * o_stride0 + (size_t)h * DH + cc * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 4 * j + rr;
+            const v4u x = *reinterpret_cast<const v4u*>(so + r * OST + cc * 16);
+            if (row0 + r < len_q) *reinterpret_cast<v4u*>(ob + (size_t)r * o_stride0) = x;
+        }
+    } else if (row_e < len_q) {
         _Float16* op = out + (size_t)(q_start + row_e) * o_stride0 + (size_t)h * DH;
         static_for<4>([&](auto dc) {
             constexpr int d = decltype(dc)::value;
@@ -513,10 +517,8 @@ extern "C" int qs_flash_attn_varlen_fwd(const void* q, const void* k, const void
     bool& configured = configured_dev[qs_device_slot()];
     if (!configured) {
         hipError_t e1 = hipSuccess;
-        for (const void* fn : {reinterpret_cast<const void*>(flash_fwd_kernel<true, true>),
-                               reinterpret_cast<const void*>(flash_fwd_kernel<true, false>),
-                               reinterpret_cast<const void*>(flash_fwd_kernel<false, true>),
-                               reinterpret_cast<const void*>(flash_fwd_kernel<false, false>)}) {
+        for (const void* fn : {reinterpret_cast<const void*>(flash_fwd_kernel<true, 0>), reinterpret_cast<const void*>(flash_fwd_kernel<true, 1>),
+                               reinterpret_cast<const void*>(flash_fwd_kernel<false, 0>), reinterpret_cast<const void*>(flash_fwd_kernel<false, 1>)}) {
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
             if (e != hipSuccess) e1 = e;
         }
@@ -531,11 +533,11 @@ extern "C" int qs_flash_attn_varlen_fwd(const void* q, const void* k, const void
                        (const _Float16*)k, (const _Float16*)v, (_Float16*)out, cu_seqlens_q, cu_seqlens_k, num_heads,  \
                        num_kv_heads, q_stride0, k_stride0, v_stride0, o_stride0, scale_log2)
     if (causal) {
-        if (g_flash_variant == 0) QS_FL(true, true);
-        else QS_FL(true, false);
+        if (g_flash_variant == 0) QS_FL(true, 1);
+        else QS_FL(true, 0);
     } else {
-        if (g_flash_variant == 0) QS_FL(false, true);
-        else QS_FL(false, false);
+        if (g_flash_variant == 0) QS_FL(false, 1);
+        else QS_FL(false, 0);
     }
 #undef QS_FL
     return qs_launch_status("flash_attn_varlen");

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-3   # fp16 inputs / probabilities rounded to fp16 for the matrix cores; outputs are O(1)
 
 
-@pytest.fixture(params=[0, 1], ids=["block_pipelined", "per_tile_loop"], autouse=True)
+@pytest.fixture(params=[0, 1], ids=["round6", "rounds2to5"], autouse=True)
 def flash_variant(request):
     """Every case runs through both key loops of the provider (include/qserve_amd.h qs_debug_flash_variant): the default
     block-pipelined one with the lazy running maximum (round 6) and the per-tile loop of rounds 2-5."""

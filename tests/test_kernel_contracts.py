@@ -25,7 +25,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not ava
 def asm(tmp_path_factory):
     out = {}
     d = tmp_path_factory.mktemp("asm")
-    for name in ("attention_mfma", "attention_mfma8", "gemm_w4a8_ring", "gemm_w4a8_tiled", "gemm_w4a8_wide"):
+    for name in ("attention_mfma", "attention_mfma8", "gemm_w4a8_ring", "gemm_w4a8_tiled", "gemm_w4a8_wide", "flash_prefill"):
         dst = d / (name + ".s")
         r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(dst),
                             os.path.join(CSRC, name + ".hip")], capture_output=True, text=True)
@@ -78,7 +78,32 @@ def test_kv8_attention_page_loop_has_only_the_hand_placed_vmcnt_waits(asm):
         assert waits == ["9", "0", "9", "0"], f"{name}: {waits}"
 
 
-@pytest.mark.parametrize("unit", ["attention_mfma", "attention_mfma8", "gemm_w4a8_ring", "gemm_w4a8_tiled", "gemm_w4a8_wide"])
+def test_flash_prefill_key_loop_waits_and_copies(asm):
+    """The prefill attention's key loop (round-6 kernel, VAR = 1: flash_fwd_kernelILb?ELi1E): (a) between the loop header and its
+    back edge the vector-memory queue is waited on ONLY by the asm `s_waitcnt vmcnt(0)` of tiles_landed() - rounds 2-5 carried
+    eight compiler-placed counted waits (for the Q fragments, loaded before the loop) in front of the Q.K^T MFMAs of every tile,
+    which also drained the LDS-DMA of the next tile; (b) the loop holds no register copies of the O accumulators (32 v_mov_b64 per
+    tile and wave before); (c) both tiles of the unrolled loop hold their 32 MFMAs."""
+    ks = {n: b for n, b in kernels(asm["flash_prefill"]).items() if "flash_fwd_kernel" in n}
+    new = {n: b for n, b in ks.items() if re.search(r"flash_fwd_kernelILb[01]ELi1E", n)}
+    assert len(ks) == 4 and len(new) == 2
+    for name, body in new.items():
+        lines = body.splitlines()
+        head = next(i for i, l in enumerate(lines) if "Inner Loop Header" in l)
+        label = lines[head].split(":")[0].strip()
+        back = max(i for i, l in enumerate(lines) if re.search(r"s_cbranch_\w+\s+" + re.escape(label) + r"\b", l))
+        loop = lines[head:back]
+        ins = _instructions("\n".join(loop))
+        compiler_waits = [ops for mn, ops, inside in ins if mn == "s_waitcnt" and "vmcnt" in ops and not inside]
+        assert not compiler_waits, f"{name}: compiler-placed vector-memory waits inside the key loop: {compiler_waits}"
+        asm_waits = [ops for mn, ops, inside in ins if mn == "s_waitcnt" and "vmcnt" in ops and inside]
+        assert asm_waits == ["vmcnt(0)", "vmcnt(0)"], f"{name}: {asm_waits}"
+        assert not [1 for mn, _, _ in ins if mn.startswith("v_mov_b64")], f"{name}: accumulator copies inside the key loop"
+        assert sum(1 for mn, _, _ in ins if mn.startswith("v_mfma_f32_32x32x16_f16")) == 64
+        assert not [1 for mn, _, _ in ins if mn.startswith("scratch_")]
+
+
+@pytest.mark.parametrize("unit", ["attention_mfma", "attention_mfma8", "gemm_w4a8_ring", "gemm_w4a8_tiled", "gemm_w4a8_wide", "flash_prefill"])
 def test_hot_path_kernels_do_not_spill(asm, unit):
     text = asm[unit]
     names = re.findall(r"^\s*\.amdhsa_kernel (\S+)", text, re.M)
