@@ -425,6 +425,40 @@ def gemm_config1_bench(torch, dev):
     return res
 
 
+FP16_PEAK_TFLOPS = 2500.0       # dense fp16 MFMA peak (MI355X_MICROARCH.md: 2.5 PF dense, 256 CUs x 4 SIMDs x 1024 flop / clock at 2.4 GHz)
+
+
+def prefill_attention_bench(torch, dev, cfg, batch, prompt_len):
+    """The prompt phase's attention provider (flash_attn_varlen_func -> csrc/flash_prefill.hip) at the headline shape: `batch`
+    prompts of `prompt_len` tokens, causal; flops counted on the lower triangle (4 B H L^2 Dh / 2), against the dense fp16 MFMA
+    peak.  Not part of the decode step (`per_step` 0); VERDICT r05 item 7."""
+    from flash_attn.flash_attn_interface import flash_attn_varlen_func
+    H, Hkv, L = cfg["heads"], cfg["kv_heads"], prompt_len
+    T = batch * L
+    g = torch.Generator(device=dev).manual_seed(7)
+    qkv = torch.randn((T, (H + 2 * Hkv) * 128), dtype=torch.float16, device=dev, generator=g)
+    q, k, v = qkv.split([H * 128, Hkv * 128, Hkv * 128], dim=-1)
+    q, k, v = q.reshape(T, H, 128), k.reshape(T, Hkv, 128), v.reshape(T, Hkv, 128)
+    cu = torch.arange(0, batch + 1, dtype=torch.int32, device=dev) * L
+    for _ in range(2):
+        flash_attn_varlen_func(q, k, v, cu, cu, L, L, causal=True)
+    torch.cuda.synchronize()
+    meas = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            flash_attn_varlen_func(q, k, v, cu, cu, L, L, causal=True)
+        e1.record()
+        torch.cuda.synchronize()
+        meas.append(e0.elapsed_time(e1) * 1e3 / 5)
+    us = sorted(meas)[1]
+    flops = 4.0 * batch * H * L * L * 128 / 2
+    return [dict(kernel=f"flash_attn_varlen[causal B={batch} L={L} H={H} Hkv={Hkv}]", family="prefill_attention", us=us,
+                 bytes=int(2 * T * (2 * H + 2 * Hkv) * 128), tflops=flops / us / 1e6, frac_of_fp16_mfma_peak=flops / us / 1e6 / FP16_PEAK_TFLOPS,
+                 peak_tflops=FP16_PEAK_TFLOPS, per_step=0)]
+
+
 def cpu_baseline(args, cfg, torch):
     """The reference's PyTorch-CPU linear / attention path (oracle/torch_cpu.py: unpack + de-quantise + fp32 matmul; page
     gather + de-quantise + fp32 softmax attention) on the host cores, on a bounded sample of the step: the four GEMMs of a
@@ -593,6 +627,7 @@ def main():
             kernels = kernel_bench(eng, args, torch, ctxs)      # every rank times its own shard's kernels; rank 0 reports
             if world == 1 and not args.no_extras and args.model == "llama3-8b":
                 kernels += gemm_config1_bench(torch, dev)
+                kernels += prefill_attention_bench(torch, dev, cfg, per_gpu_batch, args.prompt_len)
         except Exception as e:
             if world == 1:
                 raise
@@ -787,7 +822,8 @@ def main():
                            peak=HBM_PEAK_GBS, unit="GB/s", frac=round(fb / fu / 1e3 / HBM_PEAK_GBS, 4), us_per_layer=round(fu, 2),
                            algorithmic_bytes=fb, step_share=round(fu * len(eng.layers) / (ms * 1e3), 3))
         for r in kernels:
-            for k2, nd in (("us", 2), ("gbs", 1), ("tops", 1), ("frac_of_hbm_peak", 4), ("frac_of_int8_mfma_peak", 4),
+            for k2, nd in (("us", 2), ("gbs", 1), ("tops", 1), ("tflops", 1), ("frac_of_hbm_peak", 4), ("frac_of_int8_mfma_peak", 4),
+                           ("frac_of_fp16_mfma_peak", 4),
                            ("sustained_clock_ghz", 3), ("peak_tops_at_measured_clock", 1), ("frac_of_peak_at_measured_clock", 4)):
                 if k2 in r:
                     r[k2] = round(r[k2], nd)

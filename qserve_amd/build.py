@@ -62,7 +62,8 @@ def build(force=False, verbose=True, extra=(), timing=False):
     objs = [o for o, _ in res]
     rebuilt = any(r for _, r in res)
     if rebuilt or not os.path.exists(lib) or force:
-        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib]
+        # (--no-undefined: a symbol one translation unit expects from another and does not get must fail HERE, not at dlopen)
+        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-Wl,--no-undefined", *objs, "-o", lib]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")

@@ -780,7 +780,8 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         const int own_lo = (num_kv_heads - 1) * G * DH;                           // first row element of the finishing workgroup
         if (hkv != num_kv_heads - 1) {
             // (kflags & 64: the armed one-shot fault of qs_debug_inject_fault - sequence 0's KV head 0 never delivers)
-            for (int e = tid2; e < G * DH / 2 && !((kflags & 64) && b == 0 && hkv == 0); e += NWT * 64) {
+            // (kflags & 512: timing libraries only - nobody publishes: with 256 below, what the hand-over costs apart from the wait)
+            for (int e = tid2; e < G * DH / 2 && !((kflags & 64) && b == 0 && hkv == 0) && !(kflags & 512); e += NWT * 64) {
                 v2u gr;
                 gr.x = reinterpret_cast<const u32*>(&s_meta[0][0][0])[e];
                 gr.y = tag;
@@ -804,7 +805,9 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
                 // BOUNDED (round 5): after spin_cap polls the wave stops waiting, sets QS_ERR_ATTN_HANDOVER in the device error word
                 // (the word behind the exchange rows) and quantises what it has - a wrong row and a status bit instead of a hung
                 // GPU.  The generation still advances, so the NEXT launch is clean by itself (a late granule carries a stale tag).
-                const int spin_cap = (kflags & 64) ? 4096 : QS_SPIN_CAP;
+                // (kflags & 256: timing libraries only, WRONG RESULTS - the finisher takes whatever its first poll returns: the launch
+                //  without the wait for the other KV heads' workgroups, profiles/round6_attn_handover.txt)
+                const int spin_cap = (kflags & 256) ? 1 : (kflags & 64) ? 4096 : QS_SPIN_CAP;
                 int polls = 0;
                 for (;;) {
                     const v4u g00 = __builtin_amdgcn_raw_buffer_load_b128(xrs, o0, 0, 17);
@@ -817,7 +820,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
                     raw[1] = (v4u){g10.x, g10.z, g11.x, g11.z};
                     if (!__builtin_amdgcn_ballot_w64((p0 && m0) || (p1 && m1))) break;
                     if (++polls >= spin_cap) {
-                        if ((tid2 & 63) == 0)
+                        if ((tid2 & 63) == 0 && !(kflags & 256))
                             atomicOr(qcounters + QS_ATTNQ_CAP + (size_t)QS_ATTNQ_CAP * QS_ATTNQ_ROW, QS_ERR_ATTN_HANDOVER);
                         break;
                     }
@@ -1132,7 +1135,10 @@ int qs_launch_decode_mfma(int G, dim3 grid, hipStream_t st, const _Float16* q, c
     int8_t* qout = nullptr;
     __half *qscale = nullptr, *qsum = nullptr;
     unsigned* qcnt = nullptr;
-    if (g_qs_attn_quant.qout && nsplit == 1 && H * DH <= 4096 && (qcnt = qs_attn_quant_counters(st, (int)grid.y))) {
+    // (qs_set_row_sum_order(1) with a row sum asked for: the finisher reproduces THIS library's order of invoke_quant_fuse_sum, not the
+    //  reference's - the pair is issued instead, so that the fused entry stays bit-identical to the two calls in both modes)
+    const bool sum_order_ok = !(qs_get_row_sum_order() && g_qs_attn_quant.qsum);
+    if (g_qs_attn_quant.qout && sum_order_ok && nsplit == 1 && H * DH <= 4096 && (qcnt = qs_attn_quant_counters(st, (int)grid.y))) {
         qout = g_qs_attn_quant.qout;
         qscale = reinterpret_cast<__half*>(g_qs_attn_quant.qscale);
         qsum = reinterpret_cast<__half*>(g_qs_attn_quant.qsum);

@@ -431,6 +431,53 @@ def test_attention_quant_fusion_is_bit_identical_to_the_pair(gpu, B, H, Hkv, L, 
         assert torch.equal(p2.k, p1.k) and torch.equal(p2.v, p1.v), "cache pages differ"
 
 
+def test_attention_quant_fusion_equals_the_pair_under_the_reference_sum_order(gpu):
+    """qs_set_row_sum_order(1) (the reference's half-accumulator order of the row sum): the in-kernel finisher reproduces this
+    library's own order, so the fused entry must fall back to the pair there - otherwise the two forms of the same op would
+    differ in a_ssums (round 6; before, the fused entry ignored the switch)."""
+    import qserve_backend.fused_attention as fa
+    import qserve_backend.fused_kernels as fk
+    from qserve_amd import fused
+    from qserve_amd._lib import lib
+    B, H, Hkv, L = 16, 32, 8, 700
+    g = torch.Generator(device=gpu).manual_seed(99)
+    mb = (L + 63) // 64 + 1
+    nblocks = B * mb
+    tables = torch.stack([torch.randperm(nblocks, generator=torch.Generator().manual_seed(1)).reshape(B, mb),
+                          torch.randperm(nblocks, generator=torch.Generator().manual_seed(2)).reshape(B, mb)], dim=1).numpy()
+
+    def fresh():
+        pools = DevPools(nblocks, Hkv, True, gpu, fill=0)
+        g2 = torch.Generator(device=gpu).manual_seed(7)
+        nd = Hkv * 64 * 64
+        for p in (pools.k, pools.v):
+            p[:, :nd] = torch.randint(0, 256, (nblocks, nd), dtype=torch.uint8, device=gpu, generator=g2)
+            p[:, nd:].view(torch.float16).copy_((torch.rand((nblocks, (pools.pb - nd) // 2), device=gpu, generator=g2) * 0.5 + 0.05).half())
+        return pools
+    new = torch.randn((B, (H + 2 * Hkv) * 128), generator=g, device=gpu, dtype=torch.float16)
+    q, k, v = new.split([H * 128, Hkv * 128, Hkv * 128], dim=-1)
+    q, k, v = q.reshape(B, H, 128), k.reshape(B, Hkv, 128), v.reshape(B, Hkv, 128)
+    lens = torch.full((B,), L, dtype=torch.int32, device=gpu)
+    args = (None, 8192, 64, Hkv * 64, L, 128, ROPE, True, True, True)
+    assert lib.qs_set_row_sum_order(1) == 0
+    try:
+        p1 = fresh()
+        out1 = fa.single_query_attention(q, k, v, p1.pointers(tables), lens, *args)
+        q1 = torch.empty((B, H * 128), dtype=torch.int8, device=gpu)
+        s1, m1 = torch.empty((B,), dtype=torch.float16, device=gpu), torch.empty((B,), dtype=torch.float16, device=gpu)
+        fk.invoke_quant_fuse_sum(q1, out1.reshape(B, -1), m1, s1)
+        p2 = fresh()
+        q2 = torch.empty((B, H * 128), dtype=torch.int8, device=gpu)
+        s2, m2 = torch.empty((B,), dtype=torch.float16, device=gpu), torch.empty((B,), dtype=torch.float16, device=gpu)
+        out2 = fused.single_query_attention_quant(q, k, v, p2.pointers(tables), lens, q2, s2, *args[1:], quant_sum=m2)
+        torch.cuda.synchronize()
+    finally:
+        lib.qs_set_row_sum_order(0)
+    assert torch.equal(out2.view(torch.int16), out1.view(torch.int16)) and torch.equal(q2, q1)
+    assert torch.equal(s2.view(torch.int16), s1.view(torch.int16))
+    assert torch.equal(m2.view(torch.int16), m1.view(torch.int16)), "row sum of the fused entry differs from invoke_quant_fuse_sum's in the reference order"
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Parity against the REFERENCE-ORDER restatement at BASELINE sizes (VERDICT round 2, item 1).  The oracle's "kernel" mode
 # follows the reference's own arithmetic (fp16 hfma2 de-quantisation, fp16 partial dot products, probabilities rounded to
