@@ -263,7 +263,9 @@ int qs_single_query_attention_quant(const void* q, const void* k, const void* v,
 
 /* Kernel selection for A/B tests: 0 = matrix-core kernels (KV4 and KV8) with the split-KV heuristic [default],
  * 1 = VALU kernels, 2 = prefill writer without the RoPE table, 3 = KV4 matrix-core kernel with the service wave always
- * owning pages (A/B of the page-ownership rule), 100 + n = matrix-core kernels with exactly n KV splits.
+ * owning pages (A/B of the page-ownership rule), 5 = one raw barrier instead of the polled operand flag, 7 = the attention +
+ * quant fusion hands the PAYLOAD to the last KV head's workgroup also where it otherwise gathers the row statistics (group sizes
+ * 4 and 8; A/B of the hand-over, same bits), 100 + n = matrix-core kernels with exactly n KV splits.
  * (200 + bits: ablation / trace instantiations of the KV4 kernel, QS_TIMING builds only; ignored by the shipped library.) */
 void qs_set_attention_variant(int variant);
 

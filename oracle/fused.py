@@ -32,8 +32,9 @@ def _wave64_butterfly_sum(f):
 
 def hip_order_row_sum(contrib, nt=256):
     """The row sums exactly as qserve_amd/csrc/row_ops.h orders them (the LIBRARY's own order, stated here so that the GPU tests can
-    demand bit-equality instead of "equal up to the association of an fp32 sum"): `nt` virtual threads per row (256; 1024 for
-    invoke_quant / silu_and_mul_quant rows wider than 4096); thread t owns the 8-element chunks (c * nt + t) * 8 .. + 7 and adds
+    demand bit-equality instead of "equal up to the association of an fp32 sum") for the NORM kernels' statistics (mean, variance,
+    the sum of the normalised row; invoke_quant_fuse_sum has its own order since round 6: block_order_row_sum): `nt` = 256
+    virtual threads per row; thread t owns the 8-element chunks (c * nt + t) * 8 .. + 7 and adds
     its fp32 contributions sequentially (c outer, element inner, starting from +0); wave64 butterfly; waves left to right.
     contrib: float32 [T, H] (H % 8 == 0)."""
     contrib = np.asarray(contrib, np.float32)
@@ -53,8 +54,28 @@ def hip_order_row_sum(contrib, nt=256):
     return tot
 
 
-def _quant_threads(hidden):
-    return 1024 if hidden > 4096 else 256          # row_ops.h WIDE_ROW
+def block_order_row_sum(contrib):
+    """The row sum of invoke_quant_fuse_sum (and of the fusions that end in it: silu_and_mul + quant, decode attention + quant)
+    exactly as this library orders it since round 6 (qserve_amd/csrc/row_ops.h reduce_max_blocksum): the row is cut into
+    512-element blocks = 64 chunks of 8; lane l of a block adds the 8 elements of chunk l left to right (from +0; a chunk beyond
+    the row is +0), the 64 lanes go through the wave butterfly (xor 32, 16, 8, 4, 2, 1), and the block sums are added left to
+    right starting from block 0.  Independent of how many threads a kernel runs - which is what lets the workgroups of the decode
+    attention (each holds G x 128 values of the row = whole blocks for G = 4, 8) reproduce invoke_quant_fuse_sum's bits from
+    one published partial each.  contrib: float32 [T, H] (H % 8 == 0)."""
+    contrib = np.asarray(contrib, np.float32)
+    T, H = contrib.shape
+    nblk = (H + 511) // 512
+    pad = np.zeros((T, nblk * 512), np.float32)
+    pad[:, :H] = contrib
+    a = pad.reshape(T, nblk, 64, 8)
+    acc = np.zeros((T, nblk, 64), np.float32)
+    for e in range(8):
+        acc = (acc + a[..., e]).astype(np.float32)
+    blk = _wave64_butterfly_sum(acc)                                  # [T, nblk]
+    tot = blk[:, 0]
+    for k in range(1, nblk):
+        tot = (tot + blk[:, k]).astype(np.float32)
+    return tot
 
 
 def quant_per_token(x, with_sum=False, sum_order="exact"):
@@ -69,9 +90,9 @@ def quant_per_token(x, with_sum=False, sum_order="exact"):
     q = rni_sat_s8(pre)
     if with_sum:
         # the reference sums in fp32 (fused_kernels.cu:104-122; its own association: 1024 strided threads + warp butterflies);
-        # "exact" = the order-free sum rounded once, "hip" = this library's association, bit for bit (hip_order_row_sum)
+        # "exact" = the order-free sum rounded once, "hip" = this library's association, bit for bit (block_order_row_sum)
         if sum_order == "hip":
-            s = hip_order_row_sum(xf, _quant_threads(xf.shape[-1])).astype(np.float16)
+            s = block_order_row_sum(xf).astype(np.float16)
         else:
             s = xf.sum(axis=-1, dtype=np.float64).astype(np.float32).astype(np.float16)
         return q, scale, s, pre

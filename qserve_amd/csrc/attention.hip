@@ -628,7 +628,7 @@ extern "C" int qs_single_query_attention(const void* q, const void* k, const voi
         return qs_launch_decode_mfma(G, grid, st, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
                                      kv_pointers, length_per_sample, (_Float16*)out, num_heads, num_kv_heads,
                                      q_stride0, kv_stride0, max_blocks, timestep, rotary_base, memory_max_seqlen,
-                                     g_attn_variant >= 100 ? g_attn_variant - 100 : 0, g_attn_variant == 5 ? 2 : 0);
+                                     g_attn_variant >= 100 ? g_attn_variant - 100 : 0, g_attn_variant == 5 ? 2 : g_attn_variant == 7 ? 1024 : 0);
     if (!int4_kv_cache && g_attn_variant != 1 && max_blocks <= 192)
         return qs_launch_decode_mfma8(G, grid, st, (const _Float16*)q, (const _Float16*)k, (const _Float16*)v,
                                       kv_pointers, length_per_sample, (_Float16*)out, num_heads, num_kv_heads,

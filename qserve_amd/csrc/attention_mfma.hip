@@ -50,6 +50,9 @@ typedef u32 v2u __attribute__((ext_vector_type(2)));
 constexpr int QS_ATTNQ_CAP = 4096;   // sequences the attention + quant fusion can hand over (larger batches run the pair)
 constexpr int QS_ATTNQ_ROW = 4096;   // values per row at most (H x 128 <= 4096: quant_kernel's 256-thread mapping)
 constexpr int SVC = NW - 1;    // the service wave (RoPE, operand build, new token) - the wave that owns the fewest units
+#ifndef QS_SEQ
+#define QS_SEQ(x) asm volatile("" : "+v"(x))   // one fp32 addition at a time (no re-association / pairing): row_ops.h
+#endif
 constexpr int MAXP = 192;      // longest page table this kernel is dispatched for (dispatcher: max_blocks <= MAXP)
 
 // (explicit global address space: a generic pointer would make these FLAT stores, and a flat access may alias LDS, so
@@ -778,7 +781,101 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
         }
         v2u* const xrow = reinterpret_cast<v2u*>(qcounters + QS_ATTNQ_CAP) + (size_t)b * (QS_ATTNQ_ROW / 2);
         const int own_lo = (num_kv_heads - 1) * G * DH;                           // first row element of the finishing workgroup
-        if (hkv != num_kv_heads - 1) {
+        if ((G == 4 || G == 8) && !(kflags & 1024)) {
+            // ---- Round 6: ALL-GATHER of the row statistics (G = 4, 8: a workgroup's G x 128 values are whole 512-element blocks of the
+            // row).  Every workgroup publishes ONE 16-byte granule {amax, block sum(s), tag} of its own values - one write-through
+            // store -, polls the Hkv granules of its sequence (one cache-missing 16-byte load per lane, lanes < Hkv; its own values come
+            // from registers) and quantises its OWN values: 16 bytes per workgroup cross the chip instead of 1 KiB, and the row's
+            // work is spread over the Hkv workgroups instead of waiting for the last one.  invoke_quant_fuse_sum's row sum is defined
+            // block by block (row_ops.h reduce_max_blocksum, oracle.fused.block_order_row_sum): the block sums travel, every workgroup
+            // adds them left to right - qout / qscale / qsum are BIT-IDENTICAL to invoke_quant(_fuse_sum)(out), as before.
+            // In-run against the payload form (kflags & 1024 = qs_set_attention_variant(7), kept for the other group sizes):
+            // bs = 64: 20.4 -> 19.9 us at 1 033 tokens, equal at 1 535; bs = 128 (BASELINE config 3): 37.0 -> 34.5 us
+            // (profiles/round6_attn_allgather.txt).  Waiting for LATER-dispatched workgroups is safe under in-order dispatch: the
+            // workgroups of a sequence are consecutive block ids, so at most one sequence straddles the resident set and its waiting
+            // members never hold back the slots its missing members need (everybody else finishes); every wait is bounded anyway.
+            // The generation word moves on only after a successful gather - i.e. after every member has read it.
+            float* const sm = reinterpret_cast<float*>(&s_kv[0]);                 // (the rings are dead)
+            v4u* const gran = reinterpret_cast<v4u*>(xrow);
+            if (wave == 0) {
+                const int ln = (int)lid2;
+                float amax = 0.f, s0 = 0.f, s1 = 0.f;
+                {
+                    const h8 vv = __builtin_bit_cast(h8, reinterpret_cast<const v4u*>(&s_meta[0][0][0])[ln]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float f = (float)vv[j];
+                        s0 += f;
+                        QS_SEQ(s0);
+                        amax = fmaxf(amax, fabsf(f));
+                    }
+                }
+                if (G == 8) {
+                    const h8 vv = __builtin_bit_cast(h8, reinterpret_cast<const v4u*>(&s_meta[0][0][0])[64 + ln]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float f = (float)vv[j];
+                        s1 += f;
+                        QS_SEQ(s1);
+                        amax = fmaxf(amax, fabsf(f));
+                    }
+                }
+                amax = wave_max(amax);
+                s0 = wave_sum(s0);
+                if (G == 8) s1 = wave_sum(s1);
+                v4u mine = {__builtin_bit_cast(u32, amax), __builtin_bit_cast(u32, s0), __builtin_bit_cast(u32, s1), tag};
+                if (ln == 0 && !((kflags & 64) && b == 0 && hkv == 0) && !(kflags & 512)) {
+                    v4u* const dst = gran + hkv;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(mine) : "memory");
+                }
+                const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(gran, 0, num_kv_heads * 16, 0x00020000);
+                const bool peer = ln < num_kv_heads && ln != hkv;
+                const u32 goff = ln < num_kv_heads ? (u32)ln * 16u : 0xFFFFFF00u;
+                const int spin_cap = (kflags & 256) ? 1 : (kflags & 64) ? 4096 : QS_SPIN_CAP;
+                int polls = 0;
+                v4u g;
+                for (;;) {
+                    g = __builtin_amdgcn_raw_buffer_load_b128(grs, goff, 0, 17);
+                    if (!__builtin_amdgcn_ballot_w64(peer && g.w != tag)) break;
+                    if (++polls >= spin_cap) {
+                        if (ln == 0 && !(kflags & 256))
+                            atomicOr(qcounters + QS_ATTNQ_CAP + (size_t)QS_ATTNQ_CAP * QS_ATTNQ_ROW, QS_ERR_ATTN_HANDOVER);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (ln == hkv) g = mine;                                           // own values from registers, not from memory
+                float am = ln < num_kv_heads ? __builtin_bit_cast(float, g.x) : 0.f;
+                am = wave_max(am);
+                float tot = 0.f;
+                for (int j = 0; j < num_kv_heads; ++j) {
+                    tot = tot + __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)g.y, j));
+                    QS_SEQ(tot);
+                    if (G == 8) {
+                        tot = tot + __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)g.z, j));
+                        QS_SEQ(tot);
+                    }
+                }
+                if (ln == 0) {
+                    sm[0] = am;
+                    sm[1] = tot;
+                }
+            }
+            __syncthreads();
+            const float r = sm[0];
+            if (tid2 < G * 16) {
+                const h8 vv = __builtin_bit_cast(h8, reinterpret_cast<const v4u*>(&s_meta[0][0][0])[tid2]);
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = (float)vv[j];
+                qs_store_q8(qout + (size_t)b * hidden + (size_t)hkv * G * DH + tid2 * 8, f, 127.0f / r);
+            }
+            if (hkv == num_kv_heads - 1 && tid2 == 0) {
+                qscale[b] = __float2half_rn(r / 127.0f);
+                if (qrowsum) qrowsum[b] = __float2half_rn(sm[1]);
+                qcounters[b] = tag;
+            }
+        } else if (hkv != num_kv_heads - 1) {
             // (kflags & 64: the armed one-shot fault of qs_debug_inject_fault - sequence 0's KV head 0 never delivers)
             // (kflags & 512: timing libraries only - nobody publishes: with 256 below, what the hand-over costs apart from the wait)
             for (int e = tid2; e < G * DH / 2 && !((kflags & 64) && b == 0 && hkv == 0) && !(kflags & 512); e += NWT * 64) {

@@ -42,25 +42,6 @@ __device__ __forceinline__ float block_reduce_once(float v, float* sm, int op) {
     for (int w = 1; w < NT / 64; ++w) r = op == 0 ? r + sm[w] : fmaxf(r, sm[w]);
     return r;
 }
-template <int NT = TPB>
-__device__ __forceinline__ void block_reduce_max_sum(float& mx, float& sum, float* sm, float* sm2, bool want_sum) {
-    mx = wave_max(mx);
-    if (want_sum) sum = wave_sum(sum);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) {
-        sm[wave] = mx;
-        if (want_sum) sm2[wave] = sum;
-    }
-    __syncthreads();
-    float r = sm[0], s = want_sum ? sm2[0] : 0.f;
-#pragma unroll
-    for (int w = 1; w < NT / 64; ++w) {
-        r = fmaxf(r, sm[w]);
-        if (want_sum) s = s + sm2[w];
-    }
-    mx = r;
-    sum = s;
-}
 // rows wider than this are handled by 1024-thread workgroups (same rule in invoke_quant and silu_and_mul_quant, so the
 // two associate their fp32 statistics identically)
 constexpr int WIDE_ROW = qs_row::WIDE_ROW;
@@ -84,7 +65,7 @@ template <int NC, int NT>
 __global__ __launch_bounds__(NT) void quant_kernel(int8_t* __restrict__ out, const _Float16* __restrict__ in,
                                                     __half* __restrict__ sum_out, __half* __restrict__ scale_out,
                                                     int hidden) {
-    __shared__ float sm[2 * (NT / 64)];
+    __shared__ float sm[(1 + NC) * (NT / 64)];
     const size_t base = (size_t)blockIdx.x * hidden;
     qs_row::quant_row<NC, NT / 64, NT / 64, false>(out + base, in + base, sum_out ? sum_out + blockIdx.x : nullptr,
                                                    scale_out + blockIdx.x, hidden, sm, (int)threadIdx.x);
@@ -214,7 +195,7 @@ template <int NC, int NT>
 __global__ __launch_bounds__(NT) void silu_mul_quant_kernel(int8_t* __restrict__ out, const _Float16* __restrict__ in,
                                                              __half* __restrict__ sum_out,
                                                              __half* __restrict__ scale_out, int d) {
-    __shared__ float sm[2][NT / 64];
+    __shared__ float sm[(1 + NC) * (NT / 64)];
     const size_t ib = (size_t)blockIdx.x * 2 * d, ob = (size_t)blockIdx.x * d;
     h8 x[NC], y[NC], o[NC];
 #pragma unroll
@@ -225,9 +206,10 @@ __global__ __launch_bounds__(NT) void silu_mul_quant_kernel(int8_t* __restrict__
             y[c] = load8(in + ib + d + i);
         }
     }
-    float amax = 0.f, sum = 0.f;
+    float amax1[1] = {0.f}, sum1[1][NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
+        sum1[0][c] = 0.f;
         const int i = (c * NT + threadIdx.x) * 8;
         if (i < d) {
 #pragma unroll
@@ -236,13 +218,15 @@ __global__ __launch_bounds__(NT) void silu_mul_quant_kernel(int8_t* __restrict__
                 const _Float16 sl = silu_h(xf);                             // silu_and_mul_kernel
                 o[c][j] = (_Float16)((float)sl * (float)y[c][j]);
                 const float f = (float)o[c][j];
-                sum += f;                                                    // quant_kernel's statistics
-                amax = fmaxf(amax, fabsf(f));
+                sum1[0][c] += f;                                            // quant_kernel's statistics (block order, row_ops.h)
+                QS_SEQ(sum1[0][c]);
+                amax1[0] = fmaxf(amax1[0], fabsf(f));
             }
         }
     }
-    block_reduce_max_sum<NT>(amax, sum, sm[0], sm[1], sum_out != nullptr);
-    
+    float amax, sum;
+    qs_row::reduce_max_blocksum<NC, NT / 64, NT / 64>(amax1, sum1, sm, sm + NT / 64, sum_out != nullptr, (d + 511) / 512,
+                                                      (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), amax, sum);
     if (threadIdx.x == 0) {
         scale_out[blockIdx.x] = __float2half_rn(amax / 127.0f);
         if (sum_out) sum_out[blockIdx.x] = __float2half_rn(sum);

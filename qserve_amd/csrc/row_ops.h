@@ -155,6 +155,45 @@ __device__ __forceinline__ void reduce_max_sum(float (&mx)[NVW / PW], float (&su
     sum_out = s;
 }
 
+// invoke_quant(_fuse_sum)'s statistics (round 6).  The row sum is DEFINED over 512-element blocks (64 chunks of 8): lane l of the
+// wave that owns a block adds the 8 elements of chunk l left to right (from +0), the 64 lanes go through the wave butterfly, and the
+// block sums are added left to right - oracle.fused.block_order_row_sum.  Independent of the number of threads a kernel runs, and
+// reproducible by ANY holder of a whole block: the decode attention's workgroups (G x 128 values of a row each) publish their
+// block sums and every one of them ends with the same bits as invoke_quant_fuse_sum over the finished row (attention_mfma.hip).
+// mx[j], sum[j][c]: virtual wave j's maximum and its chain over chunk set c (block c * NVW + wave + j * PW); sm: NVW floats,
+// sm2: NC * NVW floats; nblk = ceil(hidden / 512).
+template <int NC, int NVW, int PW>
+__device__ __forceinline__ void reduce_max_blocksum(float (&mx)[NVW / PW], float (&sum)[NVW / PW][NC], float* sm, float* sm2,
+                                                    bool want_sum, int nblk, int wave, int lane, float& mx_out, float& sum_out) {
+    constexpr int VPW = NVW / PW;
+#pragma unroll
+    for (int j = 0; j < VPW; ++j) {
+        const float m = wave_max(mx[j]);
+        if (lane == 0) sm[wave + j * PW] = m;
+        if (want_sum) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float sb = wave_sum(sum[j][c]);
+                if (lane == 0) sm2[c * NVW + wave + j * PW] = sb;
+            }
+        }
+    }
+    __syncthreads();
+    float r = sm[0];
+#pragma unroll
+    for (int w = 1; w < NVW; ++w) r = fmaxf(r, sm[w]);
+    float s = 0.f;
+    if (want_sum) {
+        s = sm2[0];
+        for (int b = 1; b < nblk; ++b) {
+            s = s + sm2[b];
+            QS_SEQ(s);
+        }
+    }
+    mx_out = r;
+    sum_out = s;
+}
+
 // ---- the row sum in the REFERENCE's order (qs_set_row_sum_order(1)) ------------------------------------------------------
 // generalLayerNorm_fuse_sum (layernorm_kernels.cu:275-306) runs min(hidden, 1024) threads (rounded up to 32) per token; thread t
 // adds the normalised fp16 values of elements t, t + nt, ... into a HALF accumulator (`T_scalar sum`; `sum += float` is the
@@ -190,7 +229,7 @@ __device__ __forceinline__ float ref_order_row_sum(const _Float16* hv, int hidde
 }
 
 // ---- invoke_quant(_fuse_sum) of one row -------------------------------------------------------------------------------
-// out int8 [hidden], in fp16 [hidden]; sum_out may be null.  sm: 2 * NVW floats of LDS.  SC: `in` was published by other
+// out int8 [hidden], in fp16 [hidden]; sum_out may be null.  sm: (1 + NC) * NVW floats of LDS.  SC: `in` was published by other
 // workgroups of this launch (cache-bypassing loads).  `ready` runs before the first load of `in` (the GEMM tail waits there
 // for the row to be complete).  Every thread of the workgroup must call (barriers); `active` = tid < 64 * PW.
 template <int NC, int NVW, int PW, bool SC, class Hook = NoHook>
@@ -219,30 +258,28 @@ __device__ __forceinline__ void quant_row(int8_t* __restrict__ out, const _Float
                 }
             }
     }
-    float amax[VPW], sum[VPW];
+    float amax[VPW], sum[VPW][NC];
 #pragma unroll
     for (int j = 0; j < VPW; ++j) {
         amax[j] = 0.f;
-        sum[j] = 0.f;
-        if (active) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int i = (c * NT + tid + j * 64 * PW) * 8;
-                if (i < hidden) {
-                    const h8 v = __builtin_bit_cast(h8, raw[j][c]);
+        for (int c = 0; c < NC; ++c) {
+            sum[j][c] = 0.f;                                // (a chunk beyond the row contributes +0 to its block)
+            const int i = (c * NT + tid + j * 64 * PW) * 8;
+            if (active && i < hidden) {
+                const h8 v = __builtin_bit_cast(h8, raw[j][c]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float f = (float)v[e];
-                        sum[j] += f;
-                        QS_SEQ(sum[j]);
-                        amax[j] = fmaxf(amax[j], fabsf(f));
-                    }
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[e];
+                    sum[j][c] += f;
+                    QS_SEQ(sum[j][c]);
+                    amax[j] = fmaxf(amax[j], fabsf(f));
                 }
             }
         }
     }
     float mx, s;
-    reduce_max_sum<NVW, PW>(amax, sum, sm, sm + NVW, sum_out != nullptr, wave, lane, active, mx, s);
+    reduce_max_blocksum<NC, NVW, PW>(amax, sum, sm, sm + NVW, sum_out != nullptr, (hidden + 511) / 512, wave, lane, mx, s);
     if (tid == 0) {
         *scale_out = __float2half_rn(mx / 127.0f);                      // fused_kernels.cu:72
         if (sum_out) *sum_out = __float2half_rn(s);                     // :121

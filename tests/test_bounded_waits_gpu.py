@@ -53,15 +53,19 @@ def test_k_slice_seam_gives_up_reports_and_recovers(gpu, variant, M, N, K):
         lib.qs_device_reset()
 
 
-def test_attention_quant_hand_over_gives_up_reports_and_recovers(gpu):
+@pytest.mark.parametrize("form", ["payload_to_finisher", "statistics_all_gather"])
+def test_attention_quant_hand_over_gives_up_reports_and_recovers(gpu, form):
     """Through the decode engine (tiny Llama, fused pairs: the attention launch carries the quantiser): an injected missing
-    KV-head row makes DecodeEngine.check() raise; after qs_device_reset() a fresh engine reproduces the healthy run bit for bit."""
+    KV-head row makes DecodeEngine.check() raise; after qs_device_reset() a fresh engine reproduces the healthy run bit for bit.
+    Both hand-over forms of attention_mfma.hip: group size 2 hands the payload to the last KV head's workgroup, group size 4
+    gathers the row statistics (round 6: every workgroup of the sequence waits there - all of them must give up and report)."""
     from qserve_amd import _lib
     from qserve_amd.decode import TINY, DecodeEngine
     lib = _lib.lib
+    cfg = TINY if form == "payload_to_finisher" else dict(TINY, name="tiny-llama-g4", hidden=1024, heads=8, kv_heads=2, inter=1024)
 
     def engine():
-        e = DecodeEngine(TINY, batch=5, prompt_len=70, max_new=6, group_size=-1, device="cuda:0", seed=3, fuse_pairs=True)
+        e = DecodeEngine(cfg, batch=5, prompt_len=70, max_new=6, group_size=-1, device="cuda:0", seed=3, fuse_pairs=True)
         e.prefill_cache(70)
         return e
 
