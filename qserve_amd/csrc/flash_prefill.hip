@@ -28,7 +28,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef u32 v2u __attribute__((ext_vector_type(2)));
 
 #ifndef QS_FLASH_DBG
-#define QS_FLASH_DBG 0            // timing experiments (scripts/bench_flash.py; results wrong): 1 no exp2, 2 no P.V, 4 no Q.K^T, 8 no tile loads, 16 no key loop
+#define QS_FLASH_DBG 0            // timing experiments (scripts/bench_flash.py; results wrong): 1 no exp2, 2 no P.V, 4 no Q.K^T, 8 no tile loads, 16 no key loop, 32 no output stores, 64 no Q loads
 #endif
 constexpr int DH = 128;
 #ifndef QS_FLASH_NW
@@ -123,7 +123,10 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
     {
         const _Float16* qp = q + (size_t)(q_start + row_ld) * q_stride0 + (size_t)h * DH + 8 * hi;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const h8*>(qp + 16 * s);
+        for (int s = 0; s < 8; ++s) {
+            if (QS_FLASH_DBG & 64) qf[s] = (h8){(_Float16)(0.01f * lane), 1, 2, 3, 4, 5, 6, (_Float16)s};
+            else qf[s] = *reinterpret_cast<const h8*>(qp + 16 * s);
+        }
     }
 
     // ---- key range ----------------------------------------------------------------------------------------------------
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(64 * NWV, QS_FLASH_OCC) void flash_fwd_kernel(const
         for (int j = 0; j < 8; ++j) {
             const int r = 4 * j + rr;
             const v4u x = *reinterpret_cast<const v4u*>(so + r * OST + cc * 16);
-            if (row0 + r < len_q) *reinterpret_cast<v4u*>(ob + (size_t)r * o_stride0) = x;
+            if (row0 + r < len_q && (!(QS_FLASH_DBG & 32) || x.x == 0x12345678u)) *reinterpret_cast<v4u*>(ob + (size_t)r * o_stride0) = x;
         }
     } else if (row_e < len_q) {
         _Float16* op = out + (size_t)(q_start + row_e) * o_stride0 + (size_t)h * DH;
