@@ -444,53 +444,61 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
         constexpr int RS = 144;                        // staged row stride (bytes): 128 + 16 keeps 16-byte alignment
         uint8_t* const st = a_ring + (PERSIST ? 2 * APAIR : 0) + wave * (16 * RS);
         _Float16* const orow = reinterpret_cast<_Float16*>(out) + en0 + wn * 64 + (lane_e & 7) * 8;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const float sa = (float)sa_h[mt];
-            const float ss = MODE == 0 ? (float)ss_h[mt] : 0.f;
-#pragma unroll
-            for (int cl = 0; cl < 4; ++cl) {
-                const v4i s = acc[mt][cl];
-                h4 o;
-                if (MODE == 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(s[r], (float)ws4[cl][r], sa, (float)wz4[cl][r], ss, epi_fma);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(s[r], (float)ws4[cl][r], sa);
+        // The per-channel convention (qs_set_gemm_epilogue) is a wave-uniform BRANCH around two copies of the loop, not a per-element
+        // select (round 6): with the run-time flag inside epi_per_chn the compiler evaluated both forms of every output and picked one -
+        // 64 v_pk_fma_f32 + 128 v_cndmask on top of 450 VALU per tile and wave, in the one part of the kernel the matrix pipe idles in.
+        auto store_tile = [&](auto fma_c) {
+            constexpr int FMA = decltype(fma_c)::value;
+    #pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float sa = (float)sa_h[mt];
+                const float ss = MODE == 0 ? (float)ss_h[mt] : 0.f;
+    #pragma unroll
+                for (int cl = 0; cl < 4; ++cl) {
+                    const v4i s = acc[mt][cl];
+                    h4 o;
+                    if (MODE == 0) {
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_chn(s[r], (float)ws4[cl][r], sa, (float)wz4[cl][r], ss, FMA);
+                    } else {
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = (_Float16)epi_per_group(s[r], (float)ws4[cl][r], sa);
+                    }
+                    if (ACT) {     // lanes 0-31: gate, lanes 32-63: up of the same (token, channel) -> silu_and_mul's arithmetic
+                        const v2u ob = __builtin_bit_cast(v2u, o);
+                        // one swap hands every lane the pair it finishes: r[0] = (x of lanes 0-31 | y of lanes 0-31) = gate elements
+                        // 0, 1 for the lower half, 2, 3 for the upper; r[1] = (x | y of lanes 32-63) = the matching up elements
+                        const auto sw = __builtin_amdgcn_permlane32_swap(ob.x, ob.y, false, false);
+                        const h2 gt = __builtin_bit_cast(h2, (u32)sw[0]), up = __builtin_bit_cast(h2, (u32)sw[1]);
+                        const int hh = g >> 1;
+                        h2 a;
+                        a[0] = (_Float16)((float)qs_silu_h((float)gt[0]) * (float)up[0]);
+                        a[1] = (_Float16)((float)qs_silu_h((float)gt[1]) * (float)up[1]);
+                        *reinterpret_cast<h2*>(st + li * RS + (8 * cl + 4 * (g & 1) + 2 * hh) * 2) = a;
+                    } else {
+                        *reinterpret_cast<h4*>(st + li * RS + (32 * (g >> 1) + 8 * cl + 4 * (g & 1)) * 2) = o;
+                    }
                 }
-                if (ACT) {     // lanes 0-31: gate, lanes 32-63: up of the same (token, channel) -> silu_and_mul's arithmetic
-                    const v2u ob = __builtin_bit_cast(v2u, o);
-                    // one swap hands every lane the pair it finishes: r[0] = (x of lanes 0-31 | y of lanes 0-31) = gate elements
-                    // 0, 1 for the lower half, 2, 3 for the upper; r[1] = (x | y of lanes 32-63) = the matching up elements
-                    const auto sw = __builtin_amdgcn_permlane32_swap(ob.x, ob.y, false, false);
-                    const h2 gt = __builtin_bit_cast(h2, (u32)sw[0]), up = __builtin_bit_cast(h2, (u32)sw[1]);
-                    const int hh = g >> 1;
-                    h2 a;
-                    a[0] = (_Float16)((float)qs_silu_h((float)gt[0]) * (float)up[0]);
-                    a[1] = (_Float16)((float)qs_silu_h((float)gt[1]) * (float)up[1]);
-                    *reinterpret_cast<h2*>(st + li * RS + (8 * cl + 4 * (g & 1) + 2 * hh) * 2) = a;
-                } else {
-                    *reinterpret_cast<h4*>(st + li * RS + (32 * (g >> 1) + 8 * cl + 4 * (g & 1)) * 2) = o;
+                if (ACT) {         // 16 tokens x 32 channels of this wave: 64-byte row pieces (four waves complete a 256-byte row)
+                    const int r = lane_e >> 2;
+                    const int m = em0 + wm * (16 * MT) + 16 * mt + r;
+                    const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane_e & 3) * 16);
+                    if (m < M)
+                        *reinterpret_cast<v4u*>(reinterpret_cast<_Float16*>(out) + (size_t)m * (N / 2) + (en0 / 64 + wn) * 32 +
+                                                (lane_e & 3) * 8) = v;
+                    continue;
+                }
+    #pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int r = i * 8 + (lane_e >> 3);
+                    const int m = em0 + wm * (16 * MT) + 16 * mt + r;
+                    const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane_e & 7) * 16);
+                    if (m < M) *reinterpret_cast<v4u*>(orow + (size_t)m * N) = v;
                 }
             }
-            if (ACT) {         // 16 tokens x 32 channels of this wave: 64-byte row pieces (four waves complete a 256-byte row)
-                const int r = lane_e >> 2;
-                const int m = em0 + wm * (16 * MT) + 16 * mt + r;
-                const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane_e & 3) * 16);
-                if (m < M)
-                    *reinterpret_cast<v4u*>(reinterpret_cast<_Float16*>(out) + (size_t)m * (N / 2) + (en0 / 64 + wn) * 32 +
-                                            (lane_e & 3) * 8) = v;
-                continue;
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = i * 8 + (lane_e >> 3);
-                const int m = em0 + wm * (16 * MT) + 16 * mt + r;
-                const v4u v = *reinterpret_cast<const v4u*>(st + r * RS + (lane_e & 7) * 16);
-                if (m < M) *reinterpret_cast<v4u*>(orow + (size_t)m * N) = v;
-            }
-        }
+        };
+        if (MODE == 0 && epi_fma) store_tile(std::integral_constant<int, 1>());
+        else store_tile(std::integral_constant<int, 0>());
         if (!PERSIST || next >= ntiles) break;
         tile = next;
     }
