@@ -203,12 +203,54 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
                      : "memory");
     };
+    // Epilogue operands of a tile (PERSIST kernels, round 6): the 256 channel scales (+ scale * zero) and the 256 token scales (+ token
+    // sums) are requested by LDS-DMA into 3 KiB above the rings when the PREVIOUS tile's epilogue has read its own (kernel start for
+    // the first tile) and read from LDS after the k loop.  As register loads behind the k loop they were a dependent memory round
+    // trip per tile with the matrix pipe idle, and the compiler's vmcnt(0) for them also drained the next tile's prefetched stages.
+    // Layout: [w scale 256 halfs | w scale*zero 256 halfs | token scale 256 x 4-byte slots | token sum 256 slots].
+    constexpr int SC_OFF = NS * (BM * 64 + WSTAGE + 512);
+    uint8_t* const s_sc = smem + SC_OFF;
+    auto issue_scales = [&](int tm0, int tn0) {
+        const u32 sc_lds = lds0 + SC_OFF;
+        auto dma4p = [&](const void* src, u32 dst) {
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(dst) : "memory");
+        };
+        auto dma2p = [&](const void* src, u32 dst) {
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_ushort %0, off" ::"v"(src), "s"(dst) : "memory");
+        };
+        const int ln = fresh(lane);
+        if (wave < 4) {                                // waves 0, 1: w scale; 2, 3: w scale * zero - 128 halfs per instruction
+            const int lc = 128 * (wave & 1) + 2 * ln;  // local channel: ACT = [128 gate | 128 up]
+            const int gc = ACT ? (lc < 128 ? 32 * (tn0 / 64) + lc : N / 2 + 32 * (tn0 / 64) + (lc - 128)) : tn0 + lc;
+            if (wave < 2) dma4p(reinterpret_cast<const _Float16*>(wscales) + gc, sc_lds + 256 * wave);
+            else if (MODE == 0) dma4p(reinterpret_cast<const _Float16*>(wszs) + gc, sc_lds + 512 + 256 * (wave - 2));
+        }
+        {                                              // waves 0-3: token scale of 64 tokens each; waves 4-7: token sums
+            int m = tm0 + 64 * (wave & 3) + ln;
+            m = m < M ? m : M - 1;
+            if (wave < 4) dma2p(reinterpret_cast<const _Float16*>(ascales) + m, sc_lds + 1024 + 256 * wave);
+            else if (MODE == 0) dma2p(reinterpret_cast<const _Float16*>(assums) + m, sc_lds + 2048 + 256 * (wave - 4));
+        }
+    };
+    // Round 6: the stream of stages runs ACROSS tile boundaries.  While the last NS - 1 stages of a tile compute, stage indices
+    // beyond the tile (u >= nh, pair >= nh / 2) are the FIRST stages of the workgroup's next tile: same per-lane offsets (the next
+    // tile's token rows are a wave-uniform distance away when neither tile is clipped by M), the next tile's scalar bases.
+    // Before, the DMA engine idled from stage nh - 6 to the fill behind the epilogue's barrier - with the k loop within 10 % of a
+    // CU's LDS-DMA fill rate that pause is throughput lost: 12.5 us per tile whatever K (65 536 x 4 096 x K: 22.4 / 33.8 / 52.2 /
+    // 93.4 us per tile at K = 1024 / 2048 / 4096 / 8192 = 0.62 us per stage + 12.5).
+    const uint8_t* w_base_n = nullptr;                // (valid while `stream`)
+    const int8_t* m_base_n = nullptr;
+    long long a_delta_n = 0;
     auto issue_a = [&](int pr, int pslot, int i) {                 // instruction i of activation pair pr (stages 2pr, 2pr+1)
-        dma16(a_off[i], A + (size_t)pr * 128, lds0 + pslot * APAIR + (i * 8 + wave) * 1024);
+        const bool nx = pr >= (nh >> 1);                           // wave-uniform
+        const int8_t* base = nx ? A + a_delta_n + (size_t)(pr - (nh >> 1)) * 128 : A + (size_t)pr * 128;
+        dma16(a_off[i], base, lds0 + pslot * APAIR + (i * 8 + wave) * 1024);
     };
     auto issue_w = [&](int u, int slot, int i) {                   // i = 0: weights of stage u, 1: its per-group meta
-        if (i == 0) dma16(w_off, w_base + (size_t)u * 1024, lds0 + (NS / 2) * APAIR + slot * WSTAGE + wave * 1024);
-        else dma4(m_off, m_base + (size_t)(u >> 1) * N, lds0 + (NS / 2) * APAIR + NS * WSTAGE + slot * 512 + (wave & 1) * 256);
+        const bool nx = u >= nh;
+        const int uu = nx ? u - nh : u;
+        if (i == 0) dma16(w_off, (nx ? w_base_n : w_base) + (size_t)uu * 1024, lds0 + (NS / 2) * APAIR + slot * WSTAGE + wave * 1024);
+        else dma4(m_off, (nx ? m_base_n : m_base) + (size_t)(uu >> 1) * N, lds0 + (NS / 2) * APAIR + NS * WSTAGE + slot * 512 + (wave & 1) * 256);
     };
     // Issue order of a wave (vmcnt retires in order): W(0), then for q = 0, 1, ...: A(q), W(2q+1), W(2q+2).  The
     // prologue issues W(0..4), A(0), A(1); stage u issues W(u+5) and, when u is even, A(u/2 + 2) before it.  Stage v
@@ -337,8 +379,11 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
     using c1 = std::integral_constant<int, 1>;
     int tile = blockIdx.x;
     setup(tile);
+    if (PERSIST) issue_scales(m0, n0);
     if (!(DBG & 2)) issue_fill();
     bool first = true;
+    bool streamed = false;            // this tile's first NS - 1 stages were requested during the previous tile's last stages
+    int slot = 0;                     // ring position of the stage about to run (continues across streamed tile boundaries)
     while (true) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -346,18 +391,22 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
             for (int cl = 0; cl < 4; ++cl) acc[mt][cl] = (v4i){0, 0, 0, 0};
         // first tile: W(0), A(0), W(1) have landed, the rest of the fill stays in flight.  Later tiles: the fill was issued
         // before the previous tile's epilogue - everything (its stores included) is complete
+        // (streamed: the steady-state count - the requests of the last stages are its fill; the epilogue's stores are younger, so
+        //  "at most 3 NW + NA2 outstanding" can only over-wait)
         if (first) wait_vm_dyn((DBG & 2) ? 0 : allowed(0));
+        else if (streamed) wait_vm<3 * NW + NA2>();
         else wait_vm<0>();
         first = false;
         raw_barrier();
+        if (!streamed) slot = 0;
         {
-            const Raw q0 = read_w(0);
+            const Raw q0 = read_w(slot);
 #pragma unroll
-            for (int t = 0; t < PD; ++t) bq[t] = read_b(0, 0, t);
+            for (int t = 0; t < PD; ++t) bq[t] = read_b(slot >> 1, 0, t);
 #pragma unroll
             for (int cl = 0; cl < 4; ++cl) a0[cl] = build(q0, cl);
         }
-        int u = 0, slot = 0;
+        int u = 0;
         for (; u + NS < nh; u += 2) {                  // steady state: both stages of the pair prefetch, no branches
             if (u) wait_vm<(DBG & 2) ? 0 : 3 * NW + NA2>();        // (u = 0: the fill's wait and barrier)
             if (u && !(DBG & 8)) raw_barrier();
@@ -367,6 +416,32 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
             if (!(DBG & 8)) raw_barrier();
             stage(c1{}, std::true_type{}, true, true, u + 1, slot, a1, a0);
             slot = slot + 1 == NS ? 0 : slot + 1;
+        }
+        // the next tile of this workgroup, if its first stages can ride on this tile's last ones: both tiles inside M (their
+        // token rows then differ by a wave-uniform distance) and K long enough for the fill pattern W(0..4), A(0), A(1)
+        const int next = tile + (int)gridDim.x;
+        bool stream = false;
+        if (PERSIST && !(DBG & 2) && next < ntiles && nh >= NS + 2 && m0 + BM <= M) {
+            int bmn, bnn;
+            tile_coords(next, bmn, bnn);
+            if (bmn * BM + BM <= M) {
+                stream = true;
+                a_delta_n = (long long)(bmn * BM - m0) * K;
+                w_base_n = W + (size_t)trow(bnn * BN / 64, 0) * KT * 512;
+                m_base_n = ((wave & 1) ? zeros : scales8) + chan32(bnn * BN / 64, 0);
+            }
+        }
+        if (stream) {
+            for (; u < nh; u += 2) {                   // the last stages: steady-state issue pattern, indices beyond the tile = the next one's
+                wait_vm<3 * NW + NA2>();
+                if (!(DBG & 8)) raw_barrier();
+                stage(c0{}, std::true_type{}, true, true, u, slot, a0, a1);
+                slot = slot + 1 == NS ? 0 : slot + 1;
+                wait_vm<3 * NW + NA2>();
+                if (!(DBG & 8)) raw_barrier();
+                stage(c1{}, std::true_type{}, true, true, u + 1, slot, a1, a0);
+                slot = slot + 1 == NS ? 0 : slot + 1;
+            }
         }
         for (; u < nh; u += 2) {                       // drain
             if (u) {
@@ -383,7 +458,6 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
 
         // ---- fused epilogue -------------------------------------------------------------------------------------
         const int em0 = m0, en0 = n0;                  // (m0 / n0 move on to the next tile below)
-        const int next = tile + (int)gridDim.x;
         const int lane_e = fresh(lane);
         const int li = lane_e & 15, g = lane_e >> 4;   // (shadow the loop's copies, see `fresh`)
         const int ncol0 = chan32(en0 / 64 + wn, g >> 1) + 4 * (g & 1);
@@ -408,21 +482,21 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
         // compiler places after the fill would also wait for the fill (vmcnt retires in order)
         h4 ws4[4], wz4[4];
         _Float16 sa_h[MT], ss_h[MT];
-#pragma unroll
-        for (int cl = 0; cl < 4; ++cl) {
-            ws4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wscales) + ncol0 + 8 * cl);
-            if (MODE == 0) wz4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wszs) + ncol0 + 8 * cl);
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            int m = mrow0 + 16 * mt;
-            m = m < M ? m : M - 1;
-            sa_h[mt] = reinterpret_cast<const _Float16*>(ascales)[m];
-            if (MODE == 0) ss_h[mt] = reinterpret_cast<const _Float16*>(assums)[m];
-        }
-        if (PERSIST) {
+        if (PERSIST) {                                 // staged by LDS-DMA one tile ago (issue_scales); every wave's DMA of it is long complete
+            const int lcol = ACT ? ((g >> 1) * 128 + 32 * wn + 4 * (g & 1)) : (64 * wn + 32 * (g >> 1) + 4 * (g & 1));
 #pragma unroll
             for (int cl = 0; cl < 4; ++cl) {
+                ws4[cl] = *reinterpret_cast<const h4*>(s_sc + 2 * (lcol + 8 * cl));
+                if (MODE == 0) wz4[cl] = *reinterpret_cast<const h4*>(s_sc + 512 + 2 * (lcol + 8 * cl));
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int tl = wm * (16 * MT) + 16 * mt + li;
+                sa_h[mt] = *reinterpret_cast<const _Float16*>(s_sc + 1024 + 4 * tl);
+                if (MODE == 0) ss_h[mt] = *reinterpret_cast<const _Float16*>(s_sc + 2048 + 4 * tl);
+            }
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl) {           // read BEFORE the barrier behind which the next tile's operands are requested
                 asm volatile("" : "+v"(ws4[cl]));
                 if (MODE == 0) asm volatile("" : "+v"(wz4[cl]));
             }
@@ -431,18 +505,36 @@ __global__ __launch_bounds__(512, 1) void w4a8_gemm_tiled(const int8_t* __restri
                 asm volatile("" : "+v"(sa_h[mt]));
                 if (MODE == 0) asm volatile("" : "+v"(ss_h[mt]));
             }
+        } else {
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl) {
+                ws4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wscales) + ncol0 + 8 * cl);
+                if (MODE == 0) wz4[cl] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(wszs) + ncol0 + 8 * cl);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                int m = mrow0 + 16 * mt;
+                m = m < M ? m : M - 1;
+                sa_h[mt] = reinterpret_cast<const _Float16*>(ascales)[m];
+                if (MODE == 0) ss_h[mt] = reinterpret_cast<const _Float16*>(assums)[m];
+            }
         }
         raw_barrier();                                 // the rings are dead: every wave left the k loop
-        if (PERSIST && next < ntiles) {                // next tile's fill: pair slots 0, 1 and weight slots 0..4
+        // the pair slot of this tile's LAST stages: dead now, refilled only by the next tile's first stage (behind the barrier at
+        // the top of the tile) - the staging rows below live there (not streamed: the ring restarts, that slot is pair slot 2)
+        const int ps_last = stream ? ((slot == 0 ? NS - 1 : slot - 1) >> 1) : 2;
+        if (PERSIST && next < ntiles) {                // next tile: its fill is already in flight (streamed) or issued here
             setup(next);
-            issue_fill();
+            issue_scales(m0, n0);
+            if (!stream) issue_fill();
         }
+        streamed = stream;
         // The fp16 tile of this wave goes through LDS, 16 tokens x 64 channels at a time, so that every store
         // instruction writes whole 128-byte rows (the accumulator layout would scatter 8-byte pieces over 32 lines per
         // instruction).  The staging rows live in activation pair slot 2, which the fill does not touch; they are
         // written and read by the same wave: an LDS wait, no barrier.
         constexpr int RS = 144;                        // staged row stride (bytes): 128 + 16 keeps 16-byte alignment
-        uint8_t* const st = a_ring + (PERSIST ? 2 * APAIR : 0) + wave * (16 * RS);
+        uint8_t* const st = a_ring + (PERSIST ? ps_last * APAIR : 0) + wave * (16 * RS);
         _Float16* const orow = reinterpret_cast<_Float16*>(out) + en0 + wn * 64 + (lane_e & 7) * 8;
         // The per-channel convention (qs_set_gemm_epilogue) is a wave-uniform BRANCH around two copies of the loop, not a per-element
         // select (round 6): with the run-time flag inside epi_per_chn the compiler evaluated both forms of every output and picked one -
@@ -514,7 +606,7 @@ int launch_tiled(const int8_t* A, const uint8_t* W, const int8_t* zeros, const i
                  hipStream_t stream) {
     auto kern = w4a8_gemm_tiled<MT, MODE, OUTK, DBG>;
     constexpr int BM = 32 * MT;
-    const size_t smem = (size_t)NS * (BM * 64 + WSTAGE + 512);   // (the epilogue's 18 KiB of staging rows alias the rings)
+    const size_t smem = (size_t)NS * (BM * 64 + WSTAGE + 512) + 3072;   // rings + the staged epilogue operands (the epilogue's 18 KiB of staging rows alias the rings)
     static bool configured_dev[QS_MAX_DEVICES] = {};   // the attribute belongs to the (kernel, device) pair
     bool& configured = configured_dev[qs_device_slot()];
     if (!configured) {
