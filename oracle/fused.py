@@ -58,8 +58,8 @@ def block_order_row_sum(contrib):
     """The row sum of invoke_quant_fuse_sum (and of the fusions that end in it: silu_and_mul + quant, decode attention + quant)
     exactly as this library orders it since round 6 (qserve_amd/csrc/row_ops.h reduce_max_blocksum): the row is cut into
     512-element blocks = 64 chunks of 8; lane l of a block adds the 8 elements of chunk l left to right (from +0; a chunk beyond
-    the row is +0), the 64 lanes go through the wave butterfly (xor 32, 16, 8, 4, 2, 1), and the block sums are added left to
-    right starting from block 0.  Independent of how many threads a kernel runs - which is what lets the workgroups of the decode
+    the row is +0), the 64 lanes go through the wave butterfly (xor 32, 16, 8, 4, 2, 1), and the block sums through ONE MORE wave
+    butterfly with lane b = block b and -0.0 in the lanes beyond the row (a fixed tree of depth 6 whatever the row length).  Independent of how many threads a kernel runs - which is what lets the workgroups of the decode
     attention (each holds G x 128 values of the row = whole blocks for G = 4, 8) reproduce invoke_quant_fuse_sum's bits from
     one published partial each.  contrib: float32 [T, H] (H % 8 == 0)."""
     contrib = np.asarray(contrib, np.float32)
@@ -72,10 +72,10 @@ def block_order_row_sum(contrib):
     for e in range(8):
         acc = (acc + a[..., e]).astype(np.float32)
     blk = _wave64_butterfly_sum(acc)                                  # [T, nblk]
-    tot = blk[:, 0]
-    for k in range(1, nblk):
-        tot = (tot + blk[:, k]).astype(np.float32)
-    return tot
+    assert nblk <= 64, "one lane per block (rows up to 32 768 elements)"
+    lanes = np.full((T, 64), -0.0, np.float32)                        # -0.0 = the identity of fp32 addition (x + -0 = x, also for +-0)
+    lanes[:, :nblk] = blk
+    return _wave64_butterfly_sum(lanes)
 
 
 def quant_per_token(x, with_sum=False, sum_order="exact"):

@@ -845,17 +845,21 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (ln == hkv) g = mine;                                           // own values from registers, not from memory
-                float am = ln < num_kv_heads ? __builtin_bit_cast(float, g.x) : 0.f;
+                // (scalar copies first: __builtin_bit_cast of a vector-element lvalue reads element 0)
+                const u32 gx = g.x, gy = g.y, gz = g.z;
+                float am = ln < num_kv_heads ? __builtin_bit_cast(float, gx) : 0.f;
                 am = wave_max(am);
-                float tot = 0.f;
-                for (int j = 0; j < num_kv_heads; ++j) {
-                    tot = tot + __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)g.y, j));
-                    QS_SEQ(tot);
-                    if (G == 8) {
-                        tot = tot + __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)g.z, j));
-                        QS_SEQ(tot);
-                    }
+                // the row sum: one more wave butterfly over the block sums, lane b = block b of the row, -0.0 beyond it (row_ops.h
+                // reduce_max_blocksum).  G = 4: block j is workgroup j's; G = 8: blocks 2 j, 2 j + 1
+                float bs;
+                if (G == 4) {
+                    bs = ln < num_kv_heads ? __builtin_bit_cast(float, gy) : -0.0f;
+                } else {
+                    const int src = (ln >> 1) < num_kv_heads ? (ln >> 1) : 0;
+                    const int yv = __builtin_amdgcn_ds_bpermute(4 * src, (int)gy), zv = __builtin_amdgcn_ds_bpermute(4 * src, (int)gz);
+                    bs = (ln >> 1) < num_kv_heads ? __builtin_bit_cast(float, (ln & 1) ? zv : yv) : -0.0f;
                 }
+                const float tot = wave_sum(bs);
                 if (ln == 0) {
                     sm[0] = am;
                     sm[1] = tot;

@@ -157,7 +157,7 @@ __device__ __forceinline__ void reduce_max_sum(float (&mx)[NVW / PW], float (&su
 
 // invoke_quant(_fuse_sum)'s statistics (round 6).  The row sum is DEFINED over 512-element blocks (64 chunks of 8): lane l of the
 // wave that owns a block adds the 8 elements of chunk l left to right (from +0), the 64 lanes go through the wave butterfly, and the
-// block sums are added left to right - oracle.fused.block_order_row_sum.  Independent of the number of threads a kernel runs, and
+// (at most 64) block sums through one more wave butterfly, lane b = block b, -0.0 beyond the row - oracle.fused.block_order_row_sum.  Independent of the number of threads a kernel runs, and
 // reproducible by ANY holder of a whole block: the decode attention's workgroups (G x 128 values of a row each) publish their
 // block sums and every one of them ends with the same bits as invoke_quant_fuse_sum over the finished row (attention_mfma.hip).
 // mx[j], sum[j][c]: virtual wave j's maximum and its chain over chunk set c (block c * NVW + wave + j * PW); sm: NVW floats,
@@ -182,14 +182,13 @@ __device__ __forceinline__ void reduce_max_blocksum(float (&mx)[NVW / PW], float
     float r = sm[0];
 #pragma unroll
     for (int w = 1; w < NVW; ++w) r = fmaxf(r, sm[w]);
+    // the block sums combined by ONE more wave butterfly - lane b holds block b's sum, lanes beyond the row hold -0.0 (the identity
+    // of fp32 addition: x + -0 = x for every x, +0 and -0 included) -, by wave 0 only (only thread 0 stores the row sum).  A fixed tree
+    // of depth 6 whatever the row length.  (As a chain of dependent adds, first on every thread, then on wave 0, it cost the 65 536-row
+    // quantiser of the prompt phase 28 % / 14 %.)
     float s = 0.f;
-    if (want_sum) {
-        s = sm2[0];
-        for (int b = 1; b < nblk; ++b) {
-            s = s + sm2[b];
-            QS_SEQ(s);
-        }
-    }
+    static_assert(NC * NVW <= 64, "one lane per block sum");
+    if (want_sum && wave == 0) s = wave_sum(lane < nblk ? sm2[lane] : -0.0f);
     mx_out = r;
     sum_out = s;
 }
