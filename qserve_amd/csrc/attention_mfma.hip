@@ -788,7 +788,7 @@ __global__ __launch_bounds__(NWT * 64, 4) void decode_attention_mfma_kernel(
             // from registers) and quantises its OWN values: 16 bytes per workgroup cross the chip instead of 1 KiB, and the row's
             // work is spread over the Hkv workgroups instead of waiting for the last one.  invoke_quant_fuse_sum's row sum is defined
             // block by block (row_ops.h reduce_max_blocksum, oracle.fused.block_order_row_sum): the block sums travel, every workgroup
-            // adds them left to right - qout / qscale / qsum are BIT-IDENTICAL to invoke_quant(_fuse_sum)(out), as before.
+            // puts them through the same final butterfly - qout / qscale / qsum are BIT-IDENTICAL to invoke_quant(_fuse_sum)(out), as before.
             // In-run against the payload form (kflags & 1024 = qs_set_attention_variant(7), kept for the other group sizes):
             // bs = 64: 20.4 -> 19.9 us at 1 033 tokens, equal at 1 535; bs = 128 (BASELINE config 3): 37.0 -> 34.5 us
             // (profiles/round6_attn_allgather.txt).  Waiting for LATER-dispatched workgroups is safe under in-order dispatch: the
