@@ -116,7 +116,10 @@ int qs_w4a8_per_group_gemm_planes(const int8_t* in_feats, const int8_t* kernel, 
 int qs_w8a8_gemm(const int8_t* in_feats, const int8_t* kernel, const void* wscales, const void* ascales,
                  void* out_feats, int M, int N, int K, qs_stream_t stream);
 
-/* Kernel-variant selection for benchmarking / A-B tests (process-wide; default -1 = the measured heuristic).  EVERY
+/* Kernel-variant selection for benchmarking / A-B tests (process-wide; default -1 = the measured heuristic).  Like every
+ * qs_set_* / qs_debug_* switch of this header it is a relaxed atomic inside the library: setting it while another host thread
+ * launches is not a data race - that launch sees the old or the new value -, but it is one value for the whole process, not a
+ * per-stream or per-thread configuration.  EVERY
  * variant of the shipped library computes the same results; the timing experiments that switch kernel parts off (wrong
  * results by design) exist only in libraries built with -DQS_TIMING (python -m qserve_amd.build --timing ->
  * libqserve_amd_timing.so, loaded by the measurement scripts through QS_AMD_LIBRARY) and are ignored otherwise:
@@ -417,7 +420,7 @@ int qs_stream_scratch_unbind(qs_stream_t stream);
  * by shuffles} per 64-value block. */
 int qs_debug_wave_reduce_selftest(const float* in, float* out, int n, qs_stream_t stream);
 
-/* A/B hook of the prefill attention provider (process-wide, not thread-safe): 0 [default] = the round-6 kernel (Q fragments
+/* A/B hook of the prefill attention provider (process-wide, see qs_set_gemm_variant): 0 [default] = the round-6 kernel (Q fragments
  * complete before the key loop, no accumulator copies in it, lazy running maximum, whole-row output through LDS); 1 = the
  * kernel of rounds 2-5.  Both compute the same softmax within the provider's tolerance (tests/test_flash_gpu.py runs both).
  * QS_EINVAL for any other value. */

@@ -592,7 +592,7 @@ int qs_launch_decode_mfma8(int G, dim3 grid, hipStream_t st, const _Float16* q, 
 // 0 = MFMA kernel for KV4 with the split-KV heuristic (default), 1 = VALU kernel everywhere, 2 = prefill writer in its
 // per-lane form (no RoPE table), 3 = KV4 MFMA kernel whose service wave always owns pages (the round-2 form: A/B),
 // 100 + n = MFMA kernel with exactly n KV splits (A/B tests)
-static int g_attn_variant = 0;
+static qs_flag g_attn_variant = 0;
 extern "C" void qs_set_attention_variant(int variant) { g_attn_variant = variant; }
 
 extern "C" int qs_single_query_attention(const void* q, const void* k, const void* v, const int64_t* kv_pointers,

@@ -1,6 +1,7 @@
 // common.h -- shared helpers for the gfx950 kernels of libqserve_amd.so
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -88,7 +89,11 @@ __device__ __forceinline__ float epi_per_group(int acc, float ws, float sa) {
     const float sc = ws * sa;
     return (float)acc * sc;
 }
-extern int g_epi_fma;   // gemm_w4a8.hip: qs_set_gemm_epilogue
+// Process-wide test / measurement hooks (kernel selection, A/B switches, fault injection) are relaxed atomics: flipping one
+// while another host thread launches is not a data race - that launch sees the old or the new value (include/qserve_amd.h says
+// which entry sets which).  They are still process-wide: not a per-stream or per-thread configuration.
+typedef std::atomic<int> qs_flag;
+extern qs_flag g_epi_fma;   // gemm_w4a8.hip: qs_set_gemm_epilogue
 extern unsigned long long* g_gemm_clk;   // gemm_w4a8.hip: qs_debug_gemm_clock_probe (device buffer, 2 words per workgroup) or null
 extern int g_gemm_clk_cap;               // workgroups the buffer holds
 
@@ -200,7 +205,7 @@ constexpr int QS_SLAB_SENTINEL = (int)0x80808080u;
 constexpr int QS_SPIN_CAP = 1 << 20;
 constexpr unsigned QS_ERR_GEMM_SEAM = 1u;     // K-slice seam: a partial tile never arrived
 constexpr unsigned QS_ERR_ATTN_HANDOVER = 2u; // attention + quant: a KV head's result row never arrived
-extern int g_inject_fault;                    // lib.hip: bit 0 next K-sliced ring GEMM launch, bit 1 next attention + quant launch
+extern qs_flag g_inject_fault;                    // lib.hip: bit 0 next K-sliced ring GEMM launch, bit 1 next attention + quant launch
 // Library scratch (split-K slabs, K-slice slabs, split-KV partials, hand-over rows, argmax keys) exists once per device (slot 0,
 // shared by every stream: launches that use it must not overlap) plus once per stream that asked for its own with
 // qs_stream_scratch_bind() (slots 1 .. QS_MAX_STREAM_SLOTS - 1; lib.hip).  qs_scratch_slot: the slot of a stream on the

@@ -484,7 +484,7 @@ extern "C" int qs_debug_flash_trace(void* buf) {
 }
 #endif
 
-static int g_flash_variant = 0;
+static qs_flag g_flash_variant = 0;
 // A/B hook (include/qserve_amd.h): 0 = lazy running maximum + tile loop unrolled over the two LDS buffers (round 6, default),
 // 1 = the loop of rounds 2-5.  The same softmax; the reference maximum differs, so low-order bits may.
 extern "C" int qs_debug_flash_variant(int variant) {

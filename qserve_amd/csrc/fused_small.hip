@@ -244,7 +244,7 @@ __global__ __launch_bounds__(NT) void silu_mul_quant_kernel(int8_t* __restrict__
     }
 }
 
-int g_row_refsum = 0;
+qs_flag g_row_refsum = 0;
 
 }  // namespace
 
@@ -506,7 +506,7 @@ ArgmaxWs* argmax_ws(hipStream_t stream) {
 }  // namespace
 
 bool qs_argmax_scratch_prealloc(hipStream_t stream) { return argmax_ws(stream) != nullptr; }
-int g_argmax_split = -1;   // qs_debug_argmax_split: -1 heuristic, 1 one workgroup per row, >= 2 forced split (tests, A/B)
+qs_flag g_argmax_split = -1;   // qs_debug_argmax_split: -1 heuristic, 1 one workgroup per row, >= 2 forced split (tests, A/B)
 extern "C" void qs_debug_argmax_split(int split) { g_argmax_split = split; }
 
 extern "C" int qs_argmax_rows(const void* x, int64_t* out, int rows, int n, int64_t row_stride, qs_stream_t stream) {

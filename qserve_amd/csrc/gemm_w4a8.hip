@@ -264,7 +264,7 @@ __global__ __launch_bounds__(MT <= 2 ? 512 : 256, 2) void w4a8_gemm_splitk(const
     }
 }
 
-int g_variant = QS_GEMM_DEFAULT;   // process-global test / measurement hook (include/qserve_amd.h qs_gemm_variant_code): not thread-safe
+qs_flag g_variant = QS_GEMM_DEFAULT;   // process-global test / measurement hook (include/qserve_amd.h qs_gemm_variant_code): not thread-safe
 }  // namespace
 thread_local QsGemmPlan g_qs_plan = {0, 0, {0, 0, 0, 0}};
 namespace {
@@ -402,7 +402,7 @@ int qs_launch_gemm_tiled(int mode, int outk, const int8_t* A, const uint8_t* W, 
 int qs_launch_gemm_wide(int mode, int outk, const int8_t* A, const uint8_t* W, const int8_t* zeros,
                         const int8_t* scales8, const void* wscales, const void* ascales, const void* wszs,
                         const void* assums, void* out, int M, int N, int K, int persist_mode, hipStream_t stream);
-extern int g_tiled_order;   // gemm_w4a8_tiled.hip
+extern qs_flag g_tiled_order;   // gemm_w4a8_tiled.hip
 namespace {
 
 constexpr int QS_UNFUSED = 1 << 20;   // internal: the chosen kernel has no activation epilogue
@@ -625,11 +625,11 @@ int dispatch(const int8_t* A, const int8_t* W, const int8_t* zeros, const int8_t
 
 }  // namespace
 
-extern int g_tiled_dbg;   // gemm_w4a8_tiled.hip: timing experiments (3100 + bits)
-extern int g_wide_order;  // gemm_w4a8_wide.hip: the same switch for the four-wave kernel
-extern int g_wide_dbg;    // gemm_w4a8_wide.hip: timing experiments (3400 + bits; QS_TIMING builds only)
-extern int g_ring_flags;  // gemm_w4a8_ring.hip: A/B switches of the decode kernel (5000 + bits), results unchanged
-extern int g_act_off;
+extern qs_flag g_tiled_dbg;   // gemm_w4a8_tiled.hip: timing experiments (3100 + bits)
+extern qs_flag g_wide_order;  // gemm_w4a8_wide.hip: the same switch for the four-wave kernel
+extern qs_flag g_wide_dbg;    // gemm_w4a8_wide.hip: timing experiments (3400 + bits; QS_TIMING builds only)
+extern qs_flag g_ring_flags;  // gemm_w4a8_ring.hip: A/B switches of the decode kernel (5000 + bits), results unchanged
+extern qs_flag g_act_off;
 extern "C" void qs_set_gemm_variant(int variant) {
     // the sticky families keep their own word (include/qserve_amd.h qs_gemm_variant_code)
     if (variant >= QS_GEMM_TILED_DEBUG_BASE && variant < QS_GEMM_TILE_ORDER_BASE) {
@@ -659,7 +659,7 @@ extern "C" void qs_set_gemm_variant(int variant) {
 // Per-channel epilogue convention (include/qserve_amd.h): 0 = (acc*ws)*sa - wz*ss with every operation rounded separately
 // (default), 1 = fmaf(acc*ws, sa, -(wz*ss)).  Process-wide, read at launch time by every W4A8 per-channel GEMM launch and by
 // qs_add_residual_rms_norm_general_planes (which finishes such a GEMM).
-int g_epi_fma = 0;
+qs_flag g_epi_fma = 0;
 extern "C" int qs_set_gemm_epilogue(int convention) {
     QS_REQUIRE(convention == 0 || convention == 1, "qs_set_gemm_epilogue: convention %d not in {0, 1}", convention);
     g_epi_fma = convention;
@@ -706,7 +706,7 @@ extern "C" int qs_w4a8_per_group_gemm(const int8_t* in_feats, const int8_t* kern
 // gate_up GEMM + silu_and_mul in one launch where the kernel family has the epilogue, as two launches through `tmp`
 // ([M, N] fp16) otherwise - bit-identical either way (the epilogue applies silu_and_mul's arithmetic to the fp16-rounded
 // GEMM outputs)
-int g_act_off = 0;   // qs_set_gemm_variant(3301 / 3300): always two launches / default (A/B, tests)
+qs_flag g_act_off = 0;   // qs_set_gemm_variant(3301 / 3300): always two launches / default (A/B, tests)
 namespace {
 template <int MODE>
 int gate_up_silu(const int8_t* in_feats, const int8_t* kernel, const int8_t* zeros, const int8_t* scales_i8,

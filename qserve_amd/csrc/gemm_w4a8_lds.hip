@@ -16,7 +16,7 @@
 //   * the two K-halves are summed exactly (int32) through LDS; fused fp32 epilogue as before.
 #include "common.h"
 
-extern int g_tiled_dbg;   // gemm_w4a8_tiled.hip: qs_set_gemm_variant(3100 + bits) timing experiments
+extern qs_flag g_tiled_dbg;   // gemm_w4a8_tiled.hip: qs_set_gemm_variant(3100 + bits) timing experiments
 namespace {
 
 constexpr int NS = 4;                 // ring depth (k-steps)

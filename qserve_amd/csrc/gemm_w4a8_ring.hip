@@ -37,7 +37,7 @@
 //   2048 = (set by the launcher) K slices across the XCDs (ring_coords); 4096 = keep every slice of a channel block on one XCD
 //        (the mapping of rounds 3-5; A/B of the activation traffic)
 //   8192 = (QS_TIMING libraries only, WRONG RESULTS) per-group launches without the level-2 dequant arithmetic
-int g_ring_flags = 0;
+qs_flag g_ring_flags = 0;
 
 namespace {
 

@@ -22,8 +22,8 @@
 #include "common.h"
 #include <type_traits>
 
-int g_tiled_dbg = 0;   // qs_set_gemm_variant(3100 + bits): 1 no MFMA, 2 no DMA, 4 no operand reads, 8 no barrier
-int g_tiled_order = 0; // qs_set_gemm_variant(3200 + 10 * p + mode): tile order A/B (mode 0 default, 1 M-fastest bands, 2 N-fastest
+qs_flag g_tiled_dbg = 0;   // qs_set_gemm_variant(3100 + bits): 1 no MFMA, 2 no DMA, 4 no operand reads, 8 no barrier
+qs_flag g_tiled_order = 0; // qs_set_gemm_variant(3200 + 10 * p + mode): tile order A/B (mode 0 default, 1 M-fastest bands, 2 N-fastest
                        // bands); p = 1: one workgroup per tile instead of per CU, p = 2: three workgroups walk all tiles (tests)
 namespace {
 

@@ -23,8 +23,8 @@
 #include <type_traits>
 #include <utility>
 
-int g_wide_order = 0;  // tile order A/B (same meaning as g_tiled_order % 10)
-int g_wide_dbg = 0;    // QS_TIMING builds only (qs_set_gemm_variant(3400 + bits), results WRONG by design): 1 no MFMA, 2 no DMA,
+qs_flag g_wide_order = 0;  // tile order A/B (same meaning as g_tiled_order % 10)
+qs_flag g_wide_dbg = 0;    // QS_TIMING builds only (qs_set_gemm_variant(3400 + bits), results WRONG by design): 1 no MFMA, 2 no DMA,
                        // 4 no activation operand reads, 8 no barrier, 16 no weight reads / unpack
 
 namespace {

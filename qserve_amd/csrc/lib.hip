@@ -15,7 +15,7 @@ extern "C" const char* qs_arch(void) { return "gfx950"; }
 extern "C" const char* qs_last_error(void) { return g_err; }
 
 // ---- bounded in-launch waits: status, reset, fault injection (common.h) ---------------------------------------------------------
-int g_inject_fault = 0;
+qs_flag g_inject_fault = 0;
 extern "C" int qs_device_status(int* error_bits) {
     QS_REQUIRE(error_bits, "qs_device_status: null output");
     *error_bits = 0;
